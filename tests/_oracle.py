@@ -1,0 +1,189 @@
+"""ctypes front-end for the CPU oracle (oracle/libd377_oracle.so). Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libd377_oracle.so")
+
+
+def build_oracle():
+    src = os.path.join(ORACLE_DIR, "d377_oracle.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def as_u8(x, n=None):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.uint8)).reshape(-1, 32)
+    if n is not None:
+        assert a.shape[0] == n
+    return a
+
+
+class Oracle:
+    OPS = {"roundtrip": 0, "scalar_mul_base": 1, "scalar_mul_var": 2, "encode_to_curve": 3, "sqrt_ratio_zeta": 4}
+
+    def __init__(self):
+        self.lib = ctypes.CDLL(build_oracle())
+        self.lib.d377o_init()
+        self.lib.d377o_run_threads.restype = ctypes.c_int
+
+    def _n(self, n):
+        return ctypes.c_size_t(n)
+
+    def sqrt_ratio_zeta(self, num, den):
+        num, den = as_u8(num), as_u8(den)
+        n = num.shape[0]
+        root = np.zeros((n, 32), np.uint8)
+        ws = np.zeros(n, np.uint8)
+        self.lib.d377o_sqrt_ratio_zeta(_p(num), _p(den), self._n(n), _p(root), _p(ws))
+        return root, ws
+
+    def decompress(self, enc):
+        enc = as_u8(enc)
+        n = enc.shape[0]
+        xyzt = np.zeros((n, 16), np.uint64)
+        st = np.zeros(n, np.uint8)
+        self.lib.d377o_decompress(_p(enc), self._n(n), _p(xyzt), _p(st))
+        return xyzt, st
+
+    def compress(self, xyzt):
+        xyzt = np.ascontiguousarray(xyzt, dtype=np.uint64).reshape(-1, 16)
+        n = xyzt.shape[0]
+        out = np.zeros((n, 32), np.uint8)
+        self.lib.d377o_compress(_p(xyzt), self._n(n), _p(out))
+        return out
+
+    def roundtrip(self, enc):
+        enc = as_u8(enc)
+        n = enc.shape[0]
+        out = np.zeros((n, 32), np.uint8)
+        st = np.zeros(n, np.uint8)
+        self.lib.d377o_roundtrip(_p(enc), self._n(n), _p(out), _p(st))
+        return out, st
+
+    def scalar_mul_base(self, k):
+        k = as_u8(k)
+        n = k.shape[0]
+        out = np.zeros((n, 32), np.uint8)
+        self.lib.d377o_scalar_mul_base(_p(k), self._n(n), _p(out))
+        return out
+
+    def scalar_mul_var(self, enc, k):
+        enc, k = as_u8(enc), as_u8(k)
+        n = enc.shape[0]
+        out = np.zeros((n, 32), np.uint8)
+        st = np.zeros(n, np.uint8)
+        self.lib.d377o_scalar_mul_var(_p(enc), _p(k), self._n(n), _p(out), _p(st))
+        return out, st
+
+    def encode_to_curve(self, r0):
+        r0 = as_u8(r0)
+        n = r0.shape[0]
+        out = np.zeros((n, 32), np.uint8)
+        self.lib.d377o_encode_to_curve(_p(r0), self._n(n), _p(out))
+        return out
+
+    def elligator_map_xyzt(self, r0):
+        r0 = as_u8(r0)
+        n = r0.shape[0]
+        out = np.zeros((n, 16), np.uint64)
+        self.lib.d377o_elligator_map_xyzt(_p(r0), self._n(n), _p(out))
+        return out
+
+    def hash_to_curve(self, r1, r2):
+        r1, r2 = as_u8(r1), as_u8(r2)
+        n = r1.shape[0]
+        out = np.zeros((n, 32), np.uint8)
+        self.lib.d377o_hash_to_curve(_p(r1), _p(r2), self._n(n), _p(out))
+        return out
+
+    def add_xyzt(self, p, q):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 16)
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros_like(p)
+        self.lib.d377o_add_xyzt(_p(p), _p(q), self._n(p.shape[0]), _p(out))
+        return out
+
+    def double_xyzt(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros_like(p)
+        self.lib.d377o_double_xyzt(_p(p), self._n(p.shape[0]), _p(out))
+        return out
+
+    def scalar_mul_xyzt(self, p, k):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 16)
+        k = as_u8(k)
+        out = np.zeros_like(p)
+        self.lib.d377o_scalar_mul_xyzt(_p(p), _p(k), self._n(p.shape[0]), _p(out))
+        return out
+
+    def eq_xyzt(self, p, q):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 16)
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(-1, 16)
+        eq = np.zeros(p.shape[0], np.uint8)
+        self.lib.d377o_eq_xyzt(_p(p), _p(q), self._n(p.shape[0]), _p(eq))
+        return eq
+
+    def generator_xyzt(self):
+        out = np.zeros(16, np.uint64)
+        self.lib.d377o_generator_xyzt(_p(out))
+        return out
+
+    def fq_from_bytes_mod_order(self, b):
+        b = as_u8(b)
+        out = np.zeros((b.shape[0], 4), np.uint64)
+        self.lib.d377o_fq_from_bytes_mod_order(_p(b), self._n(b.shape[0]), _p(out))
+        return out
+
+    def fq_from_bytes_checked(self, b):
+        b = as_u8(b)
+        out = np.zeros((b.shape[0], 4), np.uint64)
+        st = np.zeros(b.shape[0], np.uint8)
+        self.lib.d377o_fq_from_bytes_checked(_p(b), self._n(b.shape[0]), _p(out), _p(st))
+        return out, st
+
+    def fq_to_bytes(self, mont):
+        mont = np.ascontiguousarray(mont, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((mont.shape[0], 32), np.uint8)
+        self.lib.d377o_fq_to_bytes(_p(mont), self._n(mont.shape[0]), _p(out))
+        return out
+
+    def fq_mul_mont(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros_like(a)
+        self.lib.d377o_fq_mul_mont(_p(a), _p(b), self._n(a.shape[0]), _p(out))
+        return out
+
+    def fr_from_bytes_mod_order(self, b):
+        b = as_u8(b)
+        out = np.zeros((b.shape[0], 32), np.uint8)
+        self.lib.d377o_fr_from_bytes_mod_order(_p(b), self._n(b.shape[0]), _p(out))
+        return out
+
+    def fr_from_bytes_checked(self, b):
+        b = as_u8(b)
+        st = np.zeros(b.shape[0], np.uint8)
+        self.lib.d377o_fr_from_bytes_checked(_p(b), self._n(b.shape[0]), _p(st))
+        return st
+
+    def run_threads(self, op, a, b, threads):
+        """Timed-baseline driver: contiguous slices over `threads` pthreads."""
+        a = as_u8(a)
+        n = a.shape[0]
+        bb = as_u8(b) if b is not None else None
+        out = np.zeros((n, 32), np.uint8)
+        st = np.zeros(n, np.uint8)
+        used = self.lib.d377o_run_threads(self.OPS[op], _p(a), _p(bb) if bb is not None else None,
+                                          self._n(n), _p(out), _p(st), threads)
+        assert used > 0
+        return out, st, used

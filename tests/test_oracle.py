@@ -1,0 +1,282 @@
+"""Pins the CPU oracle (oracle/d377_oracle.c) and the big-integer model
+(oracle/d377_model.py) against every golden vector the reference's tests hold for the
+hot path (tests/golden/reference_kats.json cites file:line for each), against each
+other, and against the committed model vectors. CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import d377_model as m  # noqa: E402
+
+
+def hx(rows):
+    return [bytes(r).hex() for r in np.asarray(rows, dtype=np.uint8).reshape(-1, 32)]
+
+
+def frombytes(lst):
+    return np.array([list(bytes.fromhex(h)) if isinstance(h, str) else list(h) for h in lst], dtype=np.uint8)
+
+
+def mont(limbs):
+    return m.from_mont_limbs([int(x) for x in limbs])
+
+
+# --- reference KATs --------------------------------------------------------
+def test_basepoint_multiples(oracle, kats):
+    """tests/encoding.rs:55-95: each encoding decompresses, recompresses to itself and equals acc += B."""
+    hexes = kats["basepoint_multiples"]["hex"]
+    enc = frombytes(hexes)
+    xyzt, st = oracle.decompress(enc)
+    assert st.sum() == 0
+    assert hx(oracle.compress(xyzt)) == hexes
+    out, st2 = oracle.roundtrip(enc)
+    assert st2.sum() == 0 and hx(out) == hexes
+    gen = oracle.generator_xyzt()
+    acc = np.array([[0, 0, 0, 0] + [0] * 12], dtype=np.uint64)
+    ident, _ = oracle.decompress(frombytes([hexes[0]]))
+    acc = ident.copy()
+    for i in range(16):
+        assert oracle.eq_xyzt(acc, xyzt[i:i + 1])[0] == 1, i
+        assert hx(oracle.compress(acc)) == [hexes[i]]
+        acc = oracle.add_xyzt(acc, gen.reshape(1, 16))
+    # the same multiples through the scalar-mult paths
+    ks = np.zeros((16, 32), np.uint8)
+    ks[:, 0] = np.arange(16)
+    assert hx(oracle.scalar_mul_base(ks)) == hexes
+    g = np.tile(frombytes([kats["generator"]["hex"]]), (16, 1))
+    out, st = oracle.scalar_mul_var(g, ks)
+    assert st.sum() == 0 and hx(out) == hexes
+    # model agrees
+    for i, h in enumerate(hexes):
+        assert m.compress(m.scalar_mul(m.GENERATOR, i)).hex() == h
+
+
+def test_identity_and_generator(oracle, kats):
+    """tests/encoding.rs:20-52."""
+    ident_xyzt, st = oracle.decompress(frombytes([kats["identity"]["hex"]]))
+    assert st[0] == 0
+    x, y, z, t = [mont(ident_xyzt[0, 4 * i:4 * i + 4]) for i in range(4)]
+    assert (x, y, z, t) == (0, 1, 1, 0)
+    assert hx(oracle.compress(ident_xyzt)) == [kats["identity"]["hex"]]
+    first_ok = None
+    for b in range(1, 256):
+        _, st = oracle.decompress(np.array([[b] + [0] * 31], dtype=np.uint8))
+        if st[0] == 0:
+            first_ok = b
+            break
+    assert first_ok == kats["generator"]["min_first_byte"]
+    gx, st = oracle.decompress(frombytes([kats["generator"]["hex"]]))
+    gen = oracle.generator_xyzt()
+    assert oracle.eq_xyzt(gx, gen.reshape(1, 16))[0] == 1
+    assert [int(v) for v in gen[0:4]] == kats["generator"]["x_mont"]
+    assert [int(v) for v in gen[4:8]] == kats["generator"]["y_mont"]
+    assert [int(v) for v in gen[12:16]] == kats["generator"]["t_mont"]
+    # decompress returns exactly the affine generator (z = 1)
+    assert [int(v) for v in gx[0, 0:4]] == kats["generator"]["x_mont"]
+    assert [int(v) for v in gx[0, 4:8]] == kats["generator"]["y_mont"]
+
+
+def test_elligator_kats(oracle, kats):
+    """src/ark_curve/elligator.rs:86-207: affine (x, y) of the map for the 8 inputs."""
+    inputs = np.array(kats["elligator"]["inputs"], dtype=np.uint8)
+    xyzt = oracle.elligator_map_xyzt(inputs)
+    for i, (ex, ey) in enumerate(kats["elligator"]["expected_xy"]):
+        x, y, z, t = [mont(xyzt[i, 4 * j:4 * j + 4]) for j in range(4)]
+        zi = pow(z, -1, m.Q)
+        assert x * zi % m.Q == int(ex) and y * zi % m.Q == int(ey), i
+        assert x * y % m.Q == t * z % m.Q
+        # model: same affine point, same encoding
+        p = m.encode_to_curve(m.fq_from_le_bytes_mod_order(bytes(inputs[i])))
+        assert m.affine(p) == (int(ex), int(ey))
+    enc = oracle.encode_to_curve(inputs)
+    for i in range(8):
+        p = m.encode_to_curve(m.fq_from_le_bytes_mod_order(bytes(inputs[i])))
+        assert bytes(enc[i]) == m.compress(p)
+
+
+def test_sqrt_edge_cases(oracle, kats):
+    """src/ark_curve/invsqrt.rs:204-211 + proptest-regressions/invsqrt.txt:7."""
+    for c in kats["sqrt_edge_cases"]["cases"]:
+        nb = np.frombuffer(int(c["num"]).to_bytes(32, "little"), np.uint8)
+        db = np.frombuffer(int(c["den"]).to_bytes(32, "little"), np.uint8)
+        root, ws = oracle.sqrt_ratio_zeta(nb, db)
+        assert bool(ws[0]) == c["was_square"] and int.from_bytes(bytes(root[0]), "little") == c["root"]
+        assert m.sqrt_ratio_zeta(c["num"], c["den"]) == (c["was_square"], c["root"])
+    u = 1 << kats["regression_seeds"]["invsqrt_u_v_pow2"]
+    ub = np.frombuffer(u.to_bytes(32, "little"), np.uint8)
+    root, ws = oracle.sqrt_ratio_zeta(ub, ub)
+    r = int.from_bytes(bytes(root[0]), "little")
+    assert ws[0] == 1 and r * r % m.Q == 1       # u/v = 1 is square
+    assert (bool(ws[0]), r) == m.sqrt_ratio_zeta(u, u)
+
+
+def test_sqrt_contract_random(oracle):
+    """Property of src/ark_curve/invsqrt.rs:182-202 on seeded inputs, plus oracle == model."""
+    rng = np.random.default_rng(666)
+    n = 512
+    num = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    den = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    root, ws = oracle.sqrt_ratio_zeta(num, den)
+    for i in range(n):
+        u = m.fq_from_le_bytes_mod_order(bytes(num[i]))
+        v = m.fq_from_le_bytes_mod_order(bytes(den[i]))
+        r = int.from_bytes(bytes(root[i]), "little")
+        assert r < m.Q
+        if ws[i]:
+            assert u == v * r * r % m.Q
+        else:
+            assert m.ZETA * u % m.Q == v * r * r % m.Q
+        if i < 128:
+            assert (bool(ws[i]), r) == m.sqrt_ratio_zeta(u, v)
+
+
+def test_fq_examples(oracle, kats):
+    """src/fields/fq/arkworks.rs:603-673, src/fields/fq.rs:149-152."""
+    ex = kats["fq_examples"]
+    pb = np.array(ex["p_plus_1_bytes"], dtype=np.uint8)
+    mont1 = oracle.fq_from_bytes_mod_order(pb)
+    assert mont(mont1[0]) == ex["p_plus_1_reduces_to"]
+    assert bytes(oracle.fq_to_bytes(mont1)[0]) == (1).to_bytes(32, "little")
+    assert int.from_bytes(bytes(pb), "little") == m.Q + 1
+    _, st = oracle.fq_from_bytes_checked(np.full((1, 32), 0xFF, np.uint8))
+    assert st[0] == 1
+    z, st = oracle.fq_from_bytes_checked(np.zeros((1, 32), np.uint8))
+    assert st[0] == 0 and not z.any()
+    qm1 = sum(int(l) << (64 * i) for i, l in enumerate(ex["modulus_minus_one_limbs"]))
+    assert qm1 == m.Q - 1
+    a = oracle.fq_from_bytes_mod_order(np.frombuffer(qm1.to_bytes(32, "little"), np.uint8))
+    sq = oracle.fq_mul_mont(a, a)                      # (-1)^2 == 1
+    assert mont(sq[0]) == 1
+    # BigInt([1,1,1,1]) + BigInt([2,2,2,2]) == BigInt([3,3,3,3]); small products
+    one4 = sum(1 << (64 * i) for i in range(4))
+    assert (one4 + 2 * one4) % m.Q == 3 * one4 % m.Q
+    for x, y in [(1, 2), (1, 3), (1 << 192, 0)]:
+        xa = oracle.fq_from_bytes_mod_order(np.frombuffer(x.to_bytes(32, "little"), np.uint8))
+        ya = oracle.fq_from_bytes_mod_order(np.frombuffer(y.to_bytes(32, "little"), np.uint8))
+        assert mont(oracle.fq_mul_mont(xa, ya)[0]) == x * y % m.Q
+
+
+def test_fr_examples(oracle, kats):
+    """src/fields/fr/arkworks.rs:590-660, src/fields/fr.rs:129-132."""
+    ex = kats["fr_examples"]
+    pb = np.array(ex["p_plus_1_bytes"], dtype=np.uint8)
+    assert int.from_bytes(bytes(pb), "little") == m.R_ORDER + 1
+    assert bytes(oracle.fr_from_bytes_mod_order(pb)[0]) == (1).to_bytes(32, "little")
+    assert oracle.fr_from_bytes_checked(np.full((1, 32), 0xFF, np.uint8))[0] == 1
+    assert oracle.fr_from_bytes_checked(np.zeros((1, 32), np.uint8))[0] == 0
+    rm1 = sum(int(l) << (64 * i) for i, l in enumerate(ex["modulus_minus_one_limbs"]))
+    assert rm1 == m.R_ORDER - 1
+    assert oracle.fr_from_bytes_checked(np.frombuffer(rm1.to_bytes(32, "little"), np.uint8))[0] == 0
+    assert oracle.fr_from_bytes_checked(np.frombuffer((rm1 + 1).to_bytes(32, "little"), np.uint8))[0] == 1
+
+
+def test_regression_seeds(oracle, kats):
+    """tests/encoding.proptest-regressions:7-9: if it decodes, it must round-trip."""
+    seeds = np.array(kats["regression_seeds"]["encoding_bytes"], dtype=np.uint8)
+    out, st = oracle.roundtrip(seeds)
+    for i in range(3):
+        p = m.decompress(bytes(seeds[i]))
+        assert (p is None) == bool(st[i])
+        if st[i] == 0:
+            assert bytes(out[i]) == bytes(seeds[i])
+        else:
+            assert not out[i].any()
+    assert list(st) == [0, 0, 1]
+
+
+# --- committed model vectors ----------------------------------------------
+def test_vectors_sqrt(oracle, vectors):
+    v = vectors["sqrt_ratio_zeta"]
+    root, ws = oracle.sqrt_ratio_zeta(frombytes([c["num"] for c in v]), frombytes([c["den"] for c in v]))
+    assert hx(root) == [c["root"] for c in v]
+    assert list(ws) == [c["was_square"] for c in v]
+
+
+def test_vectors_encode_to_curve(oracle, vectors):
+    v = vectors["encode_to_curve"]
+    r0 = frombytes([c["r0"] for c in v])
+    assert hx(oracle.encode_to_curve(r0)) == [c["enc"] for c in v]
+    xyzt = oracle.elligator_map_xyzt(r0)
+    for i, c in enumerate(v):
+        assert [[int(x) for x in xyzt[i, 4 * j:4 * j + 4]] for j in range(4)] == c["xyzt_mont"]
+
+
+def test_vectors_decompress(oracle, vectors):
+    v = vectors["decompress"]
+    enc = frombytes([c["enc"] for c in v])
+    xyzt, st = oracle.decompress(enc)
+    out, st2 = oracle.roundtrip(enc)
+    assert list(st) == [c["status"] for c in v] == list(st2)
+    for i, c in enumerate(v):
+        if c["status"] == 0:
+            assert [[int(x) for x in xyzt[i, 4 * j:4 * j + 4]] for j in range(4)] == c["xyzt_mont"]
+            assert bytes(out[i]).hex() == c["recompressed"] == c["enc"]
+        else:
+            assert not xyzt[i].any() and not out[i].any()
+
+
+def test_vectors_scalar_mul(oracle, vectors):
+    v = vectors["scalar_mul_base"]
+    assert hx(oracle.scalar_mul_base(frombytes([c["scalar"] for c in v]))) == [c["enc"] for c in v]
+    v = vectors["scalar_mul_var"]
+    out, st = oracle.scalar_mul_var(frombytes([c["point"] for c in v]), frombytes([c["scalar"] for c in v]))
+    assert hx(out) == [c["enc"] for c in v]
+    assert list(st) == [c["status"] for c in v]
+    v = vectors["fr_mod_order"]
+    assert hx(oracle.fr_from_bytes_mod_order(frombytes([c["bytes"] for c in v]))) == [c["reduced"] for c in v]
+
+
+def test_vectors_hash_to_curve(oracle, vectors):
+    v = vectors["hash_to_curve"]
+    out = oracle.hash_to_curve(frombytes([c["r1"] for c in v]), frombytes([c["r2"] for c in v]))
+    assert hx(out) == [c["enc"] for c in v]
+
+
+# --- reference property tests replayed on seeded inputs ---------------------
+def test_roundtrip_if_successful(oracle):
+    """tests/encoding.rs:97-122 on 4096 raw strings + the small-s sweep."""
+    rng = np.random.default_rng(1)
+    raw = rng.integers(0, 256, (4096, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x1F                      # otherwise ~7/8 fail on the first check alone
+    out, st = oracle.roundtrip(raw)
+    ok = st == 0
+    assert 100 < ok.sum() < 4000
+    assert (out[ok] == raw[ok]).all() and not out[~ok].any()
+    for i in np.nonzero(ok)[0][:16]:
+        assert m.decompress(bytes(raw[i])) is not None
+    for i in np.nonzero(~ok)[0][:16]:
+        assert m.decompress(bytes(raw[i])) is None
+
+
+def test_scalar_mul_algebra(oracle):
+    """tests/operations.rs:19-60: aP + bP = (a+b)P, b(aP) = (ab)P, 3-term MSM = sum."""
+    rng = np.random.default_rng(2)
+    n = 24
+    P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ai = [m.fr_from_le_bytes_mod_order(bytes(x)) for x in a]
+    bi = [m.fr_from_le_bytes_mod_order(bytes(x)) for x in b]
+    apb = np.array([list(((x + y) % m.R_ORDER).to_bytes(32, "little")) for x, y in zip(ai, bi)], dtype=np.uint8)
+    atb = np.array([list((x * y % m.R_ORDER).to_bytes(32, "little")) for x, y in zip(ai, bi)], dtype=np.uint8)
+    aP, bP = oracle.scalar_mul_xyzt(P, a), oracle.scalar_mul_xyzt(P, b)
+    assert oracle.eq_xyzt(oracle.add_xyzt(aP, bP), oracle.scalar_mul_xyzt(P, apb)).all()
+    assert oracle.eq_xyzt(oracle.scalar_mul_xyzt(aP, b), oracle.scalar_mul_xyzt(P, atb)).all()
+    assert (oracle.compress(oracle.add_xyzt(aP, bP)) == oracle.compress(oracle.scalar_mul_xyzt(P, apb))).all()
+    assert oracle.eq_xyzt(oracle.double_xyzt(P), oracle.add_xyzt(P, P)).all()
+
+
+def test_threaded_driver_matches_serial(oracle):
+    rng = np.random.default_rng(3)
+    r0 = rng.integers(0, 256, (257, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (257, 32), dtype=np.uint8)
+    enc = oracle.encode_to_curve(r0)
+    out1, st1 = oracle.scalar_mul_var(enc, k)
+    out2, st2, used = oracle.run_threads("scalar_mul_var", enc, k, 4)
+    assert used == 4 and (out1 == out2).all() and (st1 == st2).all()
+    out3, _, _ = oracle.run_threads("encode_to_curve", r0, None, 3)
+    assert (out3 == enc).all()
