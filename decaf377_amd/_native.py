@@ -1,0 +1,80 @@
+"""ctypes binding of the C ABI declared in include/decaf377_amd.h.
+
+The shared library is built in-tree by `__graft_entry__.build()` (hipcc, gfx950) as
+decaf377_amd/lib/libdecaf377_amd.so.  There is no CPU fallback: if the library is missing
+or no MI355X is visible, loading / context creation raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdecaf377_amd.so")
+
+# every symbol include/decaf377_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "d377_version", "d377_device_count", "d377_last_error",
+    "d377_ctx_create", "d377_ctx_destroy", "d377_ctx_num_devices", "d377_ctx_device_id",
+    "d377_batch_sqrt_ratio_zeta", "d377_batch_decompress", "d377_batch_compress", "d377_batch_roundtrip",
+    "d377_batch_scalar_mul_base", "d377_batch_scalar_mul_var", "d377_batch_encode_to_curve",
+    "d377_batch_hash_to_curve",
+    "d377_batch_sqrt_ratio_zeta_dev", "d377_batch_decompress_dev", "d377_batch_compress_dev",
+    "d377_batch_roundtrip_dev", "d377_batch_scalar_mul_base_dev", "d377_batch_scalar_mul_var_dev",
+    "d377_batch_encode_to_curve_dev", "d377_batch_hash_to_curve_dev",
+]
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libdecaf377_amd.so; raises NativeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "decaf377_amd: %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (soname
+    # libamdhip64.so.7, the same as /opt/rocm's).  If this library pulled in the system copy
+    # first, a later `import torch` would map a second runtime that cannot open the GPU.
+    # Importing torch first makes both share torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.d377_version.restype = ctypes.c_char_p
+    lib.d377_last_error.restype = ctypes.c_char_p
+    lib.d377_device_count.restype = i32
+    lib.d377_ctx_create.argtypes = [ctypes.POINTER(i32), i32, ctypes.POINTER(vp)]
+    lib.d377_ctx_destroy.argtypes = [vp]
+    lib.d377_ctx_destroy.restype = None
+    lib.d377_ctx_num_devices.argtypes = [vp]
+    lib.d377_ctx_device_id.argtypes = [vp, i32]
+    host = {
+        "d377_batch_sqrt_ratio_zeta": [vp, vp, vp, sz, vp, vp],
+        "d377_batch_decompress": [vp, vp, sz, vp, vp],
+        "d377_batch_compress": [vp, vp, sz, vp],
+        "d377_batch_roundtrip": [vp, vp, sz, vp, vp],
+        "d377_batch_scalar_mul_base": [vp, vp, sz, vp],
+        "d377_batch_scalar_mul_var": [vp, vp, vp, sz, vp, vp],
+        "d377_batch_encode_to_curve": [vp, vp, sz, vp],
+        "d377_batch_hash_to_curve": [vp, vp, vp, sz, vp],
+    }
+    for name, args in host.items():
+        getattr(lib, name).argtypes = args
+        getattr(lib, name).restype = i32
+        dev = getattr(lib, name + "_dev")
+        dev.argtypes = [vp, i32, vp] + args[1:]
+        dev.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError("decaf377_amd native call failed (%d): %s" % (rc, load().d377_last_error().decode()))

@@ -1,0 +1,431 @@
+// curve.hpp -- per-lane decaf377 operations on top of fq29.hpp.
+//
+// Each function is the work ONE lane does for ONE group element; the kernels in
+// kernels.hip only add the batch indexing and the 32-byte record loads/stores.
+// Reference semantics (file:line relative to the reference crate):
+//   sqrt_ratio_zeta      src/ark_curve/invsqrt.rs:75-166 (Sarkar tables, same root)
+//   decompress           src/ark_curve/encoding.rs:32-83
+//   compress             src/ark_curve/encoding.rs:91-128
+//   elligator_map        src/ark_curve/elligator.rs:15-62
+//   ge_add / ge_double   src/min_curve/element.rs:291-322 / 119-136
+//   scalar multiplication: same group element as src/min_curve/element.rs:138-157, computed
+//   with signed 4-bit windows (encodings are canonical per group element, so the result
+//   bytes are identical).
+#pragma once
+#include "fq29.hpp"
+
+namespace d377 {
+
+#include "constants.inc"
+
+// ---- device tables (built once per context by the init kernels) -----------------------
+// gtab: 6 tables (g^(nu * 2^{0,8,16,24,32,40})), 256 entries each, 12 words per entry
+//       (9 limbs + 3 pad so an entry is three 16-byte loads).
+// s_lookup: perfect hash of the 256 elements g^-(nu * 2^39) (both tight representations)
+//       -> nu.  4096 one-byte slots.
+constexpr int GT_STRIDE = 12;
+constexpr int S_HASH_BITS = 12;
+struct SqrtTables {
+  const uint32_t* gtab;      // [6][256][GT_STRIDE]
+  const uint8_t* s_lookup;   // [1 << S_HASH_BITS]
+};
+
+#include "s_hash.inc"        // defines D377_S_HASH_K (searched offline, verified at init)
+
+D377_HD uint32_t s_hash(const fe& x) {
+  return ((x.l[0] ^ (x.l[1] << 3)) * D377_S_HASH_K) >> (32 - S_HASH_BITS);
+}
+
+D377_HD fe gt_load(const SqrtTables& T, int table, uint32_t idx) {
+  const uint32_t* p = T.gtab + ((size_t)table * 256 + idx) * GT_STRIDE;
+  fe r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4* p4 = reinterpret_cast<const uint4*>(p);
+  uint4 a = p4[0], b = p4[1], c = p4[2];
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x;
+#else
+  for (int i = 0; i < NL; ++i) r.l[i] = p[i];
+#endif
+  return r;
+}
+
+// ---- fixed exponentiations --------------------------------------------------------------
+D377_HD fe fe_sqr_n(fe x, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) x = fe_sqr(x);
+  return x;
+}
+
+// x^(2^47 - 1): 46 S + 9 M   (e_k = x^(2^k - 1); e_2k = e_k^(2^k) e_k; e_2k+1 = e_2k^2 x)
+D377_HD fe fe_pow_2_47_m1(const fe& x) {
+  fe e2 = fe_mul(fe_sqr(x), x);
+  fe e4 = fe_mul(fe_sqr_n(e2, 2), e2);
+  fe e5 = fe_mul(fe_sqr(e4), x);
+  fe e10 = fe_mul(fe_sqr_n(e5, 5), e5);
+  fe e11 = fe_mul(fe_sqr(e10), x);
+  fe e22 = fe_mul(fe_sqr_n(e11, 11), e11);
+  fe e23 = fe_mul(fe_sqr(e22), x);
+  fe e46 = fe_mul(fe_sqr_n(e23, 23), e23);
+  return fe_mul(fe_sqr(e46), x);
+}
+
+// x^((m-1)/2), m = (q-1)/2^47: sliding window (w = 4) over the fixed exponent, the schedule
+// is the byte table POW_M12_CHAIN (wave-uniform, so no divergence): 201 S + 36 M + table.
+D377_HD fe fe_pow_m12(const fe& x) {
+  fe x2 = fe_sqr(x);
+  fe t1 = x, t3 = fe_mul(t1, x2), t5 = fe_mul(t3, x2), t7 = fe_mul(t5, x2);
+  fe t9 = fe_mul(t7, x2), t11 = fe_mul(t9, x2), t13 = fe_mul(t11, x2), t15 = fe_mul(t13, x2);
+  fe acc = fe_zero();
+#pragma unroll 1
+  for (int i = 0; i < D377_POW_M12_LEN; ++i) {
+    const uint32_t e = POW_M12_CHAIN[i];
+    const int nsq = (int)(e >> 4), d = (int)(e & 15u);
+    fe f;
+    switch (d >> 1) {
+      case 0: f = t1; break;
+      case 1: f = t3; break;
+      case 2: f = t5; break;
+      case 3: f = t7; break;
+      case 4: f = t9; break;
+      case 5: f = t11; break;
+      case 6: f = t13; break;
+      default: f = t15; break;
+    }
+    if (i == 0) {
+      acc = f;
+    } else {
+      acc = fe_sqr_n(acc, nsq);
+      acc = fe_mul(acc, f);
+    }
+  }
+  return fe_sqr_n(acc, D377_POW_M12_TRAILING_SQ);
+}
+
+// zero test for a value that is a fe_mul/fe_sqr output (tight, < 2q): 0 or q
+D377_HD bool fe_mulout_is_zero(const fe& a) {
+  uint32_t o = 0, d = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { o |= a.l[i]; d |= a.l[i] ^ QL[i]; }
+  return o == 0 || d == 0;
+}
+
+// ---- sqrt_ratio_zeta ----------------------------------------------------------------------
+// src/ark_curve/invsqrt.rs:75-166.  `den` must be a multiplication output (tight, < 2q).
+// NUM_IS_ONE: the callers on the group path always pass num = 1 (encoding.rs:57,100;
+// elligator.rs:26); the generic form is used by the raw batch entry point.
+template <bool NUM_IS_ONE>
+D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, const fe& num, const fe& den, fe* res) {
+  const bool den_zero = fe_mulout_is_zero(den);
+  bool num_zero = false;
+  if (!NUM_IS_ONE) num_zero = fe_mulout_is_zero(num);
+
+  fe s = fe_pow_2_47_m1(den);                       // invsqrt.rs:88-89
+  fe t_ = fe_mul(fe_sqr(s), den);                   // :90
+  fe w = NUM_IS_ONE ? fe_mul(fe_pow_m12(t_), s)     // :91
+                    : fe_mul(fe_pow_m12(fe_mul(num, t_)), s);
+  fe v = fe_mul(w, den);                            // :93
+  fe uv = NUM_IS_ONE ? w : fe_mul(w, num);          // :94
+  fe x5 = fe_mul(uv, v);                            // :97
+  fe x4 = fe_sqr_n(x5, 8);                          // :101-107
+  fe x3 = fe_sqr_n(x4, 8);
+  fe x2 = fe_sqr_n(x3, 8);
+  fe x1 = fe_sqr_n(x2, 8);
+  fe x0 = fe_sqr_n(x1, 7);                          // :110
+
+  const uint64_t q0p = T.s_lookup[s_hash(x0)];      // :113
+  uint64_t t = q0p;
+  fe a1 = fe_mul(x1, gt_load(T, 4, (uint32_t)(t & 0xFF)));                       // :117-119
+  t += (uint64_t)T.s_lookup[s_hash(a1)] << 7;
+  fe a2 = fe_mul(fe_mul(x2, gt_load(T, 3, (uint32_t)(t & 0xFF))),
+                 gt_load(T, 4, (uint32_t)((t >> 8) & 0xFF)));                    // :122-126
+  t += (uint64_t)T.s_lookup[s_hash(a2)] << 15;
+  fe a3 = fe_mul(fe_mul(fe_mul(x3, gt_load(T, 2, (uint32_t)(t & 0xFF))),
+                        gt_load(T, 3, (uint32_t)((t >> 8) & 0xFF))),
+                 gt_load(T, 4, (uint32_t)((t >> 16) & 0xFF)));                   // :129-134
+  t += (uint64_t)T.s_lookup[s_hash(a3)] << 23;
+  fe a4 = fe_mul(fe_mul(fe_mul(fe_mul(x4, gt_load(T, 1, (uint32_t)(t & 0xFF))),
+                               gt_load(T, 2, (uint32_t)((t >> 8) & 0xFF))),
+                        gt_load(T, 3, (uint32_t)((t >> 16) & 0xFF))),
+                 gt_load(T, 4, (uint32_t)((t >> 24) & 0xFF)));                   // :137-143
+  t += (uint64_t)T.s_lookup[s_hash(a4)] << 31;
+  fe a5 = fe_mul(fe_mul(fe_mul(fe_mul(fe_mul(x5, gt_load(T, 0, (uint32_t)(t & 0xFF))),
+                                      gt_load(T, 1, (uint32_t)((t >> 8) & 0xFF))),
+                               gt_load(T, 2, (uint32_t)((t >> 16) & 0xFF))),
+                        gt_load(T, 3, (uint32_t)((t >> 24) & 0xFF))),
+                 gt_load(T, 4, (uint32_t)((t >> 32) & 0xFF)));                   // :146-153
+  t += (uint64_t)T.s_lookup[s_hash(a5)] << 39;
+
+  t = (t + 1) >> 1;                                                              // :155
+  const bool nonsq = (q0p & 1) != 0;
+  fe r = fe_select(nonsq, fe_mul(uv, fe_const(FE_NONSQUARE)), uv);               // :156-157
+  r = fe_mul(r, gt_load(T, 0, (uint32_t)(t & 0xFF)));
+  r = fe_mul(r, gt_load(T, 1, (uint32_t)((t >> 8) & 0xFF)));
+  r = fe_mul(r, gt_load(T, 2, (uint32_t)((t >> 16) & 0xFF)));
+  r = fe_mul(r, gt_load(T, 3, (uint32_t)((t >> 24) & 0xFF)));
+  r = fe_mul(r, gt_load(T, 4, (uint32_t)((t >> 32) & 0xFF)));
+  r = fe_mul(r, gt_load(T, 5, (uint32_t)((t >> 40) & 0xFF)));                    // :158-163
+
+  bool was_square = !nonsq;
+  // early-outs of invsqrt.rs:81-86, applied as selects so the wave stays converged
+  if (den_zero) { r = fe_zero(); was_square = false; }
+  if (!NUM_IS_ONE && num_zero) { r = fe_zero(); was_square = true; }
+  *res = r;
+  return was_square;
+}
+
+// ---- byte / word conversions -------------------------------------------------------------
+// 32 LE bytes (as 8 words, any 256-bit value) -> Montgomery-261, reduced mod q on the way
+// (Fq::from_le_bytes_mod_order, src/fields/fq.rs:90-102, for 32-byte inputs).
+D377_HD fe fe_from_words_mod_order(const uint32_t w[8]) {
+  return fe_mul(fe_from_words(w), fe_const(FE_R2));
+}
+// Montgomery-261 -> canonical 32 bytes (Fq::to_bytes_le)
+D377_HD void fe_to_bytes_words(const fe& a, uint32_t w[8]) { fe_to_words(fe_canon(a), w); }
+
+// full reduction of a tight value < 2q to [0, q)
+D377_HD fe fe_reduce_once(const fe& a) {
+  fe d;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    uint32_t t = a.l[i] - QL[i] - borrow;
+    borrow = t >> 31;
+    d.l[i] = (i < NL - 1) ? (t & MASK29) : t;
+  }
+  return fe_select(borrow != 0, a, d);
+}
+// q - c for canonical c != 0 (plain integers, tight limbs)
+D377_HD fe fe_canon_negate(const fe& c) {
+  fe d;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    uint32_t t = QL[i] - c.l[i] - borrow;
+    borrow = t >> 31;
+    d.l[i] = (i < NL - 1) ? (t & MASK29) : t;
+  }
+  return d;
+}
+
+// the reference's external element layout: 4 x u64 Montgomery limbs, R = 2^256
+// (Fq::from_montgomery_limbs, src/fields/fq/u64/wrapper.rs:82-85), as 8 x u32 words.
+D377_HD void fe_to_mont256_words(const fe& a, uint32_t w[8]) {
+  fe_to_words(fe_reduce_once(fe_mul(a, fe_const(FE_TO_MONT256))), w);
+}
+D377_HD fe fe_from_mont256_words(const uint32_t w[8]) {
+  return fe_mul(fe_from_words(w), fe_const(FE_FROM_MONT256));
+}
+
+// src/sign.rs:11-17
+D377_HD fe fe_abs(const fe& a) { return fe_select(fe_is_negative(a), fe_neg(a), a); }
+
+// ---- group ----------------------------------------------------------------------------------
+struct ge { fe x, y, z, t; };   // extended twisted Edwards, a = -1, d = 3021; x*y = z*t
+
+D377_HD ge ge_identity() {
+  ge r;
+  r.x = fe_zero(); r.y = fe_const(FE_ONE); r.z = fe_const(FE_ONE); r.t = fe_zero();
+  return r;
+}
+D377_HD ge ge_generator() {
+  ge r;
+  r.x = fe_const(FE_BX); r.y = fe_const(FE_BY); r.z = fe_const(FE_ONE); r.t = fe_const(FE_BT);
+  return r;
+}
+
+// src/min_curve/element.rs:291-322 (unified, complete: a = -1 is a square, d is not)
+D377_HD ge ge_add(const ge& p, const ge& q) {
+  fe a = fe_mul(fe_sub(p.y, p.x), fe_sub(q.y, q.x));
+  fe b = fe_mul(fe_add(p.y, p.x), fe_add(q.y, q.x));
+  fe c = fe_mul(fe_mul(fe_const(FE_K), p.t), q.t);
+  fe d = fe_mul(fe_dbl(p.z), q.z);
+  fe e = fe_sub(b, a), f = fe_sub(d, c), g = fe_add(d, c), h = fe_add(b, a);
+  ge r;
+  r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g); r.t = fe_mul(e, h);
+  return r;
+}
+
+// src/min_curve/element.rs:119-136
+D377_HD ge ge_double(const ge& p) {
+  fe a = fe_sqr(p.x), b = fe_sqr(p.y);
+  fe c = fe_dbl(fe_sqr(p.z));
+  fe ab = fe_add(a, b);
+  fe e = fe_sub(fe_sqr(fe_add(p.x, p.y)), ab);
+  fe g = fe_sub(b, a);          // d + b with d = -a
+  fe f = fe_sub(g, c);
+  fe h = fe_neg(ab);            // d - b
+  ge r;
+  r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g); r.t = fe_mul(e, h);
+  return r;
+}
+
+D377_HD ge ge_neg(const ge& p) {   // src/min_curve/element.rs:324-332
+  ge r = p;
+  r.x = fe_neg(p.x); r.t = fe_neg(p.t);
+  return r;
+}
+D377_HD ge ge_select(bool c, const ge& a, const ge& b) {
+  ge r;
+  r.x = fe_select(c, a.x, b.x); r.y = fe_select(c, a.y, b.y);
+  r.z = fe_select(c, a.z, b.z); r.t = fe_select(c, a.t, b.t);
+  return r;
+}
+
+// ---- encoding ------------------------------------------------------------------------------
+// Encoding::vartime_decompress, src/ark_curve/encoding.rs:32-83.  Returns status
+// (0 ok, 1 InvalidEncoding); on failure *out is unspecified (callers write zeros).
+D377_HD uint32_t ge_decompress(const SqrtTables& T, const uint32_t w[8], ge* out) {
+  uint32_t bad = (w[7] >> 29) != 0;                       // top three bits, encoding.rs:34
+  bad |= (uint32_t)words_geq(w, FQ_MODULUS_W_LIT);        // canonical, :43-44
+  bad |= (w[0] & 1u);                                     // s negative, :45
+  fe s = fe_mul(fe_from_words(w), fe_const(FE_R2));
+  fe ss = fe_sqr(s);                                      // :50
+  fe u1 = fe_sub(fe_const(FE_ONE), ss);                   // :51
+  fe u1sq = fe_sqr(u1);
+  fe u2 = fe_sub(u1sq, fe_mul(fe_const(FE_4D), ss));      // :54
+  fe v;
+  const bool was_square = fe_sqrt_ratio_zeta<true>(T, fe_zero(), fe_mul(u2, u1sq), &v);   // :57
+  bad |= (uint32_t)!was_square;                           // :58-60
+  fe two_s_u1 = fe_mul(fe_dbl(s), u1);                    // :63
+  if (fe_is_negative(fe_mul(two_s_u1, v))) v = fe_neg(v); // :64-67
+  out->x = fe_mul(fe_mul(two_s_u1, fe_sqr(v)), u2);       // :70
+  out->y = fe_mul(fe_mul(fe_add(fe_const(FE_ONE), ss), v), u1);   // :71
+  out->z = fe_const(FE_ONE);
+  out->t = fe_mul(out->x, out->y);
+  return bad;
+}
+
+// Element::vartime_compress, src/ark_curve/encoding.rs:91-128 -> canonical words of s
+D377_HD void ge_compress(const SqrtTables& T, const ge& p, uint32_t w[8]) {
+  const fe a_minus_d = fe_const(FE_A_MINUS_D);
+  fe u1 = fe_mul(fe_add(p.x, p.t), fe_sub(p.x, p.t));                       // :97
+  fe v;
+  (void)fe_sqrt_ratio_zeta<true>(T, fe_zero(), fe_mul(fe_mul(u1, a_minus_d), fe_sqr(p.x)), &v);  // :101
+  fe u2 = fe_abs(fe_mul(v, u1));                                            // :104
+  fe u3 = fe_sub(fe_mul(u2, p.z), p.t);                                     // :107
+  fe s = fe_mul(fe_mul(fe_mul(a_minus_d, v), u3), p.x);                     // :110
+  fe c = fe_canon(s);
+  const bool neg = (c.l[0] & 1u) != 0;                                      // .abs()
+  c = fe_select(neg, fe_canon_negate(c), c);
+  fe_to_words(c, w);                                                        // top bits are 0: s < q < 2^253
+}
+
+// Element::elligator_map, src/ark_curve/elligator.rs:15-62.  r0 in Montgomery-261.
+D377_HD ge ge_elligator_map(const SqrtTables& T, const fe& r0) {
+  const fe one = fe_const(FE_ONE), dma = fe_const(FE_D_MINUS_A), dd = fe_const(FE_D);
+  fe r = fe_mul(fe_const(FE_ZETA), fe_sqr(r0));                                   // :20
+  fe den = fe_mul(fe_sub(fe_mul(dd, r), dma), fe_sub(fe_mul(dma, r), dd));        // :22
+  fe num = fe_mul(fe_add(r, one), fe_const(FE_A_MINUS_2D));                       // :23
+  fe isri;
+  const bool iss = fe_sqrt_ratio_zeta<true>(T, fe_zero(), fe_mul(num, den), &isri);   // :25-26
+  isri = fe_select(iss, isri, fe_mul(isri, r0));                                  // twiddle, :28-38
+  fe s = fe_mul(isri, num);                                                       // :40
+  fe p = fe_mul(fe_mul(fe_mul(isri, s), fe_sub(r, one)), fe_const(FE_A_MINUS_2D_SQ));
+  fe t = fe_sub(fe_select(iss, fe_neg(p), p), one);                               // :41  (-sgn * ... - 1)
+  if (fe_is_negative(s) == iss) s = fe_neg(s);                                    // :43-45
+  fe e = fe_dbl(s);                                                               // :48
+  fe ss = fe_sqr(s);
+  fe f = fe_sub(one, ss);                                                         // 1 + a s^2, a = -1
+  fe g = fe_add(one, ss);                                                         // 1 - a s^2
+  ge o;
+  o.x = fe_mul(e, t); o.y = fe_mul(f, g); o.z = fe_mul(f, t); o.t = fe_mul(e, g); // :52-54
+  return o;
+}
+
+// ---- scalars -------------------------------------------------------------------------------
+// Fr::from_le_bytes_mod_order for 32 bytes (src/fields/fr.rs:82-94): k mod r, r ~ 2^250.2,
+// so at most 2^256/r < 54 subtractions: do it by conditional subtraction of 32r..r.
+D377_HD void fr_reduce_words(uint32_t k[8]) {
+#pragma unroll
+  for (int sh = 5; sh >= 0; --sh) {
+    uint32_t d[8];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      // (r << sh) word i
+      uint32_t lo = FR_ORDER_W_LIT[i] << sh;
+      if (sh > 0 && i > 0) lo |= FR_ORDER_W_LIT[i - 1] >> (32 - sh);
+      uint64_t t = (uint64_t)k[i] - lo - borrow;
+      d[i] = (uint32_t)t;
+      borrow = (t >> 63) & 1u;
+    }
+    // r << 5 still fits in 256 bits (r < 2^251)
+    if (borrow == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) k[i] = d[i];
+    }
+  }
+  // after subtracting multiples 32r..r once each the value may still be >= r only if it
+  // started >= 63r, impossible for a 256-bit value (2^256 / r < 54)
+}
+
+// signed radix-16 recoding of k < r < 2^251: k = sum d_i 16^i, d_i in [-8, 8), i = 0..63.
+// Packed as 64 nibbles (two's complement 4-bit) in 8 words.
+D377_HD void fr_recode_signed16(const uint32_t k[8], uint32_t digits[8]) {
+  uint32_t carry = 0;
+#pragma unroll
+  for (int wi = 0; wi < 8; ++wi) {
+    uint32_t outw = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t d = ((k[wi] >> (4 * j)) & 15u) + carry;
+      carry = (d >= 8u) ? 1u : 0u;          // d in 0..16; >= 8 means digit d-16 and carry
+      outw |= (d & 15u) << (4 * j);
+    }
+    digits[wi] = outw;
+  }
+  // k < 2^251 -> nibble 62 is <= 7 + carry, nibble 63 is the final carry (0 or 1): no overflow
+}
+D377_HD int fr_digit(const uint32_t digits[8], int i) {   // signed value of nibble i
+  uint32_t n = (digits[i >> 3] >> (4 * (i & 7))) & 15u;
+  return (int)(n ^ 8u) - 8;
+}
+
+// ---- scalar multiplication ----------------------------------------------------------------
+// [k]P with signed 4-bit windows, MSB first: 63 x (4 doublings + 1 table addition).
+// `Tab` is where the per-lane table 0..8 * P lives (global scratch on the GPU): it must
+// provide store(j, ge) and load(j) -> ge for j in 0..8.
+template <class Tab>
+D377_HD ge ge_scalar_mul_w4(const ge& p, const uint32_t digits[8], Tab& tab) {
+  tab.store(0, ge_identity());
+  tab.store(1, p);
+  ge acc = ge_double(p);
+  tab.store(2, acc);
+#pragma unroll 1
+  for (int j = 3; j <= 8; ++j) {
+    acc = ge_add(acc, p);
+    tab.store(j, acc);
+  }
+  int d = fr_digit(digits, 63);                 // 0 or 1
+  ge r = tab.load(d);
+#pragma unroll 1
+  for (int i = 62; i >= 0; --i) {
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) r = ge_double(r);
+    d = fr_digit(digits, i);
+    const int ad = d < 0 ? -d : d;
+    ge e = tab.load(ad);
+    e = ge_select(d < 0, ge_neg(e), e);
+    r = ge_add(r, e);
+  }
+  return r;
+}
+
+// [k]B from the shared table FB[i][j] = j * 16^i * B (i = 0..63, j = 0..8): 64 additions.
+template <class FTab>
+D377_HD ge ge_scalar_mul_base_w4(const uint32_t digits[8], const FTab& ftab) {
+  ge r = ge_identity();
+#pragma unroll 1
+  for (int i = 0; i < 64; ++i) {
+    const int d = fr_digit(digits, i);
+    const int ad = d < 0 ? -d : d;
+    ge e = ftab.load(i, ad);
+    e = ge_select(d < 0, ge_neg(e), e);
+    r = ge_add(r, e);
+  }
+  return r;
+}
+
+}  // namespace d377

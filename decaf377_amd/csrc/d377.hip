@@ -1,0 +1,620 @@
+// d377.hip -- gfx950 kernels and the C ABI (include/decaf377_amd.h) of the decaf377 batch engine.
+//
+// One lane = one group element.  Every kernel loads its 32-byte records as two 16-byte
+// vector loads per lane (a wave reads 2 KiB contiguous), keeps all field arithmetic in
+// VGPRs (fq29.hpp), and writes 32-byte records back the same way.  Work per element is
+// ~10^5 integer MACs against 64-97 bytes of traffic, so the kernels are VALU-bound; the
+// memory system only matters for the per-lane window table of the variable-base kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/decaf377_amd.h"
+#include "curve.hpp"
+
+using namespace d377;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int FB_WORDS = 36;                 // one extended point: 4 x 9 limbs
+constexpr int VB_ENTRIES = 9;                // 0..8 times P
+
+// ------------------------------------------------------------------ record I/O helpers ---
+__device__ __forceinline__ void load32(const uint8_t* base, size_t i, uint32_t w[8]) {
+  const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * i;
+  uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store32(uint8_t* base, size_t i, const uint32_t w[8]) {
+  uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ void store32_zero(uint8_t* base, size_t i) {
+  uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
+  p[0] = make_uint4(0, 0, 0, 0);
+  p[1] = make_uint4(0, 0, 0, 0);
+}
+__device__ __forceinline__ void store_ge_mont256(uint64_t* xyzt, size_t i, const ge& g) {
+  uint8_t* b = reinterpret_cast<uint8_t*>(xyzt);
+  uint32_t w[8];
+  fe_to_mont256_words(g.x, w); store32(b, 4 * i + 0, w);
+  fe_to_mont256_words(g.y, w); store32(b, 4 * i + 1, w);
+  fe_to_mont256_words(g.z, w); store32(b, 4 * i + 2, w);
+  fe_to_mont256_words(g.t, w); store32(b, 4 * i + 3, w);
+}
+__device__ __forceinline__ ge load_ge_mont256(const uint64_t* xyzt, size_t i) {
+  const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
+  uint32_t w[8];
+  ge g;
+  load32(b, 4 * i + 0, w); g.x = fe_from_mont256_words(w);
+  load32(b, 4 * i + 1, w); g.y = fe_from_mont256_words(w);
+  load32(b, 4 * i + 2, w); g.z = fe_from_mont256_words(w);
+  load32(b, 4 * i + 3, w); g.t = fe_from_mont256_words(w);
+  return g;
+}
+
+// per-lane window table in global scratch, laid out [entry][word][thread] so that the
+// stores (same entry for every lane) are fully coalesced dword rows
+struct GlobalTab {
+  uint32_t* base;
+  size_t nthreads, tid;
+  __device__ __forceinline__ void store(int j, const ge& g) {
+    uint32_t* p = base + (size_t)j * FB_WORDS * nthreads + tid;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      p[(size_t)(k) * nthreads] = g.x.l[k];
+      p[(size_t)(NL + k) * nthreads] = g.y.l[k];
+      p[(size_t)(2 * NL + k) * nthreads] = g.z.l[k];
+      p[(size_t)(3 * NL + k) * nthreads] = g.t.l[k];
+    }
+  }
+  __device__ __forceinline__ ge load(int j) const {
+    const uint32_t* p = base + (size_t)j * FB_WORDS * nthreads + tid;
+    ge g;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      g.x.l[k] = p[(size_t)(k) * nthreads];
+      g.y.l[k] = p[(size_t)(NL + k) * nthreads];
+      g.z.l[k] = p[(size_t)(2 * NL + k) * nthreads];
+      g.t.l[k] = p[(size_t)(3 * NL + k) * nthreads];
+    }
+    return g;
+  }
+};
+// shared fixed-base table FB[i][j] = j * 16^i * B, [64][9][36] words
+struct FixedTab {
+  const uint32_t* base;
+  __device__ __forceinline__ ge load(int i, int j) const {
+    const uint4* p = reinterpret_cast<const uint4*>(base + ((size_t)i * VB_ENTRIES + j) * FB_WORDS);
+    uint32_t w[FB_WORDS];
+#pragma unroll
+    for (int k = 0; k < FB_WORDS / 4; ++k) {
+      uint4 v = p[k];
+      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+    ge g;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      g.x.l[k] = w[k]; g.y.l[k] = w[NL + k]; g.z.l[k] = w[2 * NL + k]; g.t.l[k] = w[3 * NL + k];
+    }
+    return g;
+  }
+};
+
+// ------------------------------------------------------------------------- init kernels ---
+__device__ fe fe_pow_u32(const fe& x, uint32_t e) {   // e >= 1
+  int top = 31 - __clz((int)e);
+  fe r = x;
+#pragma unroll 1
+  for (int i = top - 1; i >= 0; --i) {
+    r = fe_sqr(r);
+    if ((e >> i) & 1u) r = fe_mul(r, x);
+  }
+  return r;
+}
+
+// gtab[t][nu] = g^(nu * 2^(8t)), g = zeta^m  (src/ark_curve/invsqrt.rs:41-50)
+__global__ void __launch_bounds__(BLOCK) k_init_gtab(uint32_t* gtab) {
+  const int idx = blockIdx.x * BLOCK + threadIdx.x;
+  if (idx >= 6 * 256) return;
+  const int t = idx >> 8, nu = idx & 255;
+  fe base = fe_sqr_n(fe_const(FE_SQRT_G), 8 * t);
+  fe v = nu == 0 ? fe_const(FE_ONE) : fe_pow_u32(base, (uint32_t)nu);
+  uint32_t* p = gtab + (size_t)idx * GT_STRIDE;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) p[i] = v.l[i];
+  p[9] = 0; p[10] = 0; p[11] = 0;
+}
+
+// s_lookup: keys g^-(nu * 2^39) (invsqrt.rs:27-39) in both tight representations -> nu.
+// One block of 256 threads; thread 0 then inserts sequentially and counts collisions.
+__global__ void __launch_bounds__(BLOCK) k_init_slookup(uint8_t* s_lookup, uint32_t* keys /*[256][2]*/,
+                                                        int* collisions) {
+  const int nu = threadIdx.x;
+  fe b39 = fe_sqr_n(fe_const(FE_SQRT_G_INV), 39);
+  fe v = nu == 0 ? fe_const(FE_ONE) : fe_pow_u32(b39, (uint32_t)nu);
+  fe c = fe_reduce_once(v);
+  keys[2 * nu] = s_hash(c);
+  uint32_t h2 = 0xFFFFFFFFu;
+  if (c.l[NL - 1] < (1u << 16)) {        // x < 2^248: x + q is a possible product representation
+    fe cq = fe_add(c, fe_const(Q_LIMBS));
+    uint32_t carry = 0;
+    fe n;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      uint32_t t = cq.l[i] + carry;
+      if (i < NL - 1) { n.l[i] = t & MASK29; carry = t >> RB; } else n.l[i] = t;
+    }
+    h2 = s_hash(n);
+  }
+  keys[2 * nu + 1] = h2;
+  for (int i = threadIdx.x; i < (1 << S_HASH_BITS); i += BLOCK) s_lookup[i] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int coll = 0;
+    // owner map in the table itself is ambiguous for nu = 0, so track with a second pass
+    for (int k = 0; k < 256; ++k)
+      for (int r = 0; r < 2; ++r) {
+        uint32_t h = keys[2 * k + r];
+        if (h == 0xFFFFFFFFu) continue;
+        for (int k2 = 0; k2 < k; ++k2)
+          for (int r2 = 0; r2 < 2; ++r2)
+            if (keys[2 * k2 + r2] == h) ++coll;
+        s_lookup[h] = (uint8_t)k;
+      }
+    *collisions = coll;
+  }
+}
+
+// FB[i][j] = j * 16^i * B for i = 0..63, j = 0..8
+__global__ void __launch_bounds__(64) k_init_fbase(uint32_t* fb) {
+  const int i = threadIdx.x;
+  ge pi = ge_generator();
+#pragma unroll 1
+  for (int k = 0; k < 4 * i; ++k) pi = ge_double(pi);
+  ge acc = ge_identity();
+#pragma unroll 1
+  for (int j = 0; j < VB_ENTRIES; ++j) {
+    uint32_t* p = fb + ((size_t)i * VB_ENTRIES + j) * FB_WORDS;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      p[k] = acc.x.l[k]; p[NL + k] = acc.y.l[k]; p[2 * NL + k] = acc.z.l[k]; p[3 * NL + k] = acc.t.l[k];
+    }
+    acc = ge_add(acc, pi);
+  }
+}
+
+// --------------------------------------------------------------------------- batch kernels ---
+__global__ void __launch_bounds__(BLOCK) k_sqrt_ratio_zeta(SqrtTables T, const uint8_t* num32,
+                                                           const uint8_t* den32, size_t n,
+                                                           uint8_t* root32, uint8_t* was_square) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t wn[8], wd[8], wr[8];
+    load32(num32, i, wn);
+    load32(den32, i, wd);
+    fe r;
+    const bool ws = fe_sqrt_ratio_zeta<false>(T, fe_from_words_mod_order(wn), fe_from_words_mod_order(wd), &r);
+    fe_to_bytes_words(r, wr);
+    store32(root32, i, wr);
+    was_square[i] = ws ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
+                                                      uint64_t* xyzt, uint8_t* status) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(enc32, i, w);
+    ge g;
+    const uint32_t bad = ge_decompress(T, w, &g);
+    status[i] = (uint8_t)bad;
+    if (bad) {
+      uint8_t* b = reinterpret_cast<uint8_t*>(xyzt);
+      store32_zero(b, 4 * i); store32_zero(b, 4 * i + 1); store32_zero(b, 4 * i + 2); store32_zero(b, 4 * i + 3);
+    } else {
+      store_ge_mont256(xyzt, i, g);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_compress(SqrtTables T, const uint64_t* xyzt, size_t n,
+                                                    uint8_t* enc32) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    ge_compress(T, load_ge_mont256(xyzt, i), w);
+    store32(enc32, i, w);
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_roundtrip(SqrtTables T, const uint8_t* enc32, size_t n,
+                                                     uint8_t* out32, uint8_t* status) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(enc32, i, w);
+    ge g;
+    const uint32_t bad = ge_decompress(T, w, &g);
+    ge_compress(T, g, w);
+    status[i] = (uint8_t)bad;
+    if (bad) store32_zero(out32, i); else store32(out32, i, w);
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_encode_to_curve(SqrtTables T, const uint8_t* fq32, size_t n,
+                                                           uint8_t* out32) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(fq32, i, w);
+    ge g = ge_elligator_map(T, fe_from_words_mod_order(w));
+    ge_compress(T, g, w);
+    store32(out32, i, w);
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_hash_to_curve(SqrtTables T, const uint8_t* r1, const uint8_t* r2,
+                                                         size_t n, uint8_t* out32) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(r1, i, w);
+    ge a = ge_elligator_map(T, fe_from_words_mod_order(w));
+    load32(r2, i, w);
+    ge b = ge_elligator_map(T, fe_from_words_mod_order(w));
+    ge_compress(T, ge_add(a, b), w);
+    store32(out32, i, w);
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_scalar_mul_var(SqrtTables T, const uint8_t* enc32,
+                                                          const uint8_t* scalar32, size_t n, uint8_t* out32,
+                                                          uint8_t* status, uint32_t* scratch) {
+  GlobalTab tab;
+  tab.base = scratch;
+  tab.nthreads = (size_t)gridDim.x * BLOCK;
+  tab.tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  for (size_t i = tab.tid; i < n; i += tab.nthreads) {
+    uint32_t w[8], k[8], dg[8];
+    load32(enc32, i, w);
+    load32(scalar32, i, k);
+    ge g;
+    const uint32_t bad = ge_decompress(T, w, &g);
+    fr_reduce_words(k);
+    fr_recode_signed16(k, dg);
+    ge r = ge_scalar_mul_w4(g, dg, tab);
+    ge_compress(T, r, w);
+    status[i] = (uint8_t)bad;
+    if (bad) store32_zero(out32, i); else store32(out32, i, w);
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
+                                                           const uint8_t* scalar32, size_t n, uint8_t* out32) {
+  FixedTab ft{fbase};
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t k[8], dg[8], w[8];
+    load32(scalar32, i, k);
+    fr_reduce_words(k);
+    fr_recode_signed16(k, dg);
+    ge r = ge_scalar_mul_base_w4(dg, ft);
+    ge_compress(T, r, w);
+    store32(out32, i, w);
+  }
+}
+
+// ------------------------------------------------------------------------------ host side ---
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, const char* detail) {
+  snprintf(g_err, sizeof g_err, fmt, detail);
+  return code;
+}
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) return fail(D377_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+struct DeviceState {
+  int id = -1;
+  int cus = 0;
+  uint32_t* gtab = nullptr;
+  uint8_t* s_lookup = nullptr;
+  uint32_t* fbase = nullptr;
+  uint32_t* vb_scratch = nullptr;
+  int vb_blocks = 0;
+  hipStream_t stream = nullptr;          // used by the host-pointer entry points
+  // grow-only staging buffers for the host-pointer entry points
+  uint8_t* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[4] = {0, 0, 0, 0};
+  SqrtTables tables() const { return SqrtTables{gtab, s_lookup}; }
+};
+
+}  // namespace
+
+struct d377_ctx {
+  std::vector<DeviceState> devs;
+  std::mutex mu;
+};
+
+namespace {
+
+int grid_for(const DeviceState& d, size_t n) {
+  // >> 256 workgroups when the batch allows it; capped so huge batches grid-stride
+  size_t blocks = (n + BLOCK - 1) / BLOCK;
+  size_t cap = (size_t)d.cus * 32;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+int init_device(DeviceState& d) {
+  HIP_TRY(hipSetDevice(d.id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, d.id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(D377_ERR_NO_DEVICE, "device is %s, this library is built for gfx950 only", prop.gcnArchName);
+  d.cus = prop.multiProcessorCount;
+  HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc(&d.gtab, (size_t)6 * 256 * GT_STRIDE * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&d.s_lookup, (size_t)1 << S_HASH_BITS));
+  HIP_TRY(hipMalloc(&d.fbase, (size_t)64 * VB_ENTRIES * FB_WORDS * sizeof(uint32_t)));
+  // variable-base window tables: one per resident lane, fixed grid, grid-stride over the batch
+  d.vb_blocks = d.cus * 4;
+  HIP_TRY(hipMalloc(&d.vb_scratch, (size_t)d.vb_blocks * BLOCK * VB_ENTRIES * FB_WORDS * sizeof(uint32_t)));
+  uint32_t* keys = nullptr;
+  int* coll = nullptr;
+  HIP_TRY(hipMalloc(&keys, 512 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&coll, sizeof(int)));
+  hipLaunchKernelGGL(k_init_gtab, dim3(6), dim3(BLOCK), 0, d.stream, d.gtab);
+  hipLaunchKernelGGL(k_init_slookup, dim3(1), dim3(BLOCK), 0, d.stream, d.s_lookup, keys, coll);
+  hipLaunchKernelGGL(k_init_fbase, dim3(1), dim3(64), 0, d.stream, d.fbase);
+  HIP_TRY(hipGetLastError());
+  int h_coll = -1;
+  HIP_TRY(hipMemcpyAsync(&h_coll, coll, sizeof(int), hipMemcpyDeviceToHost, d.stream));
+  HIP_TRY(hipStreamSynchronize(d.stream));
+  HIP_TRY(hipFree(keys));
+  HIP_TRY(hipFree(coll));
+  if (h_coll != 0) return fail(D377_ERR_INIT, "s_lookup perfect hash self-check failed (%s)", "collisions");
+  return D377_OK;
+}
+
+void free_device(DeviceState& d) {
+  if (d.id < 0) return;
+  (void)hipSetDevice(d.id);
+  if (d.stream) (void)hipStreamSynchronize(d.stream);
+  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch);
+  for (int i = 0; i < 4; ++i) (void)hipFree(d.buf[i]);
+  if (d.stream) (void)hipStreamDestroy(d.stream);
+}
+
+int ensure(DeviceState& d, int slot, size_t bytes) {
+  if (bytes <= d.cap[slot]) return D377_OK;
+  if (d.buf[slot]) HIP_TRY(hipFree(d.buf[slot]));
+  d.buf[slot] = nullptr; d.cap[slot] = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  HIP_TRY(hipMalloc(&d.buf[slot], want));
+  d.cap[slot] = want;
+  return D377_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH };
+
+// launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null)
+int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
+  if (n == 0) return D377_OK;
+  const SqrtTables T = d.tables();
+  const int g = grid_for(d, n);
+  switch (op) {
+    case OP_SQRT:
+      hipLaunchKernelGGL(k_sqrt_ratio_zeta, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                         (uint8_t*)out0, (uint8_t*)out1);
+      break;
+    case OP_DECOMPRESS:
+      hipLaunchKernelGGL(k_decompress, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint64_t*)out0, (uint8_t*)out1);
+      break;
+    case OP_COMPRESS:
+      hipLaunchKernelGGL(k_compress, dim3(g), dim3(BLOCK), 0, s, T, (const uint64_t*)in0, n, (uint8_t*)out0);
+      break;
+    case OP_ROUNDTRIP:
+      hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
+      break;
+    case OP_MUL_BASE:
+      hipLaunchKernelGGL(k_scalar_mul_base, dim3(g), dim3(BLOCK), 0, s, T, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
+      break;
+    case OP_MUL_VAR: {
+      int gv = g < d.vb_blocks ? g : d.vb_blocks;    // never more lanes than scratch tables
+      hipLaunchKernelGGL(k_scalar_mul_var, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                         (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch);
+      break;
+    }
+    case OP_ENCODE:
+      hipLaunchKernelGGL(k_encode_to_curve, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0);
+      break;
+    case OP_HASH:
+      hipLaunchKernelGGL(k_hash_to_curve, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                         (uint8_t*)out0);
+      break;
+  }
+  HIP_TRY(hipGetLastError());
+  return D377_OK;
+}
+
+struct OpShape { size_t in0, in1, out0, out1; };   // bytes per element
+OpShape shape_of(Op op) {
+  switch (op) {
+    case OP_SQRT: return {32, 32, 32, 1};
+    case OP_DECOMPRESS: return {32, 0, 128, 1};
+    case OP_COMPRESS: return {128, 0, 32, 0};
+    case OP_ROUNDTRIP: return {32, 0, 32, 1};
+    case OP_MUL_BASE: return {32, 0, 32, 0};
+    case OP_MUL_VAR: return {32, 32, 32, 1};
+    case OP_ENCODE: return {32, 0, 32, 0};
+    case OP_HASH: return {32, 32, 32, 0};
+  }
+  return {0, 0, 0, 0};
+}
+
+// host-pointer path: contiguous slices over the context's devices, async per device, then join
+int run_host(d377_ctx* ctx, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  const OpShape sh = shape_of(op);
+  if (n && (!in0 || (sh.in1 && !in1) || !out0 || (sh.out1 && !out1))) return fail(D377_ERR_ARG, "%s", "null buffer");
+  if (n == 0) return D377_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const size_t nd = ctx->devs.size();
+  const size_t per = (n + nd - 1) / nd;
+  int rc = D377_OK;
+  for (size_t k = 0; k < nd; ++k) {
+    DeviceState& d = ctx->devs[k];
+    const size_t lo = per * k;
+    if (lo >= n) break;
+    const size_t cnt = (lo + per <= n) ? per : n - lo;
+    HIP_TRY(hipSetDevice(d.id));
+    if ((rc = ensure(d, 0, cnt * sh.in0))) return rc;
+    if (sh.in1 && (rc = ensure(d, 1, cnt * sh.in1))) return rc;
+    if ((rc = ensure(d, 2, cnt * sh.out0))) return rc;
+    if (sh.out1 && (rc = ensure(d, 3, cnt * sh.out1))) return rc;
+    HIP_TRY(hipMemcpyAsync(d.buf[0], (const uint8_t*)in0 + lo * sh.in0, cnt * sh.in0, hipMemcpyHostToDevice, d.stream));
+    if (sh.in1)
+      HIP_TRY(hipMemcpyAsync(d.buf[1], (const uint8_t*)in1 + lo * sh.in1, cnt * sh.in1, hipMemcpyHostToDevice, d.stream));
+    if ((rc = launch(d, d.stream, op, d.buf[0], d.buf[1], cnt, d.buf[2], d.buf[3]))) return rc;
+    HIP_TRY(hipMemcpyAsync((uint8_t*)out0 + lo * sh.out0, d.buf[2], cnt * sh.out0, hipMemcpyDeviceToHost, d.stream));
+    if (sh.out1)
+      HIP_TRY(hipMemcpyAsync((uint8_t*)out1 + lo * sh.out1, d.buf[3], cnt * sh.out1, hipMemcpyDeviceToHost, d.stream));
+  }
+  for (size_t k = 0; k < nd; ++k) {
+    DeviceState& d = ctx->devs[k];
+    HIP_TRY(hipSetDevice(d.id));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+  }
+  return D377_OK;
+}
+
+int run_dev(d377_ctx* ctx, int dev, void* stream, Op op, const void* in0, const void* in1, size_t n, void* out0,
+            void* out1) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  const OpShape sh = shape_of(op);
+  if (n && (!in0 || (sh.in1 && !in1) || !out0 || (sh.out1 && !out1))) return fail(D377_ERR_ARG, "%s", "null buffer");
+  if (!aligned16(in0) || !aligned16(in1) || !aligned16(out0))
+    return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
+  DeviceState& d = ctx->devs[(size_t)dev];
+  HIP_TRY(hipSetDevice(d.id));
+  return launch(d, (hipStream_t)stream, op, in0, in1, n, out0, out1);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* d377_version(void) { return "decaf377_amd 0.1.0 (gfx950)"; }
+const char* d377_last_error(void) { return g_err; }
+
+int d377_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out) {
+  if (!out) return fail(D377_ERR_ARG, "%s", "null out pointer");
+  *out = nullptr;
+  int avail = d377_device_count();
+  if (avail <= 0) return fail(D377_ERR_NO_DEVICE, "%s", "no HIP device visible");
+  std::vector<int> ids;
+  if (!device_ids || n_dev <= 0) ids.push_back(0);
+  else ids.assign(device_ids, device_ids + n_dev);
+  for (int id : ids)
+    if (id < 0 || id >= avail) return fail(D377_ERR_ARG, "%s", "device id out of range");
+  d377_ctx* ctx = new (std::nothrow) d377_ctx();
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "out of host memory");
+  ctx->devs.resize(ids.size());
+  for (size_t k = 0; k < ids.size(); ++k) {
+    ctx->devs[k].id = ids[k];
+    int rc = init_device(ctx->devs[k]);
+    if (rc != D377_OK) {
+      for (auto& d : ctx->devs) free_device(d);
+      delete ctx;
+      return rc;
+    }
+  }
+  *out = ctx;
+  return D377_OK;
+}
+
+void d377_ctx_destroy(d377_ctx* ctx) {
+  if (!ctx) return;
+  for (auto& d : ctx->devs) free_device(d);
+  delete ctx;
+}
+int d377_ctx_num_devices(const d377_ctx* ctx) { return ctx ? (int)ctx->devs.size() : 0; }
+int d377_ctx_device_id(const d377_ctx* ctx, int dev) {
+  if (!ctx || dev < 0 || (size_t)dev >= ctx->devs.size()) return -1;
+  return ctx->devs[(size_t)dev].id;
+}
+
+int d377_batch_sqrt_ratio_zeta(d377_ctx* ctx, const uint8_t* num32, const uint8_t* den32, size_t n, uint8_t* root32,
+                               uint8_t* was_square) {
+  return run_host(ctx, OP_SQRT, num32, den32, n, root32, was_square);
+}
+int d377_batch_decompress(d377_ctx* ctx, const uint8_t* enc32, size_t n, uint64_t* xyzt, uint8_t* status) {
+  return run_host(ctx, OP_DECOMPRESS, enc32, nullptr, n, xyzt, status);
+}
+int d377_batch_compress(d377_ctx* ctx, const uint64_t* xyzt, size_t n, uint8_t* enc32) {
+  return run_host(ctx, OP_COMPRESS, xyzt, nullptr, n, enc32, nullptr);
+}
+int d377_batch_roundtrip(d377_ctx* ctx, const uint8_t* enc32, size_t n, uint8_t* enc32_out, uint8_t* status) {
+  return run_host(ctx, OP_ROUNDTRIP, enc32, nullptr, n, enc32_out, status);
+}
+int d377_batch_scalar_mul_base(d377_ctx* ctx, const uint8_t* scalar32, size_t n, uint8_t* enc32_out) {
+  return run_host(ctx, OP_MUL_BASE, scalar32, nullptr, n, enc32_out, nullptr);
+}
+int d377_batch_scalar_mul_var(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t n,
+                              uint8_t* enc32_out, uint8_t* status) {
+  return run_host(ctx, OP_MUL_VAR, enc32, scalar32, n, enc32_out, status);
+}
+int d377_batch_encode_to_curve(d377_ctx* ctx, const uint8_t* fq32, size_t n, uint8_t* enc32_out) {
+  return run_host(ctx, OP_ENCODE, fq32, nullptr, n, enc32_out, nullptr);
+}
+int d377_batch_hash_to_curve(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t* r2_32, size_t n, uint8_t* enc32_out) {
+  return run_host(ctx, OP_HASH, r1_32, r2_32, n, enc32_out, nullptr);
+}
+
+int d377_batch_sqrt_ratio_zeta_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* num32, const uint8_t* den32,
+                                   size_t n, uint8_t* root32, uint8_t* was_square) {
+  return run_dev(ctx, dev, stream, OP_SQRT, num32, den32, n, root32, was_square);
+}
+int d377_batch_decompress_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, size_t n, uint64_t* xyzt,
+                              uint8_t* status) {
+  return run_dev(ctx, dev, stream, OP_DECOMPRESS, enc32, nullptr, n, xyzt, status);
+}
+int d377_batch_compress_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t n, uint8_t* enc32) {
+  return run_dev(ctx, dev, stream, OP_COMPRESS, xyzt, nullptr, n, enc32, nullptr);
+}
+int d377_batch_roundtrip_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, size_t n, uint8_t* enc32_out,
+                             uint8_t* status) {
+  return run_dev(ctx, dev, stream, OP_ROUNDTRIP, enc32, nullptr, n, enc32_out, status);
+}
+int d377_batch_scalar_mul_base_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* scalar32, size_t n,
+                                   uint8_t* enc32_out) {
+  return run_dev(ctx, dev, stream, OP_MUL_BASE, scalar32, nullptr, n, enc32_out, nullptr);
+}
+int d377_batch_scalar_mul_var_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, const uint8_t* scalar32,
+                                  size_t n, uint8_t* enc32_out, uint8_t* status) {
+  return run_dev(ctx, dev, stream, OP_MUL_VAR, enc32, scalar32, n, enc32_out, status);
+}
+int d377_batch_encode_to_curve_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* fq32, size_t n,
+                                   uint8_t* enc32_out) {
+  return run_dev(ctx, dev, stream, OP_ENCODE, fq32, nullptr, n, enc32_out, nullptr);
+}
+int d377_batch_hash_to_curve_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* r1_32, const uint8_t* r2_32,
+                                 size_t n, uint8_t* enc32_out) {
+  return run_dev(ctx, dev, stream, OP_HASH, r1_32, r2_32, n, enc32_out, nullptr);
+}
+
+}  // extern "C"

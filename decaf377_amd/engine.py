@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference interface for the hot path, batch-shaped.
+
+Reference (crate decaf377 v0.10.1)              here (one call = one batch)
+  Encoding(pub [u8; 32])                          Encoding(array[n, 32] u8)
+  Encoding::vartime_decompress()                  Encoding.vartime_decompress() -> (Element, status)
+  Element::vartime_compress()                     Element.vartime_compress() -> Encoding
+  Element::encode_to_curve(&Fq)                   Element.encode_to_curve(Fq) -> Encoding
+  Element::hash_to_curve(&Fq, &Fq)                Element.hash_to_curve(Fq, Fq) -> Encoding
+  Element::GENERATOR * Fr                         Element.generator_mul(Fr) -> Encoding
+  element * Fr  (Encoding in, Encoding out)       Encoding.scalar_mul(Fr) -> (Encoding, status)
+  Fq::sqrt_ratio_zeta(&num, &den)                 Fq.sqrt_ratio_zeta(num, den) -> (was_square, Fq)
+  EncodingError::InvalidEncoding                  status byte 1 (0 = Ok) / EncodingError when raised
+
+Arrays may be numpy (host path: the library stages through HBM) or torch CUDA tensors (device
+path: no copies, launched on torch's current stream).  torch is plumbing only: device memory
+and streams.  There is no CPU implementation behind these classes."""
+import ctypes
+
+import numpy as np
+
+from . import _native
+
+
+class EncodingError(ValueError):
+    """src/error.rs:1-5. `InvalidEncoding` is reported per element as status 1."""
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _rows(a):
+    if a.ndim < 2:
+        raise ValueError("expected a [n, k] array of packed records")
+    return int(a.shape[0])
+
+
+class Context:
+    """Owns the device tables and scratch for one or more GPUs (d377_ctx)."""
+
+    def __init__(self, device_ids=None):
+        self._lib = _native.load()
+        self._h = ctypes.c_void_p()
+        if device_ids is None:
+            ids, n = None, 0
+        else:
+            ids, n = (ctypes.c_int * len(device_ids))(*device_ids), len(device_ids)
+        _native.check(self._lib.d377_ctx_create(ids, n, ctypes.byref(self._h)))
+        self.device_ids = [self._lib.d377_ctx_device_id(self._h, i)
+                           for i in range(self._lib.d377_ctx_num_devices(self._h))]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.d377_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _run(self, name, ins, outs_spec, n, outs=None):
+        """ins: list of arrays; outs_spec: list of (shape_tail, numpy dtype).  Host or device
+        path by the type of the first input.  `outs` lets a caller reuse output tensors."""
+        if _is_torch(ins[0]):
+            import torch
+            dev = ins[0].device
+            if dev.type != "cuda":
+                raise _native.NativeError("torch tensors must live on the GPU (there is no CPU path)")
+            if dev.index not in self.device_ids:
+                raise _native.NativeError("tensor on cuda:%s but context owns %s" % (dev.index, self.device_ids))
+            tdt = {np.uint8: torch.uint8, np.uint64: torch.int64}
+            ins = [t.contiguous() for t in ins]
+            if outs is None:
+                outs = [torch.empty((n,) + tail, dtype=tdt[dt], device=dev) for tail, dt in outs_spec]
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            args = [self._h, self.device_ids.index(dev.index), ctypes.c_void_p(stream)]
+            args += [ctypes.c_void_p(t.data_ptr()) for t in ins] + [ctypes.c_size_t(n)]
+            args += [ctypes.c_void_p(t.data_ptr()) for t in outs]
+            _native.check(getattr(self._lib, name + "_dev")(*args))
+            return outs
+        ins = [np.ascontiguousarray(a) for a in ins]
+        if outs is None:
+            outs = [np.zeros((n,) + tail, dtype=dt) for tail, dt in outs_spec]
+        args = [self._h] + [a.ctypes.data_as(ctypes.c_void_p) for a in ins] + [ctypes.c_size_t(n)]
+        args += [a.ctypes.data_as(ctypes.c_void_p) for a in outs]
+        _native.check(getattr(self._lib, name)(*args))
+        return outs
+
+    # -- the batch operations (C ABI names) ---------------------------------------------------
+    def sqrt_ratio_zeta(self, num32, den32, outs=None):
+        return self._run("d377_batch_sqrt_ratio_zeta", [num32, den32],
+                         [((32,), np.uint8), ((), np.uint8)], _rows(num32), outs)
+
+    def decompress(self, enc32, outs=None):
+        return self._run("d377_batch_decompress", [enc32], [((16,), np.uint64), ((), np.uint8)], _rows(enc32), outs)
+
+    def compress(self, xyzt, outs=None):
+        return self._run("d377_batch_compress", [xyzt], [((32,), np.uint8)], _rows(xyzt), outs)[0]
+
+    def roundtrip(self, enc32, outs=None):
+        return self._run("d377_batch_roundtrip", [enc32], [((32,), np.uint8), ((), np.uint8)], _rows(enc32), outs)
+
+    def scalar_mul_base(self, scalar32, outs=None):
+        return self._run("d377_batch_scalar_mul_base", [scalar32], [((32,), np.uint8)], _rows(scalar32), outs)[0]
+
+    def scalar_mul_var(self, enc32, scalar32, outs=None):
+        return self._run("d377_batch_scalar_mul_var", [enc32, scalar32],
+                         [((32,), np.uint8), ((), np.uint8)], _rows(enc32), outs)
+
+    def encode_to_curve(self, fq32, outs=None):
+        return self._run("d377_batch_encode_to_curve", [fq32], [((32,), np.uint8)], _rows(fq32), outs)[0]
+
+    def hash_to_curve(self, r1_32, r2_32, outs=None):
+        return self._run("d377_batch_hash_to_curve", [r1_32, r2_32], [((32,), np.uint8)], _rows(r1_32), outs)[0]
+
+
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default
+
+
+class _Bytes32:
+    """A batch of 32-byte little-endian records, shape [n, 32] uint8."""
+
+    def __init__(self, data, ctx=None):
+        if not _is_torch(data):
+            data = np.ascontiguousarray(np.asarray(data, dtype=np.uint8)).reshape(-1, 32)
+        self.data = data
+        self.ctx = ctx
+
+    def _ctx(self):
+        return self.ctx or default_context()
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    def to_bytes(self):
+        d = self.data.cpu().numpy() if _is_torch(self.data) else self.data
+        return [bytes(r) for r in d]
+
+
+class Fq(_Bytes32):
+    """Batch of base-field elements given as 32 bytes, interpreted mod q like
+    Fq::from_le_bytes_mod_order (src/fields/fq.rs:90-102)."""
+
+    @staticmethod
+    def sqrt_ratio_zeta(num, den):
+        """Fq::sqrt_ratio_zeta (src/ark_curve/invsqrt.rs:75-166) -> (was_square[n], Fq roots)."""
+        root, ws = num._ctx().sqrt_ratio_zeta(num.data, den.data)
+        return ws, Fq(root, num.ctx)
+
+
+class Fr(_Bytes32):
+    """Batch of scalars given as 32 bytes, interpreted mod r like Fr::from_le_bytes_mod_order
+    (src/fields/fr.rs:82-94)."""
+
+
+class Encoding(_Bytes32):
+    """Batch of `Encoding([u8; 32])` (src/ark_curve/encoding.rs:14-15)."""
+
+    def vartime_decompress(self):
+        """-> (Element, status[n]); status 1 = EncodingError::InvalidEncoding (encoding.rs:32-83)."""
+        xyzt, st = self._ctx().decompress(self.data)
+        return Element(xyzt, self.ctx), st
+
+    def roundtrip(self):
+        out, st = self._ctx().roundtrip(self.data)
+        return Encoding(out, self.ctx), st
+
+    def scalar_mul(self, scalars):
+        """decompress(self) * scalars, compressed (src/min_curve/ops.rs:89-95)."""
+        out, st = self._ctx().scalar_mul_var(self.data, scalars.data)
+        return Encoding(out, self.ctx), st
+
+    def unwrap_decompress(self):
+        el, st = self.vartime_decompress()
+        bad = st.cpu().numpy() if _is_torch(st) else st
+        if bad.any():
+            raise EncodingError("InvalidEncoding at index %d" % int(np.nonzero(bad)[0][0]))
+        return el
+
+
+class Element:
+    """Batch of group elements in the reference's in-memory form: X, Y, Z, T as 4 Montgomery
+    u64 limbs each (shape [n, 16]); src/min_curve/element.rs:31-38."""
+
+    def __init__(self, xyzt, ctx=None):
+        if not _is_torch(xyzt):
+            xyzt = np.ascontiguousarray(np.asarray(xyzt, dtype=np.uint64)).reshape(-1, 16)
+        self.data = xyzt
+        self.ctx = ctx
+
+    def _ctx(self):
+        return self.ctx or default_context()
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    def vartime_compress(self):
+        """Element::vartime_compress (src/ark_curve/encoding.rs:116-128)."""
+        return Encoding(self._ctx().compress(self.data), self.ctx)
+
+    @staticmethod
+    def encode_to_curve(r):
+        """Element::encode_to_curve (src/ark_curve/elligator.rs:74-76), returned compressed."""
+        return Encoding(r._ctx().encode_to_curve(r.data), r.ctx)
+
+    @staticmethod
+    def hash_to_curve(r1, r2):
+        """Element::hash_to_curve (src/ark_curve/elligator.rs:67-71), returned compressed."""
+        return Encoding(r1._ctx().hash_to_curve(r1.data, r2.data), r1.ctx)
+
+    @staticmethod
+    def generator_mul(scalars):
+        """Element::GENERATOR * scalars, returned compressed."""
+        return Encoding(scalars._ctx().scalar_mul_base(scalars.data), scalars.ctx)

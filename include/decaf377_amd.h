@@ -1,0 +1,106 @@
+/*
+ * decaf377_amd.h -- C ABI of the MI355X batch group-operation engine for decaf377.
+ *
+ * The reference crate (penumbra-zone/decaf377 v0.10.1) has no FFI or plugin interface of its
+ * own (it is a #![no_std] Rust library, src/lib.rs:1-31); the boundary below is what a
+ * Rust `extern "C"` block for this hot path would bind (INTEGRATION.md shows that block).
+ * Every entry point is a pure map over packed, unpadded, element-major arrays: element i of
+ * every output equals the reference function applied to element i of the inputs.
+ *
+ * Records
+ *   Encoding   32 bytes, `Encoding(pub [u8; 32])`                 src/ark_curve/encoding.rs:14-15
+ *   Fq / Fr    32 bytes little-endian                              src/fields/fq.rs:90-115, fr.rs:82-107
+ *   Element    16 x u64 = X, Y, Z, T, each 4 Montgomery limbs (R = 2^256, fully reduced), the
+ *              in-memory value of `Fq::from_montgomery_limbs`      src/fields/fq/u64/wrapper.rs:82-85
+ *   status     1 byte per element: 0 = Ok, 1 = EncodingError::InvalidEncoding   src/error.rs:1-5
+ *              (failed elements get all-zero output records)
+ *
+ * Return value: 0 on success, negative D377_ERR_* otherwise; per-element failures are only
+ * reported through `status`.  A context is used by one thread at a time (one call in flight
+ * per context: the variable-base kernel owns a per-context scratch table); distinct contexts
+ * are independent.  Buffers belong to the caller and are never retained.
+ *
+ * Two families:
+ *   d377_batch_*      host pointers; the library copies to the context's GPU(s), shards
+ *                     contiguous slices over them when the context owns several, and copies back.
+ *   d377_batch_*_dev  device pointers (16-byte aligned, resident on the context's device
+ *                     `dev`), enqueued on `stream` (a hipStream_t, NULL = default stream) with
+ *                     no host synchronisation: for callers that keep batches in HBM.
+ */
+#ifndef DECAF377_AMD_H
+#define DECAF377_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D377_OK 0
+#define D377_ERR_HIP (-1)        /* a HIP runtime call failed; see d377_last_error() */
+#define D377_ERR_ARG (-2)        /* null / misaligned pointer, bad device index */
+#define D377_ERR_NO_DEVICE (-3)  /* no usable gfx950 device */
+#define D377_ERR_INIT (-4)       /* device table self-check failed at context creation */
+
+typedef struct d377_ctx d377_ctx;
+
+/* Library / device discovery. */
+const char* d377_version(void);
+int d377_device_count(void);
+/* Human-readable text for the most recent error on this thread. */
+const char* d377_last_error(void);
+
+/* Builds the read-only device tables (Sarkar square-root tables of
+ * src/ark_curve/invsqrt.rs:14-66, fixed-base table of Element::GENERATOR) once per device
+ * and allocates the per-device scratch.  device_ids == NULL, n_dev == 0 -> device 0. */
+int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out);
+void d377_ctx_destroy(d377_ctx* ctx);
+int d377_ctx_num_devices(const d377_ctx* ctx);
+int d377_ctx_device_id(const d377_ctx* ctx, int dev);
+
+/* Fq::sqrt_ratio_zeta(num, den) -> (was_square, root)        src/ark_curve/invsqrt.rs:75-166
+ * num32/den32: 32-byte strings reduced mod q like Fq::from_le_bytes_mod_order. */
+int d377_batch_sqrt_ratio_zeta(d377_ctx* ctx, const uint8_t* num32, const uint8_t* den32, size_t n,
+                               uint8_t* root32, uint8_t* was_square);
+/* Encoding::vartime_decompress                                src/ark_curve/encoding.rs:32-83 */
+int d377_batch_decompress(d377_ctx* ctx, const uint8_t* enc32, size_t n, uint64_t* xyzt, uint8_t* status);
+/* Element::vartime_compress                                   src/ark_curve/encoding.rs:91-128 */
+int d377_batch_compress(d377_ctx* ctx, const uint64_t* xyzt, size_t n, uint8_t* enc32);
+/* vartime_decompress then vartime_compress (tests/encoding.rs:97-107 round trip) */
+int d377_batch_roundtrip(d377_ctx* ctx, const uint8_t* enc32, size_t n, uint8_t* enc32_out, uint8_t* status);
+/* Element::GENERATOR * Fr::from_le_bytes_mod_order(scalar) -> Encoding
+ *                                                             src/min_curve/ops.rs:89-95 */
+int d377_batch_scalar_mul_base(d377_ctx* ctx, const uint8_t* scalar32, size_t n, uint8_t* enc32_out);
+/* Encoding::vartime_decompress(enc)? * Fr::from_le_bytes_mod_order(scalar) -> Encoding */
+int d377_batch_scalar_mul_var(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t n,
+                              uint8_t* enc32_out, uint8_t* status);
+/* Element::encode_to_curve(Fq::from_le_bytes_mod_order(r)) -> Encoding
+ *                                                             src/ark_curve/elligator.rs:15-62,74-76 */
+int d377_batch_encode_to_curve(d377_ctx* ctx, const uint8_t* fq32, size_t n, uint8_t* enc32_out);
+/* Element::hash_to_curve(r1, r2) -> Encoding                  src/ark_curve/elligator.rs:67-71 */
+int d377_batch_hash_to_curve(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t* r2_32, size_t n,
+                             uint8_t* enc32_out);
+
+/* Device-pointer forms (same semantics). */
+int d377_batch_sqrt_ratio_zeta_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* num32,
+                                   const uint8_t* den32, size_t n, uint8_t* root32, uint8_t* was_square);
+int d377_batch_decompress_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, size_t n,
+                              uint64_t* xyzt, uint8_t* status);
+int d377_batch_compress_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t n,
+                            uint8_t* enc32);
+int d377_batch_roundtrip_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, size_t n,
+                             uint8_t* enc32_out, uint8_t* status);
+int d377_batch_scalar_mul_base_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* scalar32,
+                                   size_t n, uint8_t* enc32_out);
+int d377_batch_scalar_mul_var_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32,
+                                  const uint8_t* scalar32, size_t n, uint8_t* enc32_out, uint8_t* status);
+int d377_batch_encode_to_curve_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* fq32, size_t n,
+                                   uint8_t* enc32_out);
+int d377_batch_hash_to_curve_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* r1_32,
+                                 const uint8_t* r2_32, size_t n, uint8_t* enc32_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DECAF377_AMD_H */

@@ -1,0 +1,157 @@
+// Test-only host build of the per-lane device functions (decaf377_amd/csrc/*.hpp), so the
+// limb arithmetic and the curve formulas can be checked against the oracle on a machine with
+// no GPU.  NOT part of the product: nothing in decaf377_amd/ loads this; it is compiled by
+// tests/test_host_sim.py with g++ and exists only under tests/.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "curve.hpp"
+using namespace d377;
+
+static std::vector<uint32_t> g_gtab(6 * 256 * GT_STRIDE);
+static std::vector<uint8_t> g_slook(1u << S_HASH_BITS);
+static std::vector<uint32_t> g_fbase(64 * 9 * 36);
+static SqrtTables g_T;
+static int g_collisions = -1;
+
+static fe fe_pow_u64(fe x, uint64_t e) {   // Montgomery x^e, e > 0
+  fe r = x; int top = 63; while (!((e >> top) & 1)) --top;
+  for (int i = top - 1; i >= 0; --i) { r = fe_sqr(r); if ((e >> i) & 1) r = fe_mul(r, x); }
+  return r;
+}
+static fe full_norm(fe a) {   // sequential carry, value < 2^261
+  uint32_t c = 0; fe r;
+  for (int i = 0; i < NL; ++i) { uint32_t t = a.l[i] + c; if (i < NL - 1) { r.l[i] = t & MASK29; c = t >> 29; } else r.l[i] = t; }
+  return r;
+}
+struct HostTab { ge e[9]; void store(int j, const ge& g) { e[j] = g; } ge load(int j) const { return e[j]; } };
+struct HostFTab {
+  const uint32_t* p;
+  ge load(int i, int j) const {
+    ge g; const uint32_t* q = p + ((size_t)i * 9 + j) * 36;
+    for (int k = 0; k < 9; ++k) { g.x.l[k] = q[k]; g.y.l[k] = q[9 + k]; g.z.l[k] = q[18 + k]; g.t.l[k] = q[27 + k]; }
+    return g;
+  }
+};
+
+extern "C" {
+int sim_init() {
+  // same construction the init kernels perform on the device
+  fe g = fe_const(FE_SQRT_G), ginv = fe_const(FE_SQRT_G_INV), one = fe_const(FE_ONE);
+  static const int pw[6] = {0, 8, 16, 24, 32, 40};
+  for (int t = 0; t < 6; ++t) {
+    fe base = fe_sqr_n(g, pw[t]);
+    for (int nu = 0; nu < 256; ++nu) {
+      fe v = nu == 0 ? one : fe_pow_u64(base, (uint64_t)nu);
+      for (int i = 0; i < NL; ++i) g_gtab[((size_t)t * 256 + nu) * GT_STRIDE + i] = v.l[i];
+    }
+  }
+  std::vector<int> owner(1u << S_HASH_BITS, -1);
+  int coll = 0;
+  fe b39 = fe_sqr_n(ginv, 39);
+  for (int nu = 0; nu < 256; ++nu) {
+    fe v = nu == 0 ? one : fe_pow_u64(b39, (uint64_t)nu);
+    fe c = fe_reduce_once(v);                      // canonical Montgomery value in [0, q)
+    fe cq = full_norm(fe_add(c, fe_const(Q_LIMBS)));   // the other tight representation
+    const int nrep = (c.l[NL - 1] < (1u << 16)) ? 2 : 1;   // x + q only when x < 2^248
+    for (int rep = 0; rep < nrep; ++rep) {
+      fe k = rep ? cq : c;
+      uint32_t h = s_hash(k);
+      if (owner[h] >= 0 && owner[h] != nu) ++coll;
+      owner[h] = nu; g_slook[h] = (uint8_t)nu;
+    }
+  }
+  g_collisions = coll;
+  g_T.gtab = g_gtab.data(); g_T.s_lookup = g_slook.data();
+  // fixed-base table j * 16^i * B
+  ge pi = ge_generator();
+  for (int i = 0; i < 64; ++i) {
+    ge acc = ge_identity();
+    for (int j = 0; j <= 8; ++j) {
+      uint32_t* q = g_fbase.data() + ((size_t)i * 9 + j) * 36;
+      for (int k = 0; k < 9; ++k) { q[k] = acc.x.l[k]; q[9 + k] = acc.y.l[k]; q[18 + k] = acc.z.l[k]; q[27 + k] = acc.t.l[k]; }
+      acc = ge_add(acc, pi);
+    }
+    for (int j = 0; j < 4; ++j) pi = ge_double(pi);
+  }
+  return coll;
+}
+// field ops on Montgomery-256 words (8 x u32 per element), through the internal form
+void sim_fq_mul(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) fe_to_mont256_words(fe_mul(fe_from_mont256_words(a + 8 * i), fe_from_mont256_words(b + 8 * i)), out + 8 * i);
+}
+void sim_fq_sqr(const uint32_t* a, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) fe_to_mont256_words(fe_sqr(fe_from_mont256_words(a + 8 * i)), out + 8 * i);
+}
+void sim_fq_add(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) fe_to_mont256_words(fe_add(fe_from_mont256_words(a + 8 * i), fe_from_mont256_words(b + 8 * i)), out + 8 * i);
+}
+void sim_fq_sub(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) fe_to_mont256_words(fe_sub(fe_from_mont256_words(a + 8 * i), fe_from_mont256_words(b + 8 * i)), out + 8 * i);
+}
+void sim_fq_from_bytes(const uint32_t* w, size_t n, uint32_t* mont256) {
+  for (size_t i = 0; i < n; ++i) fe_to_mont256_words(fe_from_words_mod_order(w + 8 * i), mont256 + 8 * i);
+}
+void sim_fq_to_bytes(const uint32_t* mont256, size_t n, uint32_t* w) {
+  for (size_t i = 0; i < n; ++i) fe_to_bytes_words(fe_from_mont256_words(mont256 + 8 * i), w + 8 * i);
+}
+void sim_consts(uint32_t* sub8q, uint32_t* ql) { for (int i = 0; i < NL; ++i) { sub8q[i] = SUB8Q[i]; ql[i] = QL[i]; } }
+
+void sim_sqrt_ratio_zeta(const uint32_t* num, const uint32_t* den, size_t n, uint32_t* root, uint8_t* ws) {
+  for (size_t i = 0; i < n; ++i) {
+    fe r; bool w = fe_sqrt_ratio_zeta<false>(g_T, fe_from_words_mod_order(num + 8 * i), fe_from_words_mod_order(den + 8 * i), &r);
+    fe_to_bytes_words(r, root + 8 * i); ws[i] = w;
+  }
+}
+static void ge_store256(const ge& g, uint32_t* o) {
+  fe_to_mont256_words(g.x, o); fe_to_mont256_words(g.y, o + 8); fe_to_mont256_words(g.z, o + 16); fe_to_mont256_words(g.t, o + 24);
+}
+static ge ge_load256(const uint32_t* o) {
+  ge g; g.x = fe_from_mont256_words(o); g.y = fe_from_mont256_words(o + 8); g.z = fe_from_mont256_words(o + 16); g.t = fe_from_mont256_words(o + 24);
+  return g;
+}
+void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
+  for (size_t i = 0; i < n; ++i) {
+    ge g; uint32_t bad = ge_decompress(g_T, enc + 8 * i, &g);
+    st[i] = (uint8_t)bad;
+    if (bad) memset(xyzt + 32 * i, 0, 128); else ge_store256(g, xyzt + 32 * i);
+  }
+}
+void sim_compress(const uint32_t* xyzt, size_t n, uint32_t* enc) {
+  for (size_t i = 0; i < n; ++i) ge_compress(g_T, ge_load256(xyzt + 32 * i), enc + 8 * i);
+}
+void sim_roundtrip(const uint32_t* enc, size_t n, uint32_t* out, uint8_t* st) {
+  for (size_t i = 0; i < n; ++i) {
+    ge g; uint32_t bad = ge_decompress(g_T, enc + 8 * i, &g);
+    st[i] = (uint8_t)bad;
+    if (bad) memset(out + 8 * i, 0, 32); else ge_compress(g_T, g, out + 8 * i);
+  }
+}
+void sim_encode_to_curve(const uint32_t* r0, size_t n, uint32_t* enc, uint32_t* xyzt) {
+  for (size_t i = 0; i < n; ++i) {
+    ge g = ge_elligator_map(g_T, fe_from_words_mod_order(r0 + 8 * i));
+    ge_compress(g_T, g, enc + 8 * i);
+    if (xyzt) ge_store256(g, xyzt + 32 * i);
+  }
+}
+void sim_scalar_mul_var(const uint32_t* enc, const uint32_t* k, size_t n, uint32_t* out, uint8_t* st) {
+  for (size_t i = 0; i < n; ++i) {
+    ge g; uint32_t bad = ge_decompress(g_T, enc + 8 * i, &g);
+    st[i] = (uint8_t)bad;
+    if (bad) { memset(out + 8 * i, 0, 32); continue; }
+    uint32_t kk[8], dg[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_recode_signed16(kk, dg);
+    HostTab tab; ge r = ge_scalar_mul_w4(g, dg, tab);
+    ge_compress(g_T, r, out + 8 * i);
+  }
+}
+void sim_scalar_mul_base(const uint32_t* k, size_t n, uint32_t* out) {
+  HostFTab ft{g_fbase.data()};
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t kk[8], dg[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_recode_signed16(kk, dg);
+    ge_compress(g_T, ge_scalar_mul_base_w4(dg, ft), out + 8 * i);
+  }
+}
+void sim_fr_reduce(const uint32_t* k, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) { uint32_t kk[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); memcpy(out + 8 * i, kk, 32); }
+}
+}

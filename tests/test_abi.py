@@ -1,0 +1,60 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/decaf377_amd.h declares; no compute call is made (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "decaf377_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(d377_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from decaf377_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__ as g
+        g.build_native()
+    return _native.LIB_PATH
+
+
+def test_header_symbols_are_exported(libpath):
+    from decaf377_amd import _native
+    lib = ctypes.CDLL(libpath)
+    decl = _declared()
+    assert len(decl) >= 23
+    for name in decl:
+        assert hasattr(lib, name), "missing export " + name
+    assert sorted(_native.EXPORTS) == decl
+
+
+def test_binding_prototypes(libpath):
+    from decaf377_amd import _native
+    lib = _native.load()
+    assert lib.d377_version().startswith(b"decaf377_amd")
+    assert isinstance(lib.d377_device_count(), int)
+
+
+def test_no_cpu_fallback_without_gpu(libpath):
+    """Without a GPU, creating a context must fail loudly (never compute on the CPU)."""
+    from decaf377_amd import _native, Context
+    lib = _native.load()
+    if lib.d377_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_native.NativeError):
+        Context()
+
+
+def test_product_never_touches_oracle():
+    """Nothing under decaf377_amd/ may import, link or name anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "decaf377_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".inc", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "d377o_" not in text and "libd377_oracle" not in text and "d377_model" not in text, f

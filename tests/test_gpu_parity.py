@@ -1,0 +1,284 @@
+"""Parity tests proper: the HIP kernels, called through the C ABI (include/decaf377_amd.h),
+against the oracle on the same seeded inputs, against the committed golden fixtures, and --
+at BASELINE.json's full sizes -- through size-independent properties.  Bit-exact everywhere:
+this path is integer arithmetic.  Needs a real MI355X: run with `-m gpu`."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q = 725501752471715841 | 6461107452199829505 << 64 | 6968279316240510977 << 128 | 1345280370688173398 << 192
+R_ORDER = (13356249993388743167 | 5950279507993463550 << 64 | 10965441865914903552 << 128
+           | 336320092672043349 << 192)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import decaf377_amd as d
+    c = d.Context([0])
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def hx(rows):
+    return [bytes(r).hex() for r in np.asarray(rows, dtype=np.uint8).reshape(-1, 32)]
+
+
+def frombytes(lst):
+    return np.array([list(bytes.fromhex(h)) if isinstance(h, str) else list(h) for h in lst], dtype=np.uint8)
+
+
+def ibytes(v):
+    return np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+
+
+def test_native_library_is_loaded(ctx):
+    """The .so the driver looks for must actually be mapped into this process."""
+    with open("/proc/self/maps") as f:
+        assert "libdecaf377_amd.so" in f.read()
+
+
+# --- reference KATs through the GPU ----------------------------------------------------------
+def test_basepoint_multiples(ctx, kats):
+    """tests/encoding.rs:55-95 of the reference."""
+    hexes = kats["basepoint_multiples"]["hex"]
+    enc = frombytes(hexes)
+    xyzt, st = ctx.decompress(enc)
+    assert not st.any()
+    assert hx(ctx.compress(xyzt)) == hexes
+    out, st = ctx.roundtrip(enc)
+    assert not st.any() and hx(out) == hexes
+    ks = np.zeros((16, 32), np.uint8)
+    ks[:, 0] = np.arange(16)
+    assert hx(ctx.scalar_mul_base(ks)) == hexes
+    g = np.tile(frombytes([kats["generator"]["hex"]]), (16, 1))
+    out, st = ctx.scalar_mul_var(g, ks)
+    assert not st.any() and hx(out) == hexes
+
+
+def test_identity_and_generator(ctx, kats):
+    """tests/encoding.rs:20-52."""
+    xyzt, st = ctx.decompress(frombytes([kats["identity"]["hex"], kats["generator"]["hex"]]))
+    assert not st.any()
+    one = [0x7d1c7ffffffffff3, 0x7257f50f6ffffff2, 0x16d81575512c0fee, 0x0d4bda322bbb9a9d]   # Fq::ONE
+    assert [int(v) for v in xyzt[0]] == [0] * 4 + one + one + [0] * 4
+    assert [int(v) for v in xyzt[1, 0:4]] == kats["generator"]["x_mont"]
+    assert [int(v) for v in xyzt[1, 4:8]] == kats["generator"]["y_mont"]
+    assert [int(v) for v in xyzt[1, 8:12]] == one
+    assert [int(v) for v in xyzt[1, 12:16]] == kats["generator"]["t_mont"]
+    firsts = np.zeros((255, 32), np.uint8)
+    firsts[:, 0] = np.arange(1, 256)
+    _, st = ctx.decompress(firsts)
+    assert int(np.nonzero(st == 0)[0][0]) + 1 == kats["generator"]["min_first_byte"]
+
+
+def test_elligator_kats(ctx, kats, oracle):
+    """src/ark_curve/elligator.rs:86-207 -- the 8 inputs; encodings equal the oracle's, whose
+    affine (x, y) are pinned to the reference's decimals in tests/test_oracle.py."""
+    inputs = np.array(kats["elligator"]["inputs"], dtype=np.uint8)
+    enc = ctx.encode_to_curve(inputs)
+    assert (enc == oracle.encode_to_curve(inputs)).all()
+    xyzt, st = ctx.decompress(enc)
+    assert not st.any()
+    assert oracle.eq_xyzt(xyzt, oracle.elligator_map_xyzt(inputs)).all()
+
+
+def test_sqrt_edge_cases(ctx, kats):
+    """src/ark_curve/invsqrt.rs:204-211 and proptest-regressions/invsqrt.txt:7."""
+    num = np.stack([ibytes(0), ibytes(1), ibytes(0), ibytes(1 << 248), ibytes(Q), ibytes(1)])
+    den = np.stack([ibytes(1), ibytes(0), ibytes(0), ibytes(1 << 248), ibytes(5), ibytes(Q)])
+    root, ws = ctx.sqrt_ratio_zeta(num, den)
+    assert list(ws[:3]) == [1, 0, 1] and not root[:3].any()
+    r = int.from_bytes(bytes(root[3]), "little")
+    assert ws[3] == 1 and r * r % Q == 1
+    assert ws[4] == 1 and not root[4].any()      # num = q = 0 mod q
+    assert ws[5] == 0 and not root[5].any()      # den = q = 0 mod q
+
+
+def test_regression_seeds(ctx, kats):
+    seeds = np.array(kats["regression_seeds"]["encoding_bytes"], dtype=np.uint8)
+    out, st = ctx.roundtrip(seeds)
+    assert list(st) == [0, 0, 1]
+    assert (out[:2] == seeds[:2]).all() and not out[2].any()
+
+
+# --- committed model vectors -------------------------------------------------------------------
+def test_vectors(ctx, vectors):
+    v = vectors["sqrt_ratio_zeta"]
+    root, ws = ctx.sqrt_ratio_zeta(frombytes([c["num"] for c in v]), frombytes([c["den"] for c in v]))
+    assert hx(root) == [c["root"] for c in v] and list(ws) == [c["was_square"] for c in v]
+    v = vectors["encode_to_curve"]
+    assert hx(ctx.encode_to_curve(frombytes([c["r0"] for c in v]))) == [c["enc"] for c in v]
+    v = vectors["decompress"]
+    enc = frombytes([c["enc"] for c in v])
+    xyzt, st = ctx.decompress(enc)
+    out, st2 = ctx.roundtrip(enc)
+    assert list(st) == [c["status"] for c in v] == list(st2)
+    for i, c in enumerate(v):
+        if c["status"] == 0:
+            assert [[int(x) for x in xyzt[i, 4 * j:4 * j + 4]] for j in range(4)] == c["xyzt_mont"]
+            assert bytes(out[i]).hex() == c["enc"]
+        else:
+            assert not xyzt[i].any() and not out[i].any()
+    v = vectors["scalar_mul_base"]
+    assert hx(ctx.scalar_mul_base(frombytes([c["scalar"] for c in v]))) == [c["enc"] for c in v]
+    v = vectors["scalar_mul_var"]
+    out, st = ctx.scalar_mul_var(frombytes([c["point"] for c in v]), frombytes([c["scalar"] for c in v]))
+    assert hx(out) == [c["enc"] for c in v] and list(st) == [c["status"] for c in v]
+    v = vectors["hash_to_curve"]
+    assert hx(ctx.hash_to_curve(frombytes([c["r1"] for c in v]), frombytes([c["r2"] for c in v]))) == \
+        [c["enc"] for c in v]
+
+
+# --- seeded random parity against the oracle ---------------------------------------------------
+def test_sqrt_random_2_16(ctx, oracle):
+    """BASELINE config 1 size (2^16 pairs), edge pairs first; every (flag, root) vs the oracle."""
+    rng = np.random.default_rng(666)
+    n = 1 << 16
+    num = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    den = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i, (u, v) in enumerate([(0, 1), (1, 0), (0, 0), (1, 1), (1 << 248, 1 << 248)]):
+        num[i], den[i] = ibytes(u), ibytes(v)
+    root, ws = ctx.sqrt_ratio_zeta(num, den)
+    o_root, o_ws, _ = oracle.run_threads("sqrt_ratio_zeta", num, den, 8)
+    assert (ws == o_ws).all() and (root == o_root).all()
+
+
+def test_roundtrip_random_raw(ctx, oracle):
+    """2^16 raw strings (mostly invalid) + valid encodings: status and zero-output equal the oracle."""
+    rng = np.random.default_rng(667)
+    n = 1 << 16
+    raw = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    raw[: n // 2, 31] &= 0x1F
+    out, st = ctx.roundtrip(raw)
+    o_out, o_st, _ = oracle.run_threads("roundtrip", raw, None, 8)
+    assert (st == o_st).all() and (out == o_out).all()
+    assert 1000 < (st == 0).sum() < n - 1000
+    xyzt, st2 = ctx.decompress(raw[:4096])
+    o_xyzt, o_st2 = oracle.decompress(raw[:4096])
+    assert (st2 == o_st2).all() and (xyzt == o_xyzt).all()
+    ok = st2 == 0
+    assert (ctx.compress(xyzt[ok]) == raw[:4096][ok]).all()
+
+
+def test_encode_and_scalar_mul_random(ctx, oracle):
+    rng = np.random.default_rng(668)
+    n = 1 << 13
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i, v in enumerate([0, 1, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1]):
+        k[i] = ibytes(v)
+    enc = ctx.encode_to_curve(r0)
+    o_enc, _, _ = oracle.run_threads("encode_to_curve", r0, None, 8)
+    assert (enc == o_enc).all()
+    out, st = ctx.scalar_mul_var(enc, k)
+    o_out, o_st, _ = oracle.run_threads("scalar_mul_var", enc, k, 8)
+    assert (st == o_st).all() and (out == o_out).all()
+    fb = ctx.scalar_mul_base(k)
+    o_fb, _, _ = oracle.run_threads("scalar_mul_base", k, None, 8)
+    assert (fb == o_fb).all()
+    h = ctx.hash_to_curve(r0[: n // 2], r0[n // 2:])
+    assert (h[:512] == oracle.hash_to_curve(r0[:512], r0[n // 2: n // 2 + 512])).all()
+
+
+def test_ragged_and_empty(ctx, oracle):
+    """n = 0, 1, 63, 64, 65, 257 (partial waves and blocks)."""
+    rng = np.random.default_rng(669)
+    for n in (0, 1, 63, 64, 65, 257):
+        r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        enc = ctx.encode_to_curve(r0)
+        assert enc.shape == (n, 32)
+        if n:
+            assert (enc == oracle.encode_to_curve(r0)).all()
+            out, st = ctx.scalar_mul_var(enc, k)
+            o_out, o_st = oracle.scalar_mul_var(enc, k)
+            assert (out == o_out).all() and (st == o_st).all()
+            rt, st = ctx.roundtrip(enc)
+            assert (rt == enc).all() and not st.any()
+
+
+# --- device-pointer path and full-size properties ------------------------------------------------
+def test_device_path_matches_host_path(ctx, torch_mod):
+    torch = torch_mod
+    rng = np.random.default_rng(670)
+    n = 5000
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    dev = torch.device("cuda:0")
+    enc_d = ctx.encode_to_curve(torch.from_numpy(r0).to(dev))
+    out_d, st_d = ctx.scalar_mul_var(enc_d, torch.from_numpy(k).to(dev))
+    xyzt_d, st2_d = ctx.decompress(enc_d)
+    cmp_d = ctx.compress(xyzt_d)
+    torch.cuda.synchronize()
+    enc_h = ctx.encode_to_curve(r0)
+    out_h, st_h = ctx.scalar_mul_var(enc_h, k)
+    assert (enc_d.cpu().numpy() == enc_h).all()
+    assert (out_d.cpu().numpy() == out_h).all() and (st_d.cpu().numpy() == st_h).all()
+    assert (cmp_d.cpu().numpy() == enc_h).all() and not st2_d.cpu().numpy().any()
+
+
+def test_full_size_roundtrip_2_20(ctx, torch_mod, oracle):
+    """BASELINE config 2: 2^20 valid encodings decompress->compress to themselves (status 0);
+    a seeded sample is also compared with the oracle."""
+    torch = torch_mod
+    n = 1 << 20
+    g = torch.Generator(device="cpu").manual_seed(666)
+    r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
+    dev = torch.device("cuda:0")
+    enc = ctx.encode_to_curve(r0.to(dev))
+    out, st = ctx.roundtrip(enc)
+    torch.cuda.synchronize()
+    assert torch.equal(out, enc) and int(st.sum().item()) == 0
+    idx = np.arange(0, n, 4099)
+    assert (enc[idx].cpu().numpy() == oracle.encode_to_curve(r0.numpy()[idx])).all()
+
+
+def test_full_size_scalar_mul_algebra(ctx, torch_mod, oracle):
+    """tests/operations.rs:19-43 at 2^18 elements: aP + bP = (a+b)P and b(aP) = (ab)P as encodings,
+    using only GPU operations plus host big-int scalar arithmetic; then a sample vs the oracle."""
+    torch = torch_mod
+    n = 1 << 18
+    rng = np.random.default_rng(671)
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    P = ctx.encode_to_curve(r0)
+    aP, st = ctx.scalar_mul_var(P, a)
+    assert not st.any()
+    baP, st = ctx.scalar_mul_var(aP, b)
+    # (ab)P on a sample (host big-int products are slow in pure Python for 2^18)
+    m = 2048
+    ai = [int.from_bytes(bytes(x), "little") % R_ORDER for x in a[:m]]
+    bi = [int.from_bytes(bytes(x), "little") % R_ORDER for x in b[:m]]
+    ab = np.array([list((x * y % R_ORDER).to_bytes(32, "little")) for x, y in zip(ai, bi)], dtype=np.uint8)
+    apb = np.array([list(((x + y) % R_ORDER).to_bytes(32, "little")) for x, y in zip(ai, bi)], dtype=np.uint8)
+    abP, _ = ctx.scalar_mul_var(P[:m], ab)
+    assert (abP == baP[:m]).all()
+    # aP + bP == (a+b)P: add through the oracle's group law on decompressed points
+    bP, _ = ctx.scalar_mul_var(P[:m], b[:m])
+    x1, _ = ctx.decompress(aP[:m])
+    x2, _ = ctx.decompress(bP)
+    s = ctx.compress(oracle.add_xyzt(x1, x2))
+    apbP, _ = ctx.scalar_mul_var(P[:m], apb)
+    assert (s == apbP).all()
+    idx = np.arange(0, n, 1031)
+    o_out, _ = oracle.scalar_mul_var(P[idx], a[idx])
+    assert (aP[idx] == o_out).all()
+
+
+def test_bad_arguments(ctx):
+    import decaf377_amd as d
+    with pytest.raises(d.NativeError):
+        d.Context([99])

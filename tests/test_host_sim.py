@@ -1,0 +1,168 @@
+"""CPU check of the per-lane device functions (decaf377_amd/csrc/fq29.hpp, curve.hpp).
+
+The headers are compiled for the host with g++ into a test-only library under
+tests/host_sim/ (never loaded by the package) and compared with the oracle.  This
+covers the 29-bit-limb arithmetic, the lazy-reduction bounds, the Sarkar table
+construction and the curve formulas before any GPU run; the `-m gpu` tests then check
+the same functions as compiled by hipcc for gfx950."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM_DIR = os.path.join(ROOT, "tests", "host_sim")
+CSRC = os.path.join(ROOT, "decaf377_amd", "csrc")
+Q = 725501752471715841 | 6461107452199829505 << 64 | 6968279316240510977 << 128 | 1345280370688173398 << 192
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def sim():
+    lib = os.path.join(SIM_DIR, "libd377_sim.so")
+    srcs = [os.path.join(SIM_DIR, "sim.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC,
+                               os.path.join(SIM_DIR, "sim.cpp"), "-o", lib])
+    L = ctypes.CDLL(lib)
+    L.sim_init.restype = ctypes.c_int
+    assert L.sim_init() == 0, "s_lookup perfect hash has collisions"
+    return L
+
+
+def n_(n):
+    return ctypes.c_size_t(n)
+
+
+def test_constants(sim):
+    sub = np.zeros(9, np.uint32)
+    ql = np.zeros(9, np.uint32)
+    sim.sim_consts(_p(sub), _p(ql))
+    assert sum(int(v) << (29 * i) for i, v in enumerate(ql)) == Q
+    assert sum(int(v) << (29 * i) for i, v in enumerate(sub)) == 8 * Q
+    assert all((1 << 30) + 64 <= int(v) < (1 << 31) for v in sub[:8])
+
+
+def test_field_ops_match_oracle(sim, oracle):
+    rng = np.random.default_rng(11)
+    n = 4096
+    raw = rng.integers(0, 256, (2, n, 32), dtype=np.uint8)
+    # edge values: 0, 1, q-1, 2^256-1 (reduced), q+1
+    edges = [0, 1, Q - 1, (1 << 256) - 1, Q + 1, 2, Q - 2, 1 << 255]
+    for j, e in enumerate(edges):
+        raw[0, j] = np.frombuffer(int(e).to_bytes(32, "little"), np.uint8)
+        raw[1, -1 - j] = np.frombuffer(int(e).to_bytes(32, "little"), np.uint8)
+    a = oracle.fq_from_bytes_mod_order(raw[0])
+    b = oracle.fq_from_bytes_mod_order(raw[1])
+    # bytes -> Montgomery-256 through the 29-bit path
+    a_sim = np.zeros((n, 4), np.uint64)
+    sim.sim_fq_from_bytes(_p(np.ascontiguousarray(raw[0]).view(np.uint32)), n_(n), _p(a_sim))
+    assert (a_sim == a).all()
+    out = np.zeros((n, 4), np.uint64)
+    sim.sim_fq_mul(_p(a), _p(b), n_(n), _p(out))
+    assert (out == oracle.fq_mul_mont(a, b)).all()
+    sim.sim_fq_sqr(_p(a), n_(n), _p(out))
+    assert (out == oracle.fq_mul_mont(a, a)).all()
+    # add / sub against big-int arithmetic on canonical values
+    ab = oracle.fq_to_bytes(a)
+    bb = oracle.fq_to_bytes(b)
+    ai = [int.from_bytes(bytes(x), "little") for x in ab]
+    bi = [int.from_bytes(bytes(x), "little") for x in bb]
+    w = np.zeros((n, 32), np.uint8)
+    sim.sim_fq_add(_p(a), _p(b), n_(n), _p(out))
+    sim.sim_fq_to_bytes(_p(out), n_(n), _p(w))
+    assert [int.from_bytes(bytes(x), "little") for x in w] == [(x + y) % Q for x, y in zip(ai, bi)]
+    sim.sim_fq_sub(_p(a), _p(b), n_(n), _p(out))
+    sim.sim_fq_to_bytes(_p(out), n_(n), _p(w))
+    assert [int.from_bytes(bytes(x), "little") for x in w] == [(x - y) % Q for x, y in zip(ai, bi)]
+
+
+def test_sqrt_matches_oracle(sim, oracle, vectors):
+    rng = np.random.default_rng(12)
+    n = 512
+    num = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    den = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    v = vectors["sqrt_ratio_zeta"]
+    for i, c in enumerate(v):
+        num[i] = np.frombuffer(bytes.fromhex(c["num"]), np.uint8)
+        den[i] = np.frombuffer(bytes.fromhex(c["den"]), np.uint8)
+    root = np.zeros((n, 32), np.uint8)
+    ws = np.zeros(n, np.uint8)
+    sim.sim_sqrt_ratio_zeta(_p(num), _p(den), n_(n), _p(root), _p(ws))
+    r0, w0 = oracle.sqrt_ratio_zeta(num, den)
+    assert (ws == w0).all() and (root == r0).all()
+
+
+def test_group_ops_match_oracle(sim, oracle, vectors, kats):
+    rng = np.random.default_rng(13)
+    n = 256
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    enc = np.zeros((n, 32), np.uint8)
+    xyzt = np.zeros((n, 16), np.uint64)
+    sim.sim_encode_to_curve(_p(r0), n_(n), _p(enc), _p(xyzt))
+    assert (enc == oracle.encode_to_curve(r0)).all()
+    assert (xyzt == oracle.elligator_map_xyzt(r0)).all()
+    # decompress: valid + raw + golden decompress set
+    raw = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x3F
+    dv = np.array([list(bytes.fromhex(c["enc"])) for c in vectors["decompress"]], dtype=np.uint8)
+    allenc = np.concatenate([enc, raw, dv])
+    m = allenc.shape[0]
+    x2 = np.zeros((m, 16), np.uint64)
+    st = np.zeros(m, np.uint8)
+    sim.sim_decompress(_p(allenc), n_(m), _p(x2), _p(st))
+    xo, so = oracle.decompress(allenc)
+    assert (st == so).all() and (x2 == xo).all()
+    out = np.zeros((m, 32), np.uint8)
+    sim.sim_roundtrip(_p(allenc), n_(m), _p(out), _p(st))
+    oo, so = oracle.roundtrip(allenc)
+    assert (st == so).all() and (out == oo).all()
+    # compress of non-affine points (z != 1): doubles of the Elligator images
+    dbl = oracle.double_xyzt(xyzt)
+    c1 = np.zeros((n, 32), np.uint8)
+    sim.sim_compress(_p(dbl), n_(n), _p(c1))
+    assert (c1 == oracle.compress(dbl)).all()
+    # identity and basepoint multiples
+    hexes = kats["basepoint_multiples"]["hex"]
+    ks = np.zeros((16, 32), np.uint8)
+    ks[:, 0] = np.arange(16)
+    o = np.zeros((16, 32), np.uint8)
+    sim.sim_scalar_mul_base(_p(ks), n_(16), _p(o))
+    assert [bytes(x).hex() for x in o] == hexes
+
+
+def test_scalar_mul_matches_oracle(sim, oracle, vectors):
+    v = vectors["scalar_mul_var"]
+    pts = np.array([list(bytes.fromhex(c["point"])) for c in v], dtype=np.uint8)
+    ks = np.array([list(bytes.fromhex(c["scalar"])) for c in v], dtype=np.uint8)
+    n = len(v)
+    out = np.zeros((n, 32), np.uint8)
+    st = np.zeros(n, np.uint8)
+    sim.sim_scalar_mul_var(_p(pts), _p(ks), n_(n), _p(out), _p(st))
+    assert [bytes(x).hex() for x in out] == [c["enc"] for c in v]
+    assert list(st) == [c["status"] for c in v]
+    v = vectors["scalar_mul_base"]
+    ks = np.array([list(bytes.fromhex(c["scalar"])) for c in v], dtype=np.uint8)
+    out = np.zeros((len(v), 32), np.uint8)
+    sim.sim_scalar_mul_base(_p(ks), n_(len(v)), _p(out))
+    assert [bytes(x).hex() for x in out] == [c["enc"] for c in v]
+    # random set against the oracle
+    rng = np.random.default_rng(14)
+    n = 96
+    enc = oracle.encode_to_curve(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    out = np.zeros((n, 32), np.uint8)
+    st = np.zeros(n, np.uint8)
+    sim.sim_scalar_mul_var(_p(enc), _p(k), n_(n), _p(out), _p(st))
+    oo, so = oracle.scalar_mul_var(enc, k)
+    assert (out == oo).all() and (st == so).all()
+    sim.sim_scalar_mul_base(_p(k), n_(n), _p(out))
+    assert (out == oracle.scalar_mul_base(k)).all()
+    red = np.zeros((n, 32), np.uint8)
+    sim.sim_fr_reduce(_p(k), n_(n), _p(red))
+    assert (red == oracle.fr_from_bytes_mod_order(k)).all()
