@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the decaf377 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the headline workload over one batch of synthetic input that is
+already resident in HBM: BASELINE.json configs[3], 2^22 variable-base scalar multiplications
+(random Element x random Fr: decompress, [k]P, compress) PER GPU (weak scaling: every rank owns
+its own 2^22-element shard, no data-path collective).  Rank 0 prints ONE JSON line.
+
+Besides the contract keys the line carries
+  roofline       HBM view of the dominant kernel (k_scalar_mul_var): algorithmic bytes / launch
+                 duration (HIP events on the launch stream) against the 8 TB/s peak;
+  roofline_valu  the view that actually binds: integer MACs/s against the v_mad_u64_u32 issue
+                 rate measured on this chip (tools/valu_rates.hip, profiles/r01_valu_rates_*);
+  cpu_baseline   the C restatement of the reference algorithm (oracle/, kind "port") timed on the
+                 host cores of this box on the same workload (rank 0, N = 1 only);
+  extra          encodes/s of the other batch operations (round trip, Elligator, fixed base, sqrt).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes and reference-algorithm work per unit
+ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "scalar_mul_base": 64,
+              "sqrt_ratio_zeta": 97}
+# 32-bit MACs our kernels execute per unit (counted from the schedule)
+KERNEL_MACS = {"scalar_mul_var": 4.63e5}
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+VALU_MAC_PEAK = 3.28e13               # measured: v_mad_u64_u32 lane-ops/s, 8 waves/SIMD (profiles/r01_valu_rates_microbench.txt)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=22, help="elements per GPU per step (2^log2n)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    return ap.parse_args()
+
+
+def time_op(torch, fn, steps, warmup):
+    """Returns (avg kernel ms via HIP events on the current stream, wall ms per step)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3 / steps
+    ker = sum(a.elapsed_time(b) for a, b in evs) / steps
+    return ker, wall
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import decaf377_amd as d
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = d.Context([local])
+    n = 1 << args.log2n
+
+    # synthetic shard of this rank, generated on the device and resident before timing
+    g = torch.Generator(device=dev).manual_seed(666 + rank)
+    r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    scalars = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    points = ctx.encode_to_curve(r0)          # valid encodings, strategy of tests/operations.rs:6-11
+    out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    status = torch.empty((n,), dtype=torch.uint8, device=dev)
+
+    def step():
+        ctx.scalar_mul_var(points, scalars, outs=[out, status])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(status.sum().item()) == 0, "valid inputs must all decode"
+
+    total_units = n * world * args.steps
+    value = total_units / elapsed
+    line = {
+        "metric": "decaf377 var-base scalar-mults/sec + encodes/sec at 1/2/4/8 MI355X",
+        "value": value,
+        "unit": "scalar-mults/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": "2^%d variable-base scalar mult (random Element x random Fr -> Encoding) per GPU, "
+                        "BASELINE.json configs[3]" % args.log2n,
+            "elements_per_gpu": n,
+            "elements_total": n * world,
+            "sharding": "independent contiguous shards, one process per GPU, no data-path collective",
+            "inputs": "points = encode_to_curve(rand32), scalars = rand32 (reduced mod r on the GPU), seed 666+rank",
+        },
+    }
+    algo_bytes = ALGO_BYTES["scalar_mul_var"] * n
+    ach = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath)).get("k_scalar_mul_var")
+            if rec and rec.get("elements") == n:
+                traffic = rec["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    line["roofline"] = {
+        "kernel": "k_scalar_mul_var",
+        "bound": "hbm",
+        "achieved": ach,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": ach / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "kernel_ms": kernel_ms,
+        "note": "integer-ALU-bound kernel: ~4.6e5 32-bit MACs per 97 algorithmic bytes; see roofline_valu",
+    }
+    macs = KERNEL_MACS["scalar_mul_var"] * n / (kernel_ms * 1e-3)
+    line["roofline_valu"] = {
+        "bound": "valu_int32_mac",
+        "achieved": macs / 1e12,
+        "peak": VALU_MAC_PEAK / 1e12,
+        "unit": "TMAC/s",
+        "frac": macs / VALU_MAC_PEAK,
+    }
+
+    if not args.no_extra:
+        extra = {}
+        ne = 1 << 20
+        enc1 = points[:ne]
+        o1 = torch.empty((ne, 32), dtype=torch.uint8, device=dev)
+        s1 = torch.empty((ne,), dtype=torch.uint8, device=dev)
+        for name, fn in [
+            ("roundtrip", lambda: ctx.roundtrip(enc1, outs=[o1, s1])),
+            ("encode_to_curve", lambda: ctx.encode_to_curve(r0[:ne], outs=[o1])),
+            ("scalar_mul_base", lambda: ctx.scalar_mul_base(scalars[:ne], outs=[o1])),
+            ("sqrt_ratio_zeta", lambda: ctx.sqrt_ratio_zeta(r0[:ne], scalars[:ne], outs=[o1, s1])),
+        ]:
+            ker, _ = time_op(torch, fn, 3, 1)
+            extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3),
+                           "algo_GBps": ALGO_BYTES[name] * ne / (ker * 1e-3) / 1e9}
+        extra["encodes_per_sec"] = extra["roundtrip"]["per_sec"]
+        line["extra"] = extra
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _oracle import Oracle
+        orc = Oracle()
+        cores = min(os.cpu_count() or 1, 256)
+        ns = min(n, cores * 40000)
+        p_h = points[:ns].cpu().numpy()
+        k_h = scalars[:ns].cpu().numpy()
+        t0 = time.perf_counter()
+        o_out, o_st, used = orc.run_threads("scalar_mul_var", p_h, k_h, cores)
+        dt = time.perf_counter() - t0
+        same = bool((o_out == out[:ns].cpu().numpy()).all() and not o_st.any())
+        line["cpu_baseline"] = {
+            "value": ns / dt,
+            "unit": "scalar-mults/s",
+            "cores": used,
+            "kind": "port",
+            "sample": "first %d of the %d (point, scalar) pairs of this run, %d pthreads over contiguous slices; "
+                      "C restatement of the reference algorithm (Sarkar sqrt, 256-step double-and-add, 4x64 "
+                      "Montgomery), gcc -O3 -march=x86-64-v3" % (ns, n, used),
+            "seconds": dt,
+            "matches_gpu_output": same,
+        }
+        assert same, "GPU output differs from the oracle on the cpu_baseline sample"
+
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
