@@ -72,33 +72,44 @@ D377_HD fe fe_pow_2_47_m1(const fe& x) {
 }
 
 // x^((m-1)/2), m = (q-1)/2^47: sliding window (w = 4) over the fixed exponent, the schedule
-// is the byte table POW_M12_CHAIN (wave-uniform, so no divergence): 201 S + 36 M + table.
-D377_HD fe fe_pow_m12(const fe& x) {
-  fe x2 = fe_sqr(x);
-  fe t1 = x, t3 = fe_mul(t1, x2), t5 = fe_mul(t3, x2), t7 = fe_mul(t5, x2);
-  fe t9 = fe_mul(t7, x2), t11 = fe_mul(t9, x2), t13 = fe_mul(t11, x2), t15 = fe_mul(t13, x2);
-  fe acc = fe_zero();
-#pragma unroll 1
-  for (int i = 0; i < D377_POW_M12_LEN; ++i) {
-    const uint32_t e = POW_M12_CHAIN[i];
-    const int nsq = (int)(e >> 4), d = (int)(e & 15u);
+// is the table POW_M12_CHAIN (wave-uniform, so no divergence): 201 S + 36 M + table (1 S + 7 M).
+// The 8 odd powers live in `PT` (LDS on the GPU, one column per lane: conflict-free), which
+// keeps 72 VGPRs free for a second wave per SIMD.
+struct RegPowTab {                      // plain registers / stack (host simulation, init kernels)
+  fe t[8];
+  D377_HD void put(int j, const fe& v) { t[j] = v; }
+  D377_HD fe get(int j) const {
     fe f;
-    switch (d >> 1) {
-      case 0: f = t1; break;
-      case 1: f = t3; break;
-      case 2: f = t5; break;
-      case 3: f = t7; break;
-      case 4: f = t9; break;
-      case 5: f = t11; break;
-      case 6: f = t13; break;
-      default: f = t15; break;
+    switch (j) {
+      case 0: f = t[0]; break;
+      case 1: f = t[1]; break;
+      case 2: f = t[2]; break;
+      case 3: f = t[3]; break;
+      case 4: f = t[4]; break;
+      case 5: f = t[5]; break;
+      case 6: f = t[6]; break;
+      default: f = t[7]; break;
     }
-    if (i == 0) {
-      acc = f;
-    } else {
-      acc = fe_sqr_n(acc, nsq);
-      acc = fe_mul(acc, f);
-    }
+    return f;
+  }
+};
+
+template <class PT>
+D377_HD fe fe_pow_m12(const fe& x, PT& pt) {
+  fe x2 = fe_sqr(x);
+  fe cur = x;
+  pt.put(0, cur);
+#pragma unroll 1
+  for (int j = 1; j < 8; ++j) {
+    cur = fe_mul(cur, x2);
+    pt.put(j, cur);
+  }
+  fe acc = pt.get((int)(POW_M12_CHAIN[0] & 15u) >> 1);
+#pragma unroll 1
+  for (int i = 1; i < D377_POW_M12_LEN; ++i) {
+    const uint32_t e = POW_M12_CHAIN[i];
+    acc = fe_sqr_n(acc, (int)(e >> 4));
+    acc = fe_mul(acc, pt.get((int)(e & 15u) >> 1));
   }
   return fe_sqr_n(acc, D377_POW_M12_TRAILING_SQ);
 }
@@ -115,16 +126,16 @@ D377_HD bool fe_mulout_is_zero(const fe& a) {
 // src/ark_curve/invsqrt.rs:75-166.  `den` must be a multiplication output (tight, < 2q).
 // NUM_IS_ONE: the callers on the group path always pass num = 1 (encoding.rs:57,100;
 // elligator.rs:26); the generic form is used by the raw batch entry point.
-template <bool NUM_IS_ONE>
-D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, const fe& num, const fe& den, fe* res) {
+template <bool NUM_IS_ONE, class PT>
+D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, const fe& den, fe* res) {
   const bool den_zero = fe_mulout_is_zero(den);
   bool num_zero = false;
   if (!NUM_IS_ONE) num_zero = fe_mulout_is_zero(num);
 
   fe s = fe_pow_2_47_m1(den);                       // invsqrt.rs:88-89
   fe t_ = fe_mul(fe_sqr(s), den);                   // :90
-  fe w = NUM_IS_ONE ? fe_mul(fe_pow_m12(t_), s)     // :91
-                    : fe_mul(fe_pow_m12(fe_mul(num, t_)), s);
+  fe w = NUM_IS_ONE ? fe_mul(fe_pow_m12(t_, pt), s)     // :91
+                    : fe_mul(fe_pow_m12(fe_mul(num, t_), pt), s);
   fe v = fe_mul(w, den);                            // :93
   fe uv = NUM_IS_ONE ? w : fe_mul(w, num);          // :94
   fe x5 = fe_mul(uv, v);                            // :97
@@ -276,7 +287,8 @@ D377_HD ge ge_select(bool c, const ge& a, const ge& b) {
 // ---- encoding ------------------------------------------------------------------------------
 // Encoding::vartime_decompress, src/ark_curve/encoding.rs:32-83.  Returns status
 // (0 ok, 1 InvalidEncoding); on failure *out is unspecified (callers write zeros).
-D377_HD uint32_t ge_decompress(const SqrtTables& T, const uint32_t w[8], ge* out) {
+template <class PT>
+D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8], ge* out) {
   uint32_t bad = (w[7] >> 29) != 0;                       // top three bits, encoding.rs:34
   bad |= (uint32_t)words_geq(w, FQ_MODULUS_W_LIT);        // canonical, :43-44
   bad |= (w[0] & 1u);                                     // s negative, :45
@@ -286,7 +298,7 @@ D377_HD uint32_t ge_decompress(const SqrtTables& T, const uint32_t w[8], ge* out
   fe u1sq = fe_sqr(u1);
   fe u2 = fe_sub(u1sq, fe_mul(fe_const(FE_4D), ss));      // :54
   fe v;
-  const bool was_square = fe_sqrt_ratio_zeta<true>(T, fe_zero(), fe_mul(u2, u1sq), &v);   // :57
+  const bool was_square = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul(u2, u1sq), &v);   // :57
   bad |= (uint32_t)!was_square;                           // :58-60
   fe two_s_u1 = fe_mul(fe_dbl(s), u1);                    // :63
   if (fe_is_negative(fe_mul(two_s_u1, v))) v = fe_neg(v); // :64-67
@@ -298,11 +310,12 @@ D377_HD uint32_t ge_decompress(const SqrtTables& T, const uint32_t w[8], ge* out
 }
 
 // Element::vartime_compress, src/ark_curve/encoding.rs:91-128 -> canonical words of s
-D377_HD void ge_compress(const SqrtTables& T, const ge& p, uint32_t w[8]) {
+template <class PT>
+D377_HD void ge_compress(const SqrtTables& T, PT& pt, const ge& p, uint32_t w[8]) {
   const fe a_minus_d = fe_const(FE_A_MINUS_D);
   fe u1 = fe_mul(fe_add(p.x, p.t), fe_sub(p.x, p.t));                       // :97
   fe v;
-  (void)fe_sqrt_ratio_zeta<true>(T, fe_zero(), fe_mul(fe_mul(u1, a_minus_d), fe_sqr(p.x)), &v);  // :101
+  (void)fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul(fe_mul(u1, a_minus_d), fe_sqr(p.x)), &v);  // :101
   fe u2 = fe_abs(fe_mul(v, u1));                                            // :104
   fe u3 = fe_sub(fe_mul(u2, p.z), p.t);                                     // :107
   fe s = fe_mul(fe_mul(fe_mul(a_minus_d, v), u3), p.x);                     // :110
@@ -313,13 +326,14 @@ D377_HD void ge_compress(const SqrtTables& T, const ge& p, uint32_t w[8]) {
 }
 
 // Element::elligator_map, src/ark_curve/elligator.rs:15-62.  r0 in Montgomery-261.
-D377_HD ge ge_elligator_map(const SqrtTables& T, const fe& r0) {
+template <class PT>
+D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0) {
   const fe one = fe_const(FE_ONE), dma = fe_const(FE_D_MINUS_A), dd = fe_const(FE_D);
   fe r = fe_mul(fe_const(FE_ZETA), fe_sqr(r0));                                   // :20
   fe den = fe_mul(fe_sub(fe_mul(dd, r), dma), fe_sub(fe_mul(dma, r), dd));        // :22
   fe num = fe_mul(fe_add(r, one), fe_const(FE_A_MINUS_2D));                       // :23
   fe isri;
-  const bool iss = fe_sqrt_ratio_zeta<true>(T, fe_zero(), fe_mul(num, den), &isri);   // :25-26
+  const bool iss = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul(num, den), &isri);   // :25-26
   isri = fe_select(iss, isri, fe_mul(isri, r0));                                  // twiddle, :28-38
   fe s = fe_mul(isri, num);                                                       // :40
   fe p = fe_mul(fe_mul(fe_mul(isri, s), fe_sub(r, one)), fe_const(FE_A_MINUS_2D_SQ));
@@ -383,49 +397,153 @@ D377_HD int fr_digit(const uint32_t digits[8], int i) {   // signed value of nib
   return (int)(n ^ 8u) - 8;
 }
 
+// ---- fast group formulas for the scalar-multiplication loops -------------------------------
+// Same group law as ge_add / ge_double above (src/min_curve/element.rs:291-322, 119-136), with
+// the usual savings: T is only produced when the next operation consumes it, table entries are
+// kept in "cached" form (Y+X, Y-X, 2Z, 2d*T), and the doubling is sign-folded so it needs two
+// offset subtractions instead of four (with G' = A-B, H' = A+B, F' = G'+C, E' = H'-S:
+// X3 = E'F', Y3 = G'H', Z3 = F'G', T3 = E'H').
+struct gec { fe ypx, ymx, z2, kt; };      // cached extended point
+
+D377_HD ge ge_double_fast(const ge& p, bool with_t) {
+  fe a = fe_sqr(p.x), b = fe_sqr(p.y);
+  fe c = fe_dbl(fe_sqr(p.z));             // lazy
+  fe s_ = fe_sqr(fe_add(p.x, p.y));
+  fe h = fe_add(a, b);                    // H' lazy
+  fe e = fe_sub(h, s_);                   // E' = A + B - (X+Y)^2, tight
+  fe g = fe_sub(a, b);                    // G' tight
+  fe f = fe_add(g, c);                    // F' = G' + 2Z^2 (limbs < 1.5 * 2^30, times a tight operand only)
+  ge r;
+  r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g);
+  r.t = p.t;
+  if (with_t) r.t = fe_mul(e, h);
+  return r;
+}
+
+D377_HD gec ge_to_cached(const ge& p) {
+  gec c;
+  c.ypx = fe_add(p.y, p.x);               // lazy
+  c.ymx = fe_sub(p.y, p.x);
+  c.z2 = fe_dbl(p.z);                     // lazy
+  c.kt = fe_mul(fe_const(FE_K), p.t);
+  return c;
+}
+
+// p + (neg ? -q : q).  The caller has already swapped q.ypx / q.ymx for a negative digit (the
+// table loader does it by address); the sign of 2dT is applied here by swapping F and G.
+D377_HD ge ge_add_cached(const ge& p, const gec& q, bool neg, bool with_t) {
+  fe a = fe_mul(fe_sub(p.y, p.x), q.ymx);
+  fe b = fe_mul(fe_add(p.y, p.x), q.ypx);
+  fe c = fe_mul(p.t, q.kt);
+  fe d = fe_mul(p.z, q.z2);
+  fe e = fe_sub(b, a), h = fe_add(b, a);
+  fe dmc = fe_sub(d, c), dpc = fe_add(d, c);
+  fe f = fe_select(neg, dpc, dmc), g = fe_select(neg, dmc, dpc);
+  ge r;
+  r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g);
+  r.t = p.t;
+  if (with_t) r.t = fe_mul(e, h);
+  return r;
+}
+
+// affine cached entry (Z = 1): fixed-base table, 6 M (+1 for T)
+struct gea { fe ypx, ymx, kt; };
+D377_HD ge ge_add_affine(const ge& p, const gea& q, bool neg, bool with_t) {
+  fe a = fe_mul(fe_sub(p.y, p.x), q.ymx);
+  fe b = fe_mul(fe_add(p.y, p.x), q.ypx);
+  fe c = fe_mul(p.t, q.kt);
+  fe d = fe_dbl(p.z);                     // lazy
+  fe e = fe_sub(b, a), h = fe_add(b, a);
+  fe dmc = fe_sub(d, c), dpc = fe_carry(fe_add(d, c));
+  fe f = fe_select(neg, dpc, dmc), g = fe_select(neg, dmc, dpc);
+  ge r;
+  r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g);
+  r.t = p.t;
+  if (with_t) r.t = fe_mul(e, h);
+  return r;
+}
+
 // ---- scalar multiplication ----------------------------------------------------------------
-// [k]P with signed 4-bit windows, MSB first: 63 x (4 doublings + 1 table addition).
-// `Tab` is where the per-lane table 0..8 * P lives (global scratch on the GPU): it must
-// provide store(j, ge) and load(j) -> ge for j in 0..8.
+// [k]P with signed 4-bit windows, MSB first: 63 x (4 doublings + 1 cached addition).
+// `Tab` holds the per-lane table of cached 0..8 * P (global scratch on the GPU): it provides
+// store(j, gec) and load(j, swap) -> gec, where swap exchanges ypx / ymx (negative digit).
 template <class Tab>
 D377_HD ge ge_scalar_mul_w4(const ge& p, const uint32_t digits[8], Tab& tab) {
-  tab.store(0, ge_identity());
-  tab.store(1, p);
-  ge acc = ge_double(p);
-  tab.store(2, acc);
+  {
+    gec id;
+    id.ypx = fe_const(FE_ONE); id.ymx = fe_const(FE_ONE); id.z2 = fe_dbl(fe_const(FE_ONE)); id.kt = fe_zero();
+    tab.store(0, id);
+  }
+  const gec pc = ge_to_cached(p);
+  tab.store(1, pc);
+  ge acc = ge_double_fast(p, true);
+  tab.store(2, ge_to_cached(acc));
 #pragma unroll 1
   for (int j = 3; j <= 8; ++j) {
-    acc = ge_add(acc, p);
-    tab.store(j, acc);
+    acc = ge_add_cached(acc, pc, false, true);
+    tab.store(j, ge_to_cached(acc));
   }
   int d = fr_digit(digits, 63);                 // 0 or 1
-  ge r = tab.load(d);
+  ge r = ge_select(d != 0, p, ge_identity());
 #pragma unroll 1
   for (int i = 62; i >= 0; --i) {
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) r = ge_double(r);
+    for (int j = 0; j < 4; ++j) r = ge_double_fast(r, j == 3);
     d = fr_digit(digits, i);
-    const int ad = d < 0 ? -d : d;
-    ge e = tab.load(ad);
-    e = ge_select(d < 0, ge_neg(e), e);
-    r = ge_add(r, e);
+    const bool neg = d < 0;
+    const gec e = tab.load(neg ? -d : d, neg);
+    r = ge_add_cached(r, e, neg, i == 0);       // only the compressor needs the last T
   }
   return r;
 }
 
-// [k]B from the shared table FB[i][j] = j * 16^i * B (i = 0..63, j = 0..8): 64 additions.
+// signed radix-256 recoding of k < 2^251: k = sum d_i 256^i, d_i in [-128, 128), i = 0..31
+D377_HD void fr_recode_signed256(const uint32_t k[8], int digits[32]) {
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    uint32_t d = ((k[i >> 2] >> (8 * (i & 3))) & 255u) + carry;
+    carry = (d >= 128u) ? 1u : 0u;
+    digits[i] = (int)d - (int)(carry << 8);
+  }
+  // byte 31 of k is <= 7 (k < 2^251), so the last digit is <= 8 and there is no final carry
+}
+
+// [k]B from the shared table FB[i][j] = affine cached j * 256^i * B (i = 0..31, j = 0..128):
+// 32 mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.
+constexpr int FB_WINDOWS = 32;
+constexpr int FB_ENTRIES = 129;
 template <class FTab>
-D377_HD ge ge_scalar_mul_base_w4(const uint32_t digits[8], const FTab& ftab) {
+D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab) {
   ge r = ge_identity();
+  uint32_t carry = 0;
 #pragma unroll 1
-  for (int i = 0; i < 64; ++i) {
-    const int d = fr_digit(digits, i);
-    const int ad = d < 0 ? -d : d;
-    ge e = ftab.load(i, ad);
-    e = ge_select(d < 0, ge_neg(e), e);
-    r = ge_add(r, e);
+  for (int i = 0; i < FB_WINDOWS; ++i) {
+    uint32_t dd = ((k[i >> 2] >> (8 * (i & 3))) & 255u) + carry;
+    carry = (dd >= 128u) ? 1u : 0u;
+    const int d = (int)dd - (int)(carry << 8);
+    const bool neg = d < 0;
+    const gea e = ftab.load(i, neg ? -d : d, neg);
+    r = ge_add_affine(r, e, neg, true);
   }
   return r;
+}
+
+// generic x^e for a 256-bit exponent given as 8 words (init kernels only: inversion by q - 2)
+D377_HD fe fe_pow_words(const fe& x, const uint32_t (&e)[8]) {
+  fe r = fe_const(FE_ONE);
+#pragma unroll 1
+  for (int i = 255; i >= 0; --i) {
+    r = fe_sqr(r);
+    if ((e[i >> 5] >> (i & 31)) & 1u) r = fe_mul(r, x);
+  }
+  return r;
+}
+D377_HD fe fe_invert(const fe& x) {
+  // q - 2: q's low word is 0x00000001, so the subtraction borrows from the next word
+  const uint32_t ee[8] = {0xFFFFFFFFu, FQ_MODULUS_W_LIT[1] - 1u, FQ_MODULUS_W_LIT[2], FQ_MODULUS_W_LIT[3],
+                          FQ_MODULUS_W_LIT[4], FQ_MODULUS_W_LIT[5], FQ_MODULUS_W_LIT[6], FQ_MODULUS_W_LIT[7]};
+  return fe_pow_words(x, ee);
 }
 
 }  // namespace d377

@@ -21,8 +21,11 @@ using namespace d377;
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int FB_WORDS = 36;                 // one extended point: 4 x 9 limbs
-constexpr int VB_ENTRIES = 9;                // 0..8 times P
+constexpr int WAVES_PER_SIMD = 2;            // occupancy the kernels are built for (<= 256 VGPRs, 72 KiB LDS/block)
+constexpr int SLOT = 12;                     // one field element slot in a table entry: 9 limbs + 3 pad = 3 x 16 B
+constexpr int VB_ENTRIES = 9;                // cached 0..8 times P
+constexpr int VB_ENTRY_WORDS = 4 * SLOT;     // ypx, ymx, z2, kt: 192 B, 64-B aligned
+constexpr int FBW_ENTRY_WORDS = 3 * SLOT;    // affine cached: ypx, ymx, kt: 144 B
 
 // ------------------------------------------------------------------ record I/O helpers ---
 __device__ __forceinline__ void load32(const uint8_t* base, size_t i, uint32_t w[8]) {
@@ -59,51 +62,72 @@ __device__ __forceinline__ ge load_ge_mont256(const uint64_t* xyzt, size_t i) {
   return g;
 }
 
-// per-lane window table in global scratch, laid out [entry][word][thread] so that the
-// stores (same entry for every lane) are fully coalesced dword rows
+__device__ __forceinline__ void slot_store(uint32_t* p, const fe& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  q[2] = make_uint4(v.l[8], 0, 0, 0);
+}
+__device__ __forceinline__ fe slot_load(const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1], c = q[2];
+  fe r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x;
+  return r;
+}
+
+// the 8 odd powers of the fixed exponentiation, one LDS column per lane (bank = lane: no conflicts)
+struct LdsPowTab {
+  uint32_t* col;                           // &lds[threadIdx.x]
+  __device__ __forceinline__ void put(int j, const fe& v) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) col[(j * NL + k) * BLOCK] = v.l[k];
+  }
+  __device__ __forceinline__ fe get(int j) const {
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * BLOCK];
+    return r;
+  }
+};
+#define D377_POW_LDS()                                         \
+  __shared__ uint32_t lds_pow_[8 * NL * BLOCK];                \
+  LdsPowTab pt;                                                \
+  pt.col = lds_pow_ + threadIdx.x
+
+// per-lane window table of the variable-base kernel in global scratch, laid out
+// [entry][thread][4 slots x 12 words]: a wave stores one entry as 12 KiB contiguous, and a lane
+// fetches its 192-byte (three 64-B sectors) record with 16-byte loads.  A negative digit
+// swaps the ypx / ymx slots by address.
 struct GlobalTab {
   uint32_t* base;
   size_t nthreads, tid;
-  __device__ __forceinline__ void store(int j, const ge& g) {
-    uint32_t* p = base + (size_t)j * FB_WORDS * nthreads + tid;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      p[(size_t)(k) * nthreads] = g.x.l[k];
-      p[(size_t)(NL + k) * nthreads] = g.y.l[k];
-      p[(size_t)(2 * NL + k) * nthreads] = g.z.l[k];
-      p[(size_t)(3 * NL + k) * nthreads] = g.t.l[k];
-    }
+  __device__ __forceinline__ void store(int j, const gec& c) {
+    uint32_t* p = base + ((size_t)j * nthreads + tid) * VB_ENTRY_WORDS;
+    slot_store(p, c.ypx); slot_store(p + SLOT, c.ymx); slot_store(p + 2 * SLOT, c.z2); slot_store(p + 3 * SLOT, c.kt);
   }
-  __device__ __forceinline__ ge load(int j) const {
-    const uint32_t* p = base + (size_t)j * FB_WORDS * nthreads + tid;
-    ge g;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      g.x.l[k] = p[(size_t)(k) * nthreads];
-      g.y.l[k] = p[(size_t)(NL + k) * nthreads];
-      g.z.l[k] = p[(size_t)(2 * NL + k) * nthreads];
-      g.t.l[k] = p[(size_t)(3 * NL + k) * nthreads];
-    }
-    return g;
+  __device__ __forceinline__ gec load(int j, bool swap) const {
+    const uint32_t* p = base + ((size_t)j * nthreads + tid) * VB_ENTRY_WORDS;
+    gec c;
+    c.ypx = slot_load(p + (swap ? SLOT : 0));
+    c.ymx = slot_load(p + (swap ? 0 : SLOT));
+    c.z2 = slot_load(p + 2 * SLOT);
+    c.kt = slot_load(p + 3 * SLOT);
+    return c;
   }
 };
-// shared fixed-base table FB[i][j] = j * 16^i * B, [64][9][36] words
+// shared fixed-base comb FB[i][j] = affine cached j * 256^i * B, [32][129][3 slots]
 struct FixedTab {
   const uint32_t* base;
-  __device__ __forceinline__ ge load(int i, int j) const {
-    const uint4* p = reinterpret_cast<const uint4*>(base + ((size_t)i * VB_ENTRIES + j) * FB_WORDS);
-    uint32_t w[FB_WORDS];
-#pragma unroll
-    for (int k = 0; k < FB_WORDS / 4; ++k) {
-      uint4 v = p[k];
-      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-    }
-    ge g;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      g.x.l[k] = w[k]; g.y.l[k] = w[NL + k]; g.z.l[k] = w[2 * NL + k]; g.t.l[k] = w[3 * NL + k];
-    }
-    return g;
+  __device__ __forceinline__ gea load(int i, int j, bool swap) const {
+    const uint32_t* p = base + ((size_t)i * FB_ENTRIES + j) * FBW_ENTRY_WORDS;
+    gea c;
+    c.ypx = slot_load(p + (swap ? SLOT : 0));
+    c.ymx = slot_load(p + (swap ? 0 : SLOT));
+    c.kt = slot_load(p + 2 * SLOT);
+    return c;
   }
 };
 
@@ -172,47 +196,53 @@ __global__ void __launch_bounds__(BLOCK) k_init_slookup(uint8_t* s_lookup, uint3
   }
 }
 
-// FB[i][j] = j * 16^i * B for i = 0..63, j = 0..8
-__global__ void __launch_bounds__(64) k_init_fbase(uint32_t* fb) {
-  const int i = threadIdx.x;
+// FB[i][j] = j * 256^i * B in affine cached form, i = 0..31, j = 0..128 (one thread per entry)
+__global__ void __launch_bounds__(BLOCK) k_init_fbase(uint32_t* fb) {
+  const int idx = blockIdx.x * BLOCK + threadIdx.x;
+  if (idx >= FB_WINDOWS * FB_ENTRIES) return;
+  const int i = idx / FB_ENTRIES, j = idx % FB_ENTRIES;
   ge pi = ge_generator();
 #pragma unroll 1
-  for (int k = 0; k < 4 * i; ++k) pi = ge_double(pi);
+  for (int k = 0; k < 8 * i; ++k) pi = ge_double(pi);
   ge acc = ge_identity();
 #pragma unroll 1
-  for (int j = 0; j < VB_ENTRIES; ++j) {
-    uint32_t* p = fb + ((size_t)i * VB_ENTRIES + j) * FB_WORDS;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      p[k] = acc.x.l[k]; p[NL + k] = acc.y.l[k]; p[2 * NL + k] = acc.z.l[k]; p[3 * NL + k] = acc.t.l[k];
-    }
-    acc = ge_add(acc, pi);
+  for (int b = 7; b >= 0; --b) {
+    acc = ge_double(acc);
+    if ((j >> b) & 1) acc = ge_add(acc, pi);
   }
+  const fe zi = fe_invert(acc.z);
+  const fe x = fe_mul(acc.x, zi), y = fe_mul(acc.y, zi);
+  uint32_t* p = fb + (size_t)idx * FBW_ENTRY_WORDS;
+  slot_store(p, fe_carry(fe_add(y, x)));
+  slot_store(p + SLOT, fe_sub(y, x));
+  slot_store(p + 2 * SLOT, fe_mul(fe_mul(fe_const(FE_K), x), y));
 }
 
 // --------------------------------------------------------------------------- batch kernels ---
-__global__ void __launch_bounds__(BLOCK) k_sqrt_ratio_zeta(SqrtTables T, const uint8_t* num32,
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtTables T, const uint8_t* num32,
                                                            const uint8_t* den32, size_t n,
                                                            uint8_t* root32, uint8_t* was_square) {
+  D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t wn[8], wd[8], wr[8];
     load32(num32, i, wn);
     load32(den32, i, wd);
     fe r;
-    const bool ws = fe_sqrt_ratio_zeta<false>(T, fe_from_words_mod_order(wn), fe_from_words_mod_order(wd), &r);
+    const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, fe_from_words_mod_order(wn), fe_from_words_mod_order(wd), &r);
     fe_to_bytes_words(r, wr);
     store32(root32, i, wr);
     was_square[i] = ws ? 1 : 0;
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
                                                       uint64_t* xyzt, uint8_t* status) {
+  D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t w[8];
     load32(enc32, i, w);
     ge g;
-    const uint32_t bad = ge_decompress(T, w, &g);
+    const uint32_t bad = ge_decompress(T, pt, w, &g);
     status[i] = (uint8_t)bad;
     if (bad) {
       uint8_t* b = reinterpret_cast<uint8_t*>(xyzt);
@@ -223,55 +253,60 @@ __global__ void __launch_bounds__(BLOCK) k_decompress(SqrtTables T, const uint8_
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_compress(SqrtTables T, const uint64_t* xyzt, size_t n,
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_compress(SqrtTables T, const uint64_t* xyzt, size_t n,
                                                     uint8_t* enc32) {
+  D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t w[8];
-    ge_compress(T, load_ge_mont256(xyzt, i), w);
+    ge_compress(T, pt, load_ge_mont256(xyzt, i), w);
     store32(enc32, i, w);
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_roundtrip(SqrtTables T, const uint8_t* enc32, size_t n,
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_roundtrip(SqrtTables T, const uint8_t* enc32, size_t n,
                                                      uint8_t* out32, uint8_t* status) {
+  D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t w[8];
     load32(enc32, i, w);
     ge g;
-    const uint32_t bad = ge_decompress(T, w, &g);
-    ge_compress(T, g, w);
+    const uint32_t bad = ge_decompress(T, pt, w, &g);
+    ge_compress(T, pt, g, w);
     status[i] = (uint8_t)bad;
     if (bad) store32_zero(out32, i); else store32(out32, i, w);
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_encode_to_curve(SqrtTables T, const uint8_t* fq32, size_t n,
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtTables T, const uint8_t* fq32, size_t n,
                                                            uint8_t* out32) {
+  D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t w[8];
     load32(fq32, i, w);
-    ge g = ge_elligator_map(T, fe_from_words_mod_order(w));
-    ge_compress(T, g, w);
+    ge g = ge_elligator_map(T, pt, fe_from_words_mod_order(w));
+    ge_compress(T, pt, g, w);
     store32(out32, i, w);
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_hash_to_curve(SqrtTables T, const uint8_t* r1, const uint8_t* r2,
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTables T, const uint8_t* r1, const uint8_t* r2,
                                                          size_t n, uint8_t* out32) {
+  D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t w[8];
     load32(r1, i, w);
-    ge a = ge_elligator_map(T, fe_from_words_mod_order(w));
+    ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w));
     load32(r2, i, w);
-    ge b = ge_elligator_map(T, fe_from_words_mod_order(w));
-    ge_compress(T, ge_add(a, b), w);
+    ge b = ge_elligator_map(T, pt, fe_from_words_mod_order(w));
+    ge_compress(T, pt, ge_add(a, b), w);
     store32(out32, i, w);
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_scalar_mul_var(SqrtTables T, const uint8_t* enc32,
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTables T, const uint8_t* enc32,
                                                           const uint8_t* scalar32, size_t n, uint8_t* out32,
                                                           uint8_t* status, uint32_t* scratch) {
+  D377_POW_LDS();
   GlobalTab tab;
   tab.base = scratch;
   tab.nthreads = (size_t)gridDim.x * BLOCK;
@@ -281,26 +316,26 @@ __global__ void __launch_bounds__(BLOCK) k_scalar_mul_var(SqrtTables T, const ui
     load32(enc32, i, w);
     load32(scalar32, i, k);
     ge g;
-    const uint32_t bad = ge_decompress(T, w, &g);
+    const uint32_t bad = ge_decompress(T, pt, w, &g);
     fr_reduce_words(k);
     fr_recode_signed16(k, dg);
     ge r = ge_scalar_mul_w4(g, dg, tab);
-    ge_compress(T, r, w);
+    ge_compress(T, pt, r, w);
     status[i] = (uint8_t)bad;
     if (bad) store32_zero(out32, i); else store32(out32, i, w);
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
                                                            const uint8_t* scalar32, size_t n, uint8_t* out32) {
+  D377_POW_LDS();
   FixedTab ft{fbase};
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t k[8], dg[8], w[8];
+    uint32_t k[8], w[8];
     load32(scalar32, i, k);
     fr_reduce_words(k);
-    fr_recode_signed16(k, dg);
-    ge r = ge_scalar_mul_base_w4(dg, ft);
-    ge_compress(T, r, w);
+    ge r = ge_scalar_mul_base_w8(k, ft);
+    ge_compress(T, pt, r, w);
     store32(out32, i, w);
   }
 }
@@ -360,17 +395,17 @@ int init_device(DeviceState& d) {
   HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc(&d.gtab, (size_t)6 * 256 * GT_STRIDE * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&d.s_lookup, (size_t)1 << S_HASH_BITS));
-  HIP_TRY(hipMalloc(&d.fbase, (size_t)64 * VB_ENTRIES * FB_WORDS * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&d.fbase, (size_t)FB_WINDOWS * FB_ENTRIES * FBW_ENTRY_WORDS * sizeof(uint32_t)));
   // variable-base window tables: one per resident lane, fixed grid, grid-stride over the batch
-  d.vb_blocks = d.cus * 4;
-  HIP_TRY(hipMalloc(&d.vb_scratch, (size_t)d.vb_blocks * BLOCK * VB_ENTRIES * FB_WORDS * sizeof(uint32_t)));
+  d.vb_blocks = d.cus * WAVES_PER_SIMD;        // exactly the resident blocks: 2 per CU
+  HIP_TRY(hipMalloc(&d.vb_scratch, (size_t)d.vb_blocks * BLOCK * VB_ENTRIES * VB_ENTRY_WORDS * sizeof(uint32_t)));
   uint32_t* keys = nullptr;
   int* coll = nullptr;
   HIP_TRY(hipMalloc(&keys, 512 * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&coll, sizeof(int)));
   hipLaunchKernelGGL(k_init_gtab, dim3(6), dim3(BLOCK), 0, d.stream, d.gtab);
   hipLaunchKernelGGL(k_init_slookup, dim3(1), dim3(BLOCK), 0, d.stream, d.s_lookup, keys, coll);
-  hipLaunchKernelGGL(k_init_fbase, dim3(1), dim3(64), 0, d.stream, d.fbase);
+  hipLaunchKernelGGL(k_init_fbase, dim3((FB_WINDOWS * FB_ENTRIES + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, d.stream, d.fbase);
   HIP_TRY(hipGetLastError());
   int h_coll = -1;
   HIP_TRY(hipMemcpyAsync(&h_coll, coll, sizeof(int), hipMemcpyDeviceToHost, d.stream));

@@ -10,7 +10,7 @@ using namespace d377;
 
 static std::vector<uint32_t> g_gtab(6 * 256 * GT_STRIDE);
 static std::vector<uint8_t> g_slook(1u << S_HASH_BITS);
-static std::vector<uint32_t> g_fbase(64 * 9 * 36);
+static std::vector<uint32_t> g_fbase((size_t)FB_WINDOWS * FB_ENTRIES * 27);
 static SqrtTables g_T;
 static int g_collisions = -1;
 
@@ -24,12 +24,16 @@ static fe full_norm(fe a) {   // sequential carry, value < 2^261
   for (int i = 0; i < NL; ++i) { uint32_t t = a.l[i] + c; if (i < NL - 1) { r.l[i] = t & MASK29; c = t >> 29; } else r.l[i] = t; }
   return r;
 }
-struct HostTab { ge e[9]; void store(int j, const ge& g) { e[j] = g; } ge load(int j) const { return e[j]; } };
+struct HostTab {
+  gec e[9];
+  void store(int j, const gec& g) { e[j] = g; }
+  gec load(int j, bool swap) const { gec c = e[j]; if (swap) { fe t = c.ypx; c.ypx = c.ymx; c.ymx = t; } return c; }
+};
 struct HostFTab {
   const uint32_t* p;
-  ge load(int i, int j) const {
-    ge g; const uint32_t* q = p + ((size_t)i * 9 + j) * 36;
-    for (int k = 0; k < 9; ++k) { g.x.l[k] = q[k]; g.y.l[k] = q[9 + k]; g.z.l[k] = q[18 + k]; g.t.l[k] = q[27 + k]; }
+  gea load(int i, int j, bool swap) const {
+    gea g; const uint32_t* q = p + ((size_t)i * FB_ENTRIES + j) * 27;
+    for (int k = 0; k < 9; ++k) { g.ypx.l[k] = q[(swap ? 9 : 0) + k]; g.ymx.l[k] = q[(swap ? 0 : 9) + k]; g.kt.l[k] = q[18 + k]; }
     return g;
   }
 };
@@ -63,16 +67,19 @@ int sim_init() {
   }
   g_collisions = coll;
   g_T.gtab = g_gtab.data(); g_T.s_lookup = g_slook.data();
-  // fixed-base table j * 16^i * B
+  // fixed-base comb: affine cached j * 256^i * B (the k_init_fbase construction)
   ge pi = ge_generator();
-  for (int i = 0; i < 64; ++i) {
+  for (int i = 0; i < FB_WINDOWS; ++i) {
     ge acc = ge_identity();
-    for (int j = 0; j <= 8; ++j) {
-      uint32_t* q = g_fbase.data() + ((size_t)i * 9 + j) * 36;
-      for (int k = 0; k < 9; ++k) { q[k] = acc.x.l[k]; q[9 + k] = acc.y.l[k]; q[18 + k] = acc.z.l[k]; q[27 + k] = acc.t.l[k]; }
+    for (int j = 0; j < FB_ENTRIES; ++j) {
+      const fe zi = fe_invert(acc.z);
+      const fe x = fe_mul(acc.x, zi), y = fe_mul(acc.y, zi);
+      const fe ypx = fe_carry(fe_add(y, x)), ymx = fe_sub(y, x), kt = fe_mul(fe_mul(fe_const(FE_K), x), y);
+      uint32_t* q = g_fbase.data() + ((size_t)i * FB_ENTRIES + j) * 27;
+      for (int k = 0; k < 9; ++k) { q[k] = ypx.l[k]; q[9 + k] = ymx.l[k]; q[18 + k] = kt.l[k]; }
       acc = ge_add(acc, pi);
     }
-    for (int j = 0; j < 4; ++j) pi = ge_double(pi);
+    for (int j = 0; j < 8; ++j) pi = ge_double(pi);
   }
   return coll;
 }
@@ -99,7 +106,7 @@ void sim_consts(uint32_t* sub8q, uint32_t* ql) { for (int i = 0; i < NL; ++i) { 
 
 void sim_sqrt_ratio_zeta(const uint32_t* num, const uint32_t* den, size_t n, uint32_t* root, uint8_t* ws) {
   for (size_t i = 0; i < n; ++i) {
-    fe r; bool w = fe_sqrt_ratio_zeta<false>(g_T, fe_from_words_mod_order(num + 8 * i), fe_from_words_mod_order(den + 8 * i), &r);
+    RegPowTab pt; fe r; bool w = fe_sqrt_ratio_zeta<false>(g_T, pt, fe_from_words_mod_order(num + 8 * i), fe_from_words_mod_order(den + 8 * i), &r);
     fe_to_bytes_words(r, root + 8 * i); ws[i] = w;
   }
 }
@@ -112,43 +119,45 @@ static ge ge_load256(const uint32_t* o) {
 }
 void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
-    ge g; uint32_t bad = ge_decompress(g_T, enc + 8 * i, &g);
+    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
     st[i] = (uint8_t)bad;
     if (bad) memset(xyzt + 32 * i, 0, 128); else ge_store256(g, xyzt + 32 * i);
   }
 }
 void sim_compress(const uint32_t* xyzt, size_t n, uint32_t* enc) {
-  for (size_t i = 0; i < n; ++i) ge_compress(g_T, ge_load256(xyzt + 32 * i), enc + 8 * i);
+  for (size_t i = 0; i < n; ++i) { RegPowTab pt; ge_compress(g_T, pt, ge_load256(xyzt + 32 * i), enc + 8 * i); }
 }
 void sim_roundtrip(const uint32_t* enc, size_t n, uint32_t* out, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
-    ge g; uint32_t bad = ge_decompress(g_T, enc + 8 * i, &g);
+    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
     st[i] = (uint8_t)bad;
-    if (bad) memset(out + 8 * i, 0, 32); else ge_compress(g_T, g, out + 8 * i);
+    if (bad) memset(out + 8 * i, 0, 32); else ge_compress(g_T, pt, g, out + 8 * i);
   }
 }
 void sim_encode_to_curve(const uint32_t* r0, size_t n, uint32_t* enc, uint32_t* xyzt) {
   for (size_t i = 0; i < n; ++i) {
-    ge g = ge_elligator_map(g_T, fe_from_words_mod_order(r0 + 8 * i));
-    ge_compress(g_T, g, enc + 8 * i);
+    RegPowTab pt;
+    ge g = ge_elligator_map(g_T, pt, fe_from_words_mod_order(r0 + 8 * i));
+    ge_compress(g_T, pt, g, enc + 8 * i);
     if (xyzt) ge_store256(g, xyzt + 32 * i);
   }
 }
 void sim_scalar_mul_var(const uint32_t* enc, const uint32_t* k, size_t n, uint32_t* out, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
-    ge g; uint32_t bad = ge_decompress(g_T, enc + 8 * i, &g);
+    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
     st[i] = (uint8_t)bad;
     if (bad) { memset(out + 8 * i, 0, 32); continue; }
     uint32_t kk[8], dg[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_recode_signed16(kk, dg);
     HostTab tab; ge r = ge_scalar_mul_w4(g, dg, tab);
-    ge_compress(g_T, r, out + 8 * i);
+    ge_compress(g_T, pt, r, out + 8 * i);
   }
 }
 void sim_scalar_mul_base(const uint32_t* k, size_t n, uint32_t* out) {
   HostFTab ft{g_fbase.data()};
   for (size_t i = 0; i < n; ++i) {
-    uint32_t kk[8], dg[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_recode_signed16(kk, dg);
-    ge_compress(g_T, ge_scalar_mul_base_w4(dg, ft), out + 8 * i);
+    uint32_t kk[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk);
+    RegPowTab pt;
+    ge_compress(g_T, pt, ge_scalar_mul_base_w8(kk, ft), out + 8 * i);
   }
 }
 void sim_fr_reduce(const uint32_t* k, size_t n, uint32_t* out) {
