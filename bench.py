@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "scalar_mul_base": 64,
               "sqrt_ratio_zeta": 97}
 # 32-bit MACs our kernels execute per unit (counted from the schedule)
-KERNEL_MACS = {"scalar_mul_var": 4.63e5}
+KERNEL_MACS = {"scalar_mul_var": 4.152e5}   # 2 sqrt (288 S + 78 M each) + 63 windows x (16 S + 20 M) + table build, S = 117, M = 153 MACs
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 VALU_MAC_PEAK = 3.28e13               # measured: v_mad_u64_u32 lane-ops/s, 8 waves/SIMD (profiles/r01_valu_rates_microbench.txt)
 
@@ -44,6 +44,21 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except AttributeError:
+        c = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            c = max(1, min(c, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(c, 256))
 
 
 def time_op(torch, fn, steps, warmup):
@@ -154,7 +169,7 @@ def main():
         try:
             rec = json.load(open(tpath)).get("k_scalar_mul_var")
             if rec and rec.get("elements") == n:
-                traffic = rec["hbm_bytes_per_launch"]
+                traffic = rec["hbm_bytes_per_launch"]     # PMC, separate rocprofv3 passes (profiles/r01_v2_pmc.csv)
         except Exception:
             traffic = None
     line["roofline"] = {
@@ -199,10 +214,16 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _oracle import Oracle
         orc = Oracle()
-        cores = min(os.cpu_count() or 1, 256)
-        ns = min(n, cores * 40000)
-        p_h = points[:ns].cpu().numpy()
-        k_h = scalars[:ns].cpu().numpy()
+        cores = usable_cores()
+        # pilot on one thread to size a sample worth ~12 s of wall time on all cores
+        pilot = 512
+        p_h = points[:n].cpu().numpy()
+        k_h = scalars[:n].cpu().numpy()
+        t0 = time.perf_counter()
+        orc.run_threads("scalar_mul_var", p_h[:pilot], k_h[:pilot], 1)
+        per_thread = pilot / (time.perf_counter() - t0)
+        ns = int(min(n, max(4096, per_thread * cores * 12.0)))
+        p_h, k_h = p_h[:ns], k_h[:ns]
         t0 = time.perf_counter()
         o_out, o_st, used = orc.run_threads("scalar_mul_var", p_h, k_h, cores)
         dt = time.perf_counter() - t0

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdecaf377_amd.so")
+# D377_LIB lets a developer A/B another build of the same library (tools/ab_bench.sh)
+LIB_PATH = os.environ.get("D377_LIB") or os.path.join(_HERE, "lib", "libdecaf377_amd.so")
 
 # every symbol include/decaf377_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [

@@ -72,9 +72,23 @@ D377_HD fe fe_pow_2_47_m1(const fe& x) {
 }
 
 // x^((m-1)/2), m = (q-1)/2^47: sliding window (w = 4) over the fixed exponent, the schedule
-// is the table POW_M12_CHAIN (wave-uniform, so no divergence): 201 S + 36 M + table (1 S + 7 M).
+// is the table D377_POW_CHAIN (wave-uniform, so no divergence): w=4: 201 S + 36 M + (1 S + 7 M table); w=3: see constants.inc.
 // The 8 odd powers live in `PT` (LDS on the GPU, one column per lane: conflict-free), which
 // keeps 72 VGPRs free for a second wave per SIMD.
+#ifndef D377_POW_W
+#define D377_POW_W 4                    // window of the fixed exponentiation: 3 or 4
+#endif
+#if D377_POW_W == 3
+#define D377_POW_CHAIN POW_M12_CHAIN_W3
+#define D377_POW_LEN D377_POW_M12_W3_LEN
+#define D377_POW_TRAIL D377_POW_M12_W3_TRAILING_SQ
+#else
+#define D377_POW_CHAIN POW_M12_CHAIN_W4
+#define D377_POW_LEN D377_POW_M12_W4_LEN
+#define D377_POW_TRAIL D377_POW_M12_W4_TRAILING_SQ
+#endif
+constexpr int POW_TAB = 1 << (D377_POW_W - 1);   // odd powers x^1 .. x^(2^w - 1)
+
 struct RegPowTab {                      // plain registers / stack (host simulation, init kernels)
   fe t[8];
   D377_HD void put(int j, const fe& v) { t[j] = v; }
@@ -100,18 +114,18 @@ D377_HD fe fe_pow_m12(const fe& x, PT& pt) {
   fe cur = x;
   pt.put(0, cur);
 #pragma unroll 1
-  for (int j = 1; j < 8; ++j) {
+  for (int j = 1; j < POW_TAB; ++j) {
     cur = fe_mul(cur, x2);
     pt.put(j, cur);
   }
-  fe acc = pt.get((int)(POW_M12_CHAIN[0] & 15u) >> 1);
+  fe acc = pt.get((int)(D377_POW_CHAIN[0] & 15u) >> 1);
 #pragma unroll 1
-  for (int i = 1; i < D377_POW_M12_LEN; ++i) {
-    const uint32_t e = POW_M12_CHAIN[i];
+  for (int i = 1; i < D377_POW_LEN; ++i) {
+    const uint32_t e = D377_POW_CHAIN[i];
     acc = fe_sqr_n(acc, (int)(e >> 4));
     acc = fe_mul(acc, pt.get((int)(e & 15u) >> 1));
   }
-  return fe_sqr_n(acc, D377_POW_M12_TRAILING_SQ);
+  return fe_sqr_n(acc, D377_POW_TRAIL);
 }
 
 // zero test for a value that is a fe_mul/fe_sqr output (tight, < 2q): 0 or q

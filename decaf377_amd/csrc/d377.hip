@@ -21,7 +21,10 @@ using namespace d377;
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int WAVES_PER_SIMD = 2;            // occupancy the kernels are built for (<= 256 VGPRs, 72 KiB LDS/block)
+#ifndef D377_WAVES_PER_SIMD
+#define D377_WAVES_PER_SIMD 2
+#endif
+constexpr int WAVES_PER_SIMD = D377_WAVES_PER_SIMD;   // occupancy the kernels are built for (VGPR budget 512 / this; LDS = POW_TAB * 9 KiB per block)
 constexpr int SLOT = 12;                     // one field element slot in a table entry: 9 limbs + 3 pad = 3 x 16 B
 constexpr int VB_ENTRIES = 9;                // cached 0..8 times P
 constexpr int VB_ENTRY_WORDS = 4 * SLOT;     // ypx, ymx, z2, kt: 192 B, 64-B aligned
@@ -93,7 +96,7 @@ struct LdsPowTab {
   }
 };
 #define D377_POW_LDS()                                         \
-  __shared__ uint32_t lds_pow_[8 * NL * BLOCK];                \
+  __shared__ uint32_t lds_pow_[POW_TAB * NL * BLOCK];                \
   LdsPowTab pt;                                                \
   pt.col = lds_pow_ + threadIdx.x
 
