@@ -16,7 +16,8 @@ EXPORTS = [
     "d377_ctx_create", "d377_ctx_destroy", "d377_ctx_num_devices", "d377_ctx_device_id",
     "d377_batch_sqrt_ratio_zeta", "d377_batch_decompress", "d377_batch_compress", "d377_batch_roundtrip",
     "d377_batch_scalar_mul_base", "d377_batch_scalar_mul_var", "d377_batch_encode_to_curve",
-    "d377_batch_hash_to_curve",
+    "d377_batch_hash_to_curve", "d377_batch_add", "d377_batch_double", "d377_batch_eq",
+    "d377_batch_add_dev", "d377_batch_double_dev", "d377_batch_eq_dev",
     "d377_batch_sqrt_ratio_zeta_dev", "d377_batch_decompress_dev", "d377_batch_compress_dev",
     "d377_batch_roundtrip_dev", "d377_batch_scalar_mul_base_dev", "d377_batch_scalar_mul_var_dev",
     "d377_batch_encode_to_curve_dev", "d377_batch_hash_to_curve_dev",
@@ -65,6 +66,9 @@ def load():
         "d377_batch_scalar_mul_var": [vp, vp, vp, sz, vp, vp],
         "d377_batch_encode_to_curve": [vp, vp, sz, vp],
         "d377_batch_hash_to_curve": [vp, vp, vp, sz, vp],
+        "d377_batch_add": [vp, vp, vp, sz, vp],
+        "d377_batch_double": [vp, vp, sz, vp],
+        "d377_batch_eq": [vp, vp, vp, sz, vp],
     }
     for name, args in host.items():
         getattr(lib, name).argtypes = args

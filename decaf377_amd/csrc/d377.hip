@@ -343,6 +343,22 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
   }
 }
 
+__global__ void __launch_bounds__(BLOCK) k_add(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+    store_ge_mont256(out, i, ge_add(load_ge_mont256(p, i), load_ge_mont256(q, i)));
+}
+__global__ void __launch_bounds__(BLOCK) k_double(const uint64_t* p, size_t n, uint64_t* out) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+    store_ge_mont256(out, i, ge_double(load_ge_mont256(p, i)));
+}
+// decaf equality: x1 * y2 == x2 * y1  (src/min_curve/element.rs:334-340)
+__global__ void __launch_bounds__(BLOCK) k_eq(const uint64_t* p, const uint64_t* q, size_t n, uint8_t* eq) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    const ge a = load_ge_mont256(p, i), b = load_ge_mont256(q, i);
+    eq[i] = fe_eq(fe_mul(a.x, b.y), fe_mul(b.x, a.y)) ? 1 : 0;
+  }
+}
+
 // ------------------------------------------------------------------------------ host side ---
 thread_local char g_err[512] = "";
 int fail(int code, const char* fmt, const char* detail) {
@@ -440,7 +456,7 @@ int ensure(DeviceState& d, int slot, size_t bytes) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH };
+enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ };
 
 // launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null)
 int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
@@ -477,6 +493,15 @@ int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in
       hipLaunchKernelGGL(k_hash_to_curve, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
                          (uint8_t*)out0);
       break;
+    case OP_ADD:
+      hipLaunchKernelGGL(k_add, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint64_t*)in1, n, (uint64_t*)out0);
+      break;
+    case OP_DOUBLE:
+      hipLaunchKernelGGL(k_double, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
+      break;
+    case OP_EQ:
+      hipLaunchKernelGGL(k_eq, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint64_t*)in1, n, (uint8_t*)out0);
+      break;
   }
   HIP_TRY(hipGetLastError());
   return D377_OK;
@@ -493,6 +518,9 @@ OpShape shape_of(Op op) {
     case OP_MUL_VAR: return {32, 32, 32, 1};
     case OP_ENCODE: return {32, 0, 32, 0};
     case OP_HASH: return {32, 32, 32, 0};
+    case OP_ADD: return {128, 128, 128, 0};
+    case OP_DOUBLE: return {128, 0, 128, 0};
+    case OP_EQ: return {128, 128, 1, 0};
   }
   return {0, 0, 0, 0};
 }
@@ -539,7 +567,7 @@ int run_dev(d377_ctx* ctx, int dev, void* stream, Op op, const void* in0, const 
   if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
   const OpShape sh = shape_of(op);
   if (n && (!in0 || (sh.in1 && !in1) || !out0 || (sh.out1 && !out1))) return fail(D377_ERR_ARG, "%s", "null buffer");
-  if (!aligned16(in0) || !aligned16(in1) || !aligned16(out0))
+  if (!aligned16(in0) || !aligned16(in1) || (op != OP_EQ && !aligned16(out0)))
     return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
   DeviceState& d = ctx->devs[(size_t)dev];
   HIP_TRY(hipSetDevice(d.id));
@@ -621,6 +649,27 @@ int d377_batch_encode_to_curve(d377_ctx* ctx, const uint8_t* fq32, size_t n, uin
 }
 int d377_batch_hash_to_curve(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t* r2_32, size_t n, uint8_t* enc32_out) {
   return run_host(ctx, OP_HASH, r1_32, r2_32, n, enc32_out, nullptr);
+}
+
+int d377_batch_add(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint64_t* out_xyzt) {
+  return run_host(ctx, OP_ADD, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
+}
+int d377_batch_double(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
+  return run_host(ctx, OP_DOUBLE, p_xyzt, nullptr, n, out_xyzt, nullptr);
+}
+int d377_batch_eq(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint8_t* equal) {
+  return run_host(ctx, OP_EQ, p_xyzt, q_xyzt, n, equal, nullptr);
+}
+int d377_batch_add_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n,
+                       uint64_t* out_xyzt) {
+  return run_dev(ctx, dev, stream, OP_ADD, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
+}
+int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
+  return run_dev(ctx, dev, stream, OP_DOUBLE, p_xyzt, nullptr, n, out_xyzt, nullptr);
+}
+int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n,
+                      uint8_t* equal) {
+  return run_dev(ctx, dev, stream, OP_EQ, p_xyzt, q_xyzt, n, equal, nullptr);
 }
 
 int d377_batch_sqrt_ratio_zeta_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* num32, const uint8_t* den32,

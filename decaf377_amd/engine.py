@@ -117,6 +117,16 @@ class Context:
         return self._run("d377_batch_hash_to_curve", [r1_32, r2_32], [((32,), np.uint8)], _rows(r1_32), outs)[0]
 
 
+    def add(self, p_xyzt, q_xyzt, outs=None):
+        return self._run("d377_batch_add", [p_xyzt, q_xyzt], [((16,), np.uint64)], _rows(p_xyzt), outs)[0]
+
+    def double(self, p_xyzt, outs=None):
+        return self._run("d377_batch_double", [p_xyzt], [((16,), np.uint64)], _rows(p_xyzt), outs)[0]
+
+    def eq(self, p_xyzt, q_xyzt, outs=None):
+        return self._run("d377_batch_eq", [p_xyzt, q_xyzt], [((), np.uint8)], _rows(p_xyzt), outs)[0]
+
+
 _default = None
 
 
@@ -203,6 +213,18 @@ class Element:
 
     def __len__(self):
         return int(self.data.shape[0])
+
+    def __add__(self, other):
+        """Element + Element (src/min_curve/element.rs:291-322)."""
+        return Element(self._ctx().add(self.data, other.data), self.ctx)
+
+    def double(self):
+        """Element::double (src/min_curve/element.rs:119-136)."""
+        return Element(self._ctx().double(self.data), self.ctx)
+
+    def eq(self, other):
+        """PartialEq for Element: x1*y2 == x2*y1 (src/min_curve/element.rs:334-340) -> u8[n]."""
+        return self._ctx().eq(self.data, other.data)
 
     def vartime_compress(self):
         """Element::vartime_compress (src/ark_curve/encoding.rs:116-128)."""

@@ -1,0 +1,88 @@
+"""Multi-GPU layout of the hot path: one process per GPU, independent contiguous shards.
+
+Every batch operation is a pure map over elements, so N GPUs need no
+data-path collective: rank g owns records [g*n/G, (g+1)*n/G).  The only communication the
+path ever has is moving records to and from the rank that happens to hold them --
+`scatter_records` / `gather_records`, which ride RCCL over xGMI when the tensors live in HBM
+(backend "nccl") and gloo on CPU tensors (tests).  The reference has no counterpart: it is a
+single-threaded library (src/lib.rs:1).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous slice [lo, hi) of rank `rank` out of n records over `world` ranks; sizes
+    differ by at most one and cover [0, n) exactly."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def _pad_rows(n, world):
+    return (n + world - 1) // world
+
+
+def scatter_records(full, n, row_shape, dtype, device, src=0, group=None):
+    """Rank `src` holds `full` ([n, *row_shape]); every rank returns its shard_bounds slice.
+    Other ranks pass full=None.  Uses one dist.scatter of equal (padded) chunks."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rows = _pad_rows(n, world)
+    recv = torch.empty((rows,) + tuple(row_shape), dtype=dtype, device=device)
+    chunks = None
+    if rank == src:
+        assert full is not None and full.shape[0] == n
+        chunks = []
+        for r in range(world):
+            lo, hi = shard_bounds(n, world, r)
+            c = torch.zeros((rows,) + tuple(row_shape), dtype=dtype, device=device)
+            c[: hi - lo] = full[lo:hi]
+            chunks.append(c)
+    dist.scatter(recv, chunks, src=src, group=group)
+    lo, hi = shard_bounds(n, world, rank)
+    return recv[: hi - lo]
+
+
+def gather_records(local, n, dst=0, group=None):
+    """Inverse of scatter_records: rank `dst` returns the [n, ...] tensor, others None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rows = _pad_rows(n, world)
+    lo, hi = shard_bounds(n, world, rank)
+    assert local.shape[0] == hi - lo
+    send = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    send[: hi - lo] = local
+    bufs = None
+    if rank == dst:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(n, world, r)
+        parts.append(bufs[r][: b - a])
+    return torch.cat(parts, dim=0)
+
+
+def max_over_ranks(seconds, device, group=None):
+    """The bench contract's timing rule: the slowest rank's elapsed time."""
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def map_from_root(op, inputs, n, out_specs, device, src=0, group=None):
+    """Records start on rank `src`: scatter them, run `op(*local_inputs) -> tuple of tensors`
+    on every rank's shard, gather the outputs back to `src`.
+    inputs: list of ([n, ...] tensor on src | None elsewhere, row_shape, dtype)."""
+    locs = [scatter_records(t, n, rs, dt, device, src, group) for (t, rs, dt) in inputs]
+    outs = op(*locs)
+    if not isinstance(outs, (tuple, list)):
+        outs = (outs,)
+    assert len(outs) == len(out_specs)
+    return [gather_records(o, n, src, group) for o in outs]

@@ -1,0 +1,201 @@
+// decaf377_amd.hpp -- C++ host-side mirror of the reference crate's hot-path API over the C ABI.
+//
+// Same names and error behaviour as penumbra-zone/decaf377 (v0.10.1), batch-shaped:
+//   decaf377::Encoding            Encoding(pub [u8; 32])             src/ark_curve/encoding.rs:14-15
+//   decaf377::Element             opaque X, Y, Z, T Montgomery limbs  src/min_curve/element.rs:31-38
+//   decaf377::Fq / Fr             32-byte little-endian field elements src/fields/fq.rs, fr.rs
+//   decaf377::EncodingError       InvalidEncoding / InvalidSliceLength src/error.rs:1-5
+// Header-only; link with -ldecaf377_amd.  All computation happens on the GPU.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "decaf377_amd.h"
+
+namespace decaf377 {
+
+enum class EncodingError { InvalidEncoding, InvalidSliceLength };
+
+struct DeviceError : std::runtime_error {
+  explicit DeviceError(int code) : std::runtime_error(std::string("decaf377_amd: ") + d377_last_error()), code(code) {}
+  int code;
+};
+
+// Result<T, EncodingError>
+template <class T>
+struct Result {
+  bool ok;
+  T value;
+  EncodingError err;
+  const T& unwrap() const {
+    if (!ok) throw std::runtime_error("called unwrap() on Err(InvalidEncoding)");
+    return value;
+  }
+  bool is_err() const { return !ok; }
+};
+
+struct Bytes32 {
+  std::array<uint8_t, 32> b{};
+  bool operator==(const Bytes32& o) const { return b == o.b; }
+  bool operator!=(const Bytes32& o) const { return !(*this == o); }
+};
+
+namespace detail {
+// little-endian comparison of a 32-byte string against a modulus given as 4 u64 limbs
+inline bool lt_modulus(const std::array<uint8_t, 32>& v, const uint64_t (&m)[4]) {
+  for (int i = 3; i >= 0; --i) {
+    uint64_t w = 0;
+    for (int j = 7; j >= 0; --j) w = (w << 8) | v[8 * i + j];
+    if (w != m[i]) return w < m[i];
+  }
+  return false;
+}
+}  // namespace detail
+
+struct Fq : Bytes32 {
+  // src/fields/fq.rs:29-34
+  static constexpr uint64_t MODULUS_LIMBS[4] = {725501752471715841ULL, 6461107452199829505ULL,
+                                                6968279316240510977ULL, 1345280370688173398ULL};
+  /// Fq::from_le_bytes_mod_order: the bytes are carried as-is; the engine reduces them mod q.
+  static Fq from_le_bytes_mod_order(const uint8_t* bytes32) { Fq f; std::memcpy(f.b.data(), bytes32, 32); return f; }
+  /// Fq::from_bytes_checked (src/fields/fq.rs:108-115)
+  static Result<Fq> from_bytes_checked(const std::array<uint8_t, 32>& bytes) {
+    Fq f; f.b = bytes;
+    return {detail::lt_modulus(bytes, MODULUS_LIMBS), f, EncodingError::InvalidEncoding};
+  }
+  static Fq from_u64(uint64_t x) { Fq f; for (int i = 0; i < 8; ++i) f.b[i] = (uint8_t)(x >> (8 * i)); return f; }
+  std::array<uint8_t, 32> to_bytes() const { return b; }
+};
+
+struct Fr : Bytes32 {
+  // src/fields/fr.rs:29-34
+  static constexpr uint64_t MODULUS_LIMBS[4] = {13356249993388743167ULL, 5950279507993463550ULL,
+                                                10965441865914903552ULL, 336320092672043349ULL};
+  static Fr from_le_bytes_mod_order(const uint8_t* bytes32) { Fr f; std::memcpy(f.b.data(), bytes32, 32); return f; }
+  static Result<Fr> from_bytes_checked(const std::array<uint8_t, 32>& bytes) {
+    Fr f; f.b = bytes;
+    return {detail::lt_modulus(bytes, MODULUS_LIMBS), f, EncodingError::InvalidEncoding};
+  }
+  static Fr from_u64(uint64_t x) { Fr f; for (int i = 0; i < 8; ++i) f.b[i] = (uint8_t)(x >> (8 * i)); return f; }
+};
+
+struct Encoding : Bytes32 {
+  Encoding() = default;
+  explicit Encoding(const std::array<uint8_t, 32>& a) { b = a; }
+  /// TryFrom<&[u8]> (src/ark_curve/encoding.rs:131-143): wrong length -> InvalidSliceLength
+  static Result<Encoding> try_from(const uint8_t* data, size_t len) {
+    Encoding e;
+    if (len != 32) return {false, e, EncodingError::InvalidSliceLength};
+    std::memcpy(e.b.data(), data, 32);
+    return {true, e, EncodingError::InvalidEncoding};
+  }
+};
+
+struct Element {
+  std::array<uint64_t, 16> xyzt{};   // X, Y, Z, T; 4 Montgomery limbs each (R = 2^256)
+};
+
+static_assert(sizeof(Encoding) == 32 && sizeof(Fq) == 32 && sizeof(Fr) == 32 && sizeof(Element) == 128,
+              "records must be packed");
+
+/// Owns one d377_ctx (device tables, scratch).  One call in flight per Engine.
+class Engine {
+ public:
+  explicit Engine(const std::vector<int>& device_ids = {0}) {
+    int rc = d377_ctx_create(device_ids.data(), (int)device_ids.size(), &ctx_);
+    if (rc != D377_OK) throw DeviceError(rc);
+  }
+  ~Engine() { d377_ctx_destroy(ctx_); }
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  /// Encoding::vartime_decompress, one Result per input (src/ark_curve/encoding.rs:32-83)
+  std::vector<Result<Element>> vartime_decompress(const std::vector<Encoding>& encs) {
+    std::vector<Element> out(encs.size());
+    std::vector<uint8_t> st(encs.size());
+    check(d377_batch_decompress(ctx_, u8(encs), encs.size(), reinterpret_cast<uint64_t*>(out.data()), st.data()));
+    return results(out, st);
+  }
+  /// Element::vartime_compress (src/ark_curve/encoding.rs:116-128)
+  std::vector<Encoding> vartime_compress(const std::vector<Element>& els) {
+    std::vector<Encoding> out(els.size());
+    check(d377_batch_compress(ctx_, reinterpret_cast<const uint64_t*>(els.data()), els.size(), u8m(out)));
+    return out;
+  }
+  /// Element::encode_to_curve, compressed (src/ark_curve/elligator.rs:74-76)
+  std::vector<Encoding> encode_to_curve(const std::vector<Fq>& rs) {
+    std::vector<Encoding> out(rs.size());
+    check(d377_batch_encode_to_curve(ctx_, u8(rs), rs.size(), u8m(out)));
+    return out;
+  }
+  /// Element::hash_to_curve, compressed (src/ark_curve/elligator.rs:67-71)
+  std::vector<Encoding> hash_to_curve(const std::vector<Fq>& r1, const std::vector<Fq>& r2) {
+    if (r1.size() != r2.size()) throw std::invalid_argument("length mismatch");
+    std::vector<Encoding> out(r1.size());
+    check(d377_batch_hash_to_curve(ctx_, u8(r1), u8(r2), r1.size(), u8m(out)));
+    return out;
+  }
+  /// Element::GENERATOR * k, compressed
+  std::vector<Encoding> mul_generator(const std::vector<Fr>& ks) {
+    std::vector<Encoding> out(ks.size());
+    check(d377_batch_scalar_mul_base(ctx_, u8(ks), ks.size(), u8m(out)));
+    return out;
+  }
+  /// decompress(P)? * k, compressed (src/min_curve/ops.rs:89-95)
+  std::vector<Result<Encoding>> scalar_mul(const std::vector<Encoding>& ps, const std::vector<Fr>& ks) {
+    if (ps.size() != ks.size()) throw std::invalid_argument("length mismatch");
+    std::vector<Encoding> out(ps.size());
+    std::vector<uint8_t> st(ps.size());
+    check(d377_batch_scalar_mul_var(ctx_, u8(ps), u8(ks), ps.size(), u8m(out), st.data()));
+    return results(out, st);
+  }
+  /// Fq::sqrt_ratio_zeta (src/ark_curve/invsqrt.rs:75-166)
+  std::vector<std::pair<bool, Fq>> sqrt_ratio_zeta(const std::vector<Fq>& num, const std::vector<Fq>& den) {
+    if (num.size() != den.size()) throw std::invalid_argument("length mismatch");
+    std::vector<Fq> root(num.size());
+    std::vector<uint8_t> ws(num.size());
+    check(d377_batch_sqrt_ratio_zeta(ctx_, u8(num), u8(den), num.size(), u8m(root), ws.data()));
+    std::vector<std::pair<bool, Fq>> r(num.size());
+    for (size_t i = 0; i < r.size(); ++i) r[i] = {ws[i] != 0, root[i]};
+    return r;
+  }
+  /// Element + Element / double / == (src/min_curve/element.rs:291-340)
+  std::vector<Element> add(const std::vector<Element>& p, const std::vector<Element>& q) {
+    if (p.size() != q.size()) throw std::invalid_argument("length mismatch");
+    std::vector<Element> out(p.size());
+    check(d377_batch_add(ctx_, u64(p), u64(q), p.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  std::vector<Element> double_(const std::vector<Element>& p) {
+    std::vector<Element> out(p.size());
+    check(d377_batch_double(ctx_, u64(p), p.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  std::vector<bool> eq(const std::vector<Element>& p, const std::vector<Element>& q) {
+    if (p.size() != q.size()) throw std::invalid_argument("length mismatch");
+    std::vector<uint8_t> e(p.size());
+    check(d377_batch_eq(ctx_, u64(p), u64(q), p.size(), e.data()));
+    return std::vector<bool>(e.begin(), e.end());
+  }
+  d377_ctx* raw() { return ctx_; }
+
+ private:
+  template <class T> static const uint8_t* u8(const std::vector<T>& v) { return reinterpret_cast<const uint8_t*>(v.data()); }
+  template <class T> static uint8_t* u8m(std::vector<T>& v) { return reinterpret_cast<uint8_t*>(v.data()); }
+  static const uint64_t* u64(const std::vector<Element>& v) { return reinterpret_cast<const uint64_t*>(v.data()); }
+  static void check(int rc) { if (rc != D377_OK) throw DeviceError(rc); }
+  template <class T>
+  static std::vector<Result<T>> results(const std::vector<T>& v, const std::vector<uint8_t>& st) {
+    std::vector<Result<T>> r(v.size());
+    for (size_t i = 0; i < v.size(); ++i) r[i] = {st[i] == 0, v[i], EncodingError::InvalidEncoding};
+    return r;
+  }
+  d377_ctx* ctx_ = nullptr;
+};
+
+}  // namespace decaf377

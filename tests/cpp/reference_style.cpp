@@ -1,0 +1,149 @@
+// The reference's own integration tests (tests/encoding.rs, tests/operations.rs), re-expressed
+// against the C++ host mirror (include/decaf377_amd.hpp) and run on the GPU.  Test names follow
+// the reference.  Built and run by tests/test_cpp_mirror.py (-m gpu).
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+
+#include "decaf377_amd.hpp"
+
+using namespace decaf377;
+
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+static std::array<uint8_t, 32> unhex(const std::string& h) {
+  std::array<uint8_t, 32> a{};
+  for (int i = 0; i < 32; ++i) a[i] = (uint8_t)std::stoi(h.substr(2 * i, 2), nullptr, 16);
+  return a;
+}
+
+// tests/encoding.rs:20-26
+static void identity_encoding_is_zero(Engine& e) {
+  std::vector<Encoding> zero(1);                       // [0; 32]
+  auto id = e.vartime_decompress(zero);
+  CHECK(id[0].ok);
+  auto bytes = e.vartime_compress({id[0].unwrap()});
+  CHECK(bytes[0] == zero[0]);
+  auto id2 = e.vartime_decompress(bytes);
+  CHECK(e.eq({id[0].value}, {id2[0].unwrap()})[0]);
+}
+
+// tests/encoding.rs:29-52
+static void check_generator(Engine& e) {
+  std::vector<Encoding> cand(255);
+  for (int b = 1; b <= 255; ++b) cand[b - 1].b[0] = (uint8_t)b;
+  auto r = e.vartime_decompress(cand);
+  int first = 0;
+  for (int b = 1; b <= 255 && !first; ++b) if (r[b - 1].ok) first = b;
+  CHECK(first == 8);                                   // the generator [8,0,...] is minimal
+  auto enc2 = e.vartime_compress({r[7].unwrap()});
+  CHECK(enc2[0] == cand[7]);
+  auto g = e.mul_generator({Fr::from_u64(1)});         // Element::GENERATOR
+  CHECK(g[0] == cand[7]);
+}
+
+// tests/encoding.rs:55-95
+static void test_encoding_matches_sage_encoding(Engine& e) {
+  const char* expected[16] = {
+      "0000000000000000000000000000000000000000000000000000000000000000",
+      "0800000000000000000000000000000000000000000000000000000000000000",
+      "b2ecf9b9082d6306538be73b0d6ee741141f3222152da78685d6596efc8c1506",
+      "2ebd42dd3a2307083c834e79fb9e787e352dd33e0d719f86ae4adb02fe382409",
+      "6acd327d70f9588fac373d165f4d9d5300510274dffdfdf2bf0955acd78da50d",
+      "460f913e516441c286d95dd30b0a2d2bf14264f325528b06455d7cb93ba13a0b",
+      "ec8798bcbb3bf29329549d769f89cf7993e15e2c68ec7aa2a956edf5ec62ae07",
+      "48b01e513dd37d94c3b48940dc133b92ccba7f546e99d3fc2e602d284f609f00",
+      "a4e85dddd19c80ecf5ef10b9d27b6626ac1a4f90bd10d263c717ecce4da6570a",
+      "1a8fea8cbfbc91236d8c7924e3e7e617f9dd544b710ee83827737fe8dc63ae00",
+      "0a0f86eaac0c1af30eb138467c49381edb2808904c81a4b81d2b02a2d7816006",
+      "588125a8f4e2bab8d16affc4ca60c5f64b50d38d2bb053148021631f72e99b06",
+      "f43f4cefbe7326eaab1584722b1b4860de554b23a14490a03f3fd63a089add0b",
+      "76c739a33ffd15cf6554a8e705dc573f26490b64de0c5bd4e4ac75ed5af8e60b",
+      "200136952d18d3f6c70347032ba3fef4f60c240d706be2950b4f42f1a7087705",
+      "bcb0f922df1c7aa9579394020187a2e19e2d8073452c6ab9b0c4b052aa50f505"};
+  std::vector<Encoding> encs;
+  for (auto h : expected) encs.emplace_back(unhex(h));
+  auto pts = e.vartime_decompress(encs);
+  std::vector<Element> els;
+  for (auto& p : pts) { CHECK(p.ok); els.push_back(p.value); }
+  auto back = e.vartime_compress(els);
+  std::vector<Element> acc = {els[0]};                 // Element::default()
+  const std::vector<Element> basepoint = {els[1]};
+  for (int i = 0; i < 16; ++i) {
+    CHECK(back[i] == encs[i]);                         // result_hexstr == hexstr
+    CHECK(e.eq(acc, {els[i]})[0]);                     // accumulator == point
+    acc = e.add(acc, basepoint);                       // accumulator += basepoint
+  }
+}
+
+// tests/encoding.rs:97-122 (proptests) on seeded inputs
+static void round_trips_if_successful(Engine& e) {
+  std::mt19937_64 rng(666);
+  const size_t n = 20000;
+  std::vector<Encoding> raw(n);
+  for (auto& x : raw) { for (auto& b : x.b) b = (uint8_t)rng(); x.b[31] &= 0x1f; }
+  auto dec = e.vartime_decompress(raw);
+  std::vector<Element> ok_el; std::vector<size_t> ok_idx;
+  for (size_t i = 0; i < n; ++i) if (dec[i].ok) { ok_el.push_back(dec[i].value); ok_idx.push_back(i); }
+  CHECK(ok_el.size() > 1000 && ok_el.size() < n - 1000);
+  auto again = e.vartime_compress(ok_el);
+  for (size_t j = 0; j < ok_idx.size(); ++j) CHECK(again[j] == raw[ok_idx[j]]);
+  // fq / scalar_encoding_round_trip_if_successful: from_bytes_checked accepts exactly the canonical strings
+  std::array<uint8_t, 32> ff; ff.fill(0xFF);
+  CHECK(Fq::from_bytes_checked(ff).is_err() && Fr::from_bytes_checked(ff).is_err());   // fq.rs:149-152
+  std::array<uint8_t, 32> zz{};
+  CHECK(Fq::from_bytes_checked(zz).ok && Fr::from_bytes_checked(zz).ok);
+  CHECK(Encoding::try_from(ff.data(), 31).err == EncodingError::InvalidSliceLength);
+}
+
+// tests/operations.rs:19-43 on seeded inputs: b(aP) = (ab)P needs Fr arithmetic on the host, so the
+// commuting form b(aP) == a(bP) is used, plus aP + bP == (a+b)P with small scalars.
+static void scalar_mul_properties(Engine& e) {
+  std::mt19937_64 rng(667);
+  const size_t n = 4096;
+  std::vector<Fq> r(n); std::vector<Fr> a(n), b(n);
+  for (size_t i = 0; i < n; ++i) { for (auto& x : r[i].b) x = (uint8_t)rng(); for (auto& x : a[i].b) x = (uint8_t)rng(); for (auto& x : b[i].b) x = (uint8_t)rng(); }
+  auto P = e.encode_to_curve(r);                       // element_strategy()
+  auto unwrap = [](const std::vector<Result<Encoding>>& v) { std::vector<Encoding> o; for (auto& x : v) { CHECK(x.ok); o.push_back(x.value); } return o; };
+  auto aP = unwrap(e.scalar_mul(P, a)), bP = unwrap(e.scalar_mul(P, b));
+  auto baP = unwrap(e.scalar_mul(aP, b)), abP = unwrap(e.scalar_mul(bP, a));
+  for (size_t i = 0; i < n; ++i) CHECK(baP[i] == abP[i]);
+  // (a + b) P with 40-bit scalars so the sum is exact on the host
+  std::vector<Fr> sa(n), sb(n), sab(n);
+  for (size_t i = 0; i < n; ++i) { uint64_t x = rng() >> 24, y = rng() >> 24; sa[i] = Fr::from_u64(x); sb[i] = Fr::from_u64(y); sab[i] = Fr::from_u64(x + y); }
+  auto xa = unwrap(e.scalar_mul(P, sa)), xb = unwrap(e.scalar_mul(P, sb)), xab = unwrap(e.scalar_mul(P, sab));
+  auto da = e.vartime_decompress(xa), db = e.vartime_decompress(xb);
+  std::vector<Element> ea, eb; for (size_t i = 0; i < n; ++i) { ea.push_back(da[i].unwrap()); eb.push_back(db[i].unwrap()); }
+  auto sum = e.vartime_compress(e.add(ea, eb));
+  for (size_t i = 0; i < n; ++i) CHECK(sum[i] == xab[i]);
+  // hash_to_curve = encode_to_curve(r1) + encode_to_curve(r2)   (elligator.rs:67-71)
+  std::vector<Fq> r2(r.rbegin(), r.rend());
+  auto h = e.hash_to_curve(r, r2);
+  auto d1 = e.vartime_decompress(P), d2 = e.vartime_decompress(e.encode_to_curve(r2));
+  std::vector<Element> e1, e2; for (size_t i = 0; i < n; ++i) { e1.push_back(d1[i].unwrap()); e2.push_back(d2[i].unwrap()); }
+  auto hs = e.vartime_compress(e.add(e1, e2));
+  for (size_t i = 0; i < n; ++i) CHECK(h[i] == hs[i]);
+}
+
+// src/ark_curve/invsqrt.rs:182-211
+static void sqrt_ratio_edge_cases(Engine& e) {
+  auto r = e.sqrt_ratio_zeta({Fq::from_u64(0), Fq::from_u64(1)}, {Fq::from_u64(1), Fq::from_u64(0)});
+  CHECK(r[0].first == true && r[0].second == Fq::from_u64(0));
+  CHECK(r[1].first == false && r[1].second == Fq::from_u64(0));
+}
+
+int main() {
+  Engine e({0});
+  identity_encoding_is_zero(e);
+  check_generator(e);
+  test_encoding_matches_sage_encoding(e);
+  round_trips_if_successful(e);
+  scalar_mul_properties(e);
+  sqrt_ratio_edge_cases(e);
+  bool threw = false;
+  try { Engine bad({99}); } catch (const DeviceError&) { threw = true; }
+  CHECK(threw);
+  std::printf("CPP_MIRROR_OK\n");
+  return 0;
+}

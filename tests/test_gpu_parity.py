@@ -282,3 +282,28 @@ def test_bad_arguments(ctx):
     import decaf377_amd as d
     with pytest.raises(d.NativeError):
         d.Context([99])
+
+
+def test_add_double_eq(ctx, oracle, kats):
+    """Element + Element, double, == through the GPU: the reference's running-sum check
+    (tests/encoding.rs:79-94: accumulator += basepoint; assert_eq!(accumulator, point)),
+    and bit-exact extended coordinates vs the oracle's restatement of the same formulas."""
+    hexes = kats["basepoint_multiples"]["hex"]
+    pts, st = ctx.decompress(frombytes(hexes))
+    gen = pts[1:2]
+    acc = pts[0:1]
+    for i in range(16):
+        assert ctx.eq(acc, pts[i:i + 1])[0] == 1
+        assert hx(ctx.compress(acc)) == [hexes[i]]
+        acc = ctx.add(acc, gen)
+    rng = np.random.default_rng(672)
+    n = 3000
+    P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    Qp = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    s = ctx.add(P, Qp)
+    assert (s == oracle.add_xyzt(P, Qp)).all()
+    d2 = ctx.double(P)
+    assert (d2 == oracle.double_xyzt(P)).all()
+    assert ctx.eq(d2, ctx.add(P, P)).all()
+    assert not ctx.eq(P, Qp).any()
+    assert (ctx.eq(s, ctx.add(Qp, P)) == 1).all()
