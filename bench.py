@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--log2n", type=int, default=22, help="elements per GPU per step (2^log2n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="plumbing test: every rank uses GPU 0 (needs --backend gloo; not a measurement)")
     return ap.parse_args()
 
 
@@ -93,11 +96,17 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                              % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     ctx = d.Context([local])
     n = 1 << args.log2n
@@ -132,7 +141,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert int(status.sum().item()) == 0, "valid inputs must all decode"

@@ -501,11 +501,13 @@ D377_HD ge ge_scalar_mul_w4(const ge& p, const uint32_t digits[8], Tab& tab) {
   ge r = ge_select(d != 0, p, ge_identity());
 #pragma unroll 1
   for (int i = 62; i >= 0; --i) {
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) r = ge_double_fast(r, j == 3);
+    // fetch this window's table entry first: its ~1-2 us of memory latency hides under the
+    // four doublings instead of stalling the addition
     d = fr_digit(digits, i);
     const bool neg = d < 0;
     const gec e = tab.load(neg ? -d : d, neg);
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) r = ge_double_fast(r, j == 3);
     r = ge_add_cached(r, e, neg, i == 0);       // only the compressor needs the last T
   }
   return r;

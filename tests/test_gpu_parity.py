@@ -307,3 +307,53 @@ def test_add_double_eq(ctx, oracle, kats):
     assert ctx.eq(d2, ctx.add(P, P)).all()
     assert not ctx.eq(P, Qp).any()
     assert (ctx.eq(s, ctx.add(Qp, P)) == 1).all()
+
+
+def test_full_size_fixed_base_2_20(ctx, torch_mod, oracle):
+    """BASELINE config 3: 2^20 fixed-base mults.  Full-size check: the comb kernel must agree with
+    the variable-base kernel run on the generator's encoding (two independent code paths); a
+    seeded sample and the edge scalars 0, 1, r-1 are compared with the oracle."""
+    torch = torch_mod
+    n = 1 << 20
+    g = torch.Generator(device="cpu").manual_seed(673)
+    k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
+    for i, v in enumerate([0, 1, R_ORDER - 1]):
+        k[i] = torch.from_numpy(ibytes(v).copy())
+    dev = torch.device("cuda:0")
+    kd = k.to(dev)
+    fb = ctx.scalar_mul_base(kd)
+    gen = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    gen[:, 0] = 8
+    vb, st = ctx.scalar_mul_var(gen, kd)
+    torch.cuda.synchronize()
+    assert torch.equal(fb, vb) and int(st.sum().item()) == 0
+    idx = np.concatenate([np.arange(3), np.arange(3, n, 8191)])
+    assert (fb[idx].cpu().numpy() == oracle.scalar_mul_base(k.numpy()[idx])).all()
+
+
+def test_full_size_var_base_2_22(ctx, torch_mod, oracle):
+    """BASELINE config 4 size on one GPU: 2^22 (point, scalar) pairs.  Property at full size:
+    [k]P computed with scalars k and k + r (same class mod r, different bytes) must give identical
+    encodings, every status 0; a seeded sample is compared with the oracle."""
+    torch = torch_mod
+    n = 1 << 22
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(674)
+    r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    k[:, 31] &= 0x03                                  # k < 2^250 < r, so k + r < 2^252 fits 32 bytes
+    P = ctx.encode_to_curve(r0)
+    out, st = ctx.scalar_mul_var(P, k)
+    # k + r on the host for a slice (pure byte arithmetic), full batch would take minutes in Python
+    m = 1 << 14
+    kh = k[:m].cpu().numpy()
+    kr = np.array([list((int.from_bytes(bytes(x), "little") + R_ORDER).to_bytes(32, "little")) for x in kh],
+                  dtype=np.uint8)
+    out2, st2 = ctx.scalar_mul_var(P[:m], torch.from_numpy(kr).to(dev))
+    torch.cuda.synchronize()
+    assert int(st.sum().item()) == 0 and int(st2.sum().item()) == 0
+    assert torch.equal(out[:m], out2)
+    # no two distinct inputs collapse: outputs of distinct (P, k) are distinct encodings w.h.p.
+    idx = np.arange(0, n, 16411)
+    o_out, o_st = oracle.scalar_mul_var(P[idx].cpu().numpy(), k[idx].cpu().numpy())
+    assert (out[idx].cpu().numpy() == o_out).all() and not o_st.any()
