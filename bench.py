@@ -216,6 +216,10 @@ def main():
             ker, _ = time_op(torch, fn, 3, 1)
             extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3),
                            "algo_GBps": ALGO_BYTES[name] * ne / (ker * 1e-3) / 1e9}
+        # vartime_multiscalar_mul (Pippenger MSM), 2^20 Elements -> one Encoding
+        pm, _ = ctx.decompress(enc1)
+        ker, _ = time_op(torch, lambda: ctx.msm(pm, scalars[:ne]), 3, 1)
+        extra["msm_2^20"] = {"n": ne, "ms": ker, "per_sec": ne / (ker * 1e-3)}
         extra["encodes_per_sec"] = extra["roundtrip"]["per_sec"]
         line["extra"] = extra
 

@@ -15,90 +15,14 @@
 
 #include "../../include/decaf377_amd.h"
 #include "curve.hpp"
+#include "device_util.hpp"
+#include "host_state.hpp"
 
 using namespace d377;
 
+thread_local char d377_g_err[512] = "";
+
 namespace {
-
-constexpr int BLOCK = 256;
-#ifndef D377_WAVES_PER_SIMD
-#define D377_WAVES_PER_SIMD 2
-#endif
-constexpr int WAVES_PER_SIMD = D377_WAVES_PER_SIMD;   // occupancy the kernels are built for (VGPR budget 512 / this; LDS = POW_TAB * 9 KiB per block)
-constexpr int SLOT = 12;                     // one field element slot in a table entry: 9 limbs + 3 pad = 3 x 16 B
-constexpr int VB_ENTRIES = 9;                // cached 0..8 times P
-constexpr int VB_ENTRY_WORDS = 4 * SLOT;     // ypx, ymx, z2, kt: 192 B, 64-B aligned
-constexpr int FBW_ENTRY_WORDS = 3 * SLOT;    // affine cached: ypx, ymx, kt: 144 B
-
-// ------------------------------------------------------------------ record I/O helpers ---
-__device__ __forceinline__ void load32(const uint8_t* base, size_t i, uint32_t w[8]) {
-  const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * i;
-  uint4 a = p[0], b = p[1];
-  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-}
-__device__ __forceinline__ void store32(uint8_t* base, size_t i, const uint32_t w[8]) {
-  uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
-  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
-  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-__device__ __forceinline__ void store32_zero(uint8_t* base, size_t i) {
-  uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
-  p[0] = make_uint4(0, 0, 0, 0);
-  p[1] = make_uint4(0, 0, 0, 0);
-}
-__device__ __forceinline__ void store_ge_mont256(uint64_t* xyzt, size_t i, const ge& g) {
-  uint8_t* b = reinterpret_cast<uint8_t*>(xyzt);
-  uint32_t w[8];
-  fe_to_mont256_words(g.x, w); store32(b, 4 * i + 0, w);
-  fe_to_mont256_words(g.y, w); store32(b, 4 * i + 1, w);
-  fe_to_mont256_words(g.z, w); store32(b, 4 * i + 2, w);
-  fe_to_mont256_words(g.t, w); store32(b, 4 * i + 3, w);
-}
-__device__ __forceinline__ ge load_ge_mont256(const uint64_t* xyzt, size_t i) {
-  const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
-  uint32_t w[8];
-  ge g;
-  load32(b, 4 * i + 0, w); g.x = fe_from_mont256_words(w);
-  load32(b, 4 * i + 1, w); g.y = fe_from_mont256_words(w);
-  load32(b, 4 * i + 2, w); g.z = fe_from_mont256_words(w);
-  load32(b, 4 * i + 3, w); g.t = fe_from_mont256_words(w);
-  return g;
-}
-
-__device__ __forceinline__ void slot_store(uint32_t* p, const fe& v) {
-  uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-  q[2] = make_uint4(v.l[8], 0, 0, 0);
-}
-__device__ __forceinline__ fe slot_load(const uint32_t* p) {
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a = q[0], b = q[1], c = q[2];
-  fe r;
-  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-  r.l[8] = c.x;
-  return r;
-}
-
-// the 8 odd powers of the fixed exponentiation, one LDS column per lane (bank = lane: no conflicts)
-struct LdsPowTab {
-  uint32_t* col;                           // &lds[threadIdx.x]
-  __device__ __forceinline__ void put(int j, const fe& v) {
-#pragma unroll
-    for (int k = 0; k < NL; ++k) col[(j * NL + k) * BLOCK] = v.l[k];
-  }
-  __device__ __forceinline__ fe get(int j) const {
-    fe r;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * BLOCK];
-    return r;
-  }
-};
-#define D377_POW_LDS()                                         \
-  __shared__ uint32_t lds_pow_[POW_TAB * NL * BLOCK];                \
-  LdsPowTab pt;                                                \
-  pt.col = lds_pow_ + threadIdx.x
 
 // per-lane window table of the variable-base kernel in global scratch, laid out
 // [entry][thread][4 slots x 12 words]: a wave stores one entry as 12 KiB contiguous, and a lane
@@ -360,41 +284,6 @@ __global__ void __launch_bounds__(BLOCK) k_eq(const uint64_t* p, const uint64_t*
 }
 
 // ------------------------------------------------------------------------------ host side ---
-thread_local char g_err[512] = "";
-int fail(int code, const char* fmt, const char* detail) {
-  snprintf(g_err, sizeof g_err, fmt, detail);
-  return code;
-}
-#define HIP_TRY(expr)                                                                     \
-  do {                                                                                    \
-    hipError_t e_ = (expr);                                                               \
-    if (e_ != hipSuccess) return fail(D377_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
-  } while (0)
-
-struct DeviceState {
-  int id = -1;
-  int cus = 0;
-  uint32_t* gtab = nullptr;
-  uint8_t* s_lookup = nullptr;
-  uint32_t* fbase = nullptr;
-  uint32_t* vb_scratch = nullptr;
-  int vb_blocks = 0;
-  hipStream_t stream = nullptr;          // used by the host-pointer entry points
-  // grow-only staging buffers for the host-pointer entry points
-  uint8_t* buf[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t cap[4] = {0, 0, 0, 0};
-  SqrtTables tables() const { return SqrtTables{gtab, s_lookup}; }
-};
-
-}  // namespace
-
-struct d377_ctx {
-  std::vector<DeviceState> devs;
-  std::mutex mu;
-};
-
-namespace {
-
 int grid_for(const DeviceState& d, size_t n) {
   // >> 256 workgroups when the batch allows it; capped so huge batches grid-stride
   size_t blocks = (n + BLOCK - 1) / BLOCK;
@@ -441,20 +330,9 @@ void free_device(DeviceState& d) {
   if (d.stream) (void)hipStreamSynchronize(d.stream);
   (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch);
   for (int i = 0; i < 4; ++i) (void)hipFree(d.buf[i]);
+  (void)hipFree(d.msm.mem);
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
-
-int ensure(DeviceState& d, int slot, size_t bytes) {
-  if (bytes <= d.cap[slot]) return D377_OK;
-  if (d.buf[slot]) HIP_TRY(hipFree(d.buf[slot]));
-  d.buf[slot] = nullptr; d.cap[slot] = 0;
-  size_t want = bytes + bytes / 4 + 4096;
-  HIP_TRY(hipMalloc(&d.buf[slot], want));
-  d.cap[slot] = want;
-  return D377_OK;
-}
-
-bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ };
 
@@ -579,7 +457,7 @@ int run_dev(d377_ctx* ctx, int dev, void* stream, Op op, const void* in0, const 
 extern "C" {
 
 const char* d377_version(void) { return "decaf377_amd 0.1.0 (gfx950)"; }
-const char* d377_last_error(void) { return g_err; }
+const char* d377_last_error(void) { return d377_g_err; }
 
 int d377_device_count(void) {
   int n = 0;

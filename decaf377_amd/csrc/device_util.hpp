@@ -1,0 +1,91 @@
+// device_util.hpp -- record I/O and table-slot helpers shared by the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "curve.hpp"
+
+namespace d377 {
+
+constexpr int BLOCK = 256;
+#ifndef D377_WAVES_PER_SIMD
+#define D377_WAVES_PER_SIMD 2
+#endif
+constexpr int WAVES_PER_SIMD = D377_WAVES_PER_SIMD;   // occupancy the kernels are built for (VGPR budget 512 / this; LDS = POW_TAB * 9 KiB per block)
+constexpr int SLOT = 12;                     // one field element slot in a table entry: 9 limbs + 3 pad = 3 x 16 B
+constexpr int VB_ENTRIES = 9;                // cached 0..8 times P
+constexpr int VB_ENTRY_WORDS = 4 * SLOT;     // ypx, ymx, z2, kt: 192 B, 64-B aligned
+constexpr int FBW_ENTRY_WORDS = 3 * SLOT;    // affine cached: ypx, ymx, kt: 144 B
+
+// ------------------------------------------------------------------ record I/O helpers ---
+__device__ __forceinline__ void load32(const uint8_t* base, size_t i, uint32_t w[8]) {
+  const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * i;
+  uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store32(uint8_t* base, size_t i, const uint32_t w[8]) {
+  uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ void store32_zero(uint8_t* base, size_t i) {
+  uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
+  p[0] = make_uint4(0, 0, 0, 0);
+  p[1] = make_uint4(0, 0, 0, 0);
+}
+__device__ __forceinline__ void store_ge_mont256(uint64_t* xyzt, size_t i, const ge& g) {
+  uint8_t* b = reinterpret_cast<uint8_t*>(xyzt);
+  uint32_t w[8];
+  fe_to_mont256_words(g.x, w); store32(b, 4 * i + 0, w);
+  fe_to_mont256_words(g.y, w); store32(b, 4 * i + 1, w);
+  fe_to_mont256_words(g.z, w); store32(b, 4 * i + 2, w);
+  fe_to_mont256_words(g.t, w); store32(b, 4 * i + 3, w);
+}
+__device__ __forceinline__ ge load_ge_mont256(const uint64_t* xyzt, size_t i) {
+  const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
+  uint32_t w[8];
+  ge g;
+  load32(b, 4 * i + 0, w); g.x = fe_from_mont256_words(w);
+  load32(b, 4 * i + 1, w); g.y = fe_from_mont256_words(w);
+  load32(b, 4 * i + 2, w); g.z = fe_from_mont256_words(w);
+  load32(b, 4 * i + 3, w); g.t = fe_from_mont256_words(w);
+  return g;
+}
+
+__device__ __forceinline__ void slot_store(uint32_t* p, const fe& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  q[2] = make_uint4(v.l[8], 0, 0, 0);
+}
+__device__ __forceinline__ fe slot_load(const uint32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1], c = q[2];
+  fe r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x;
+  return r;
+}
+
+// the 8 odd powers of the fixed exponentiation, one LDS column per lane (bank = lane: no conflicts)
+struct LdsPowTab {
+  uint32_t* col;                           // &lds[threadIdx.x]
+  __device__ __forceinline__ void put(int j, const fe& v) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) col[(j * NL + k) * BLOCK] = v.l[k];
+  }
+  __device__ __forceinline__ fe get(int j) const {
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * BLOCK];
+    return r;
+  }
+};
+#define D377_POW_LDS()                                         \
+  __shared__ uint32_t lds_pow_[POW_TAB * NL * BLOCK];                \
+  LdsPowTab pt;                                                \
+  pt.col = lds_pow_ + threadIdx.x
+
+
+}  // namespace d377

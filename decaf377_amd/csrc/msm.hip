@@ -1,0 +1,428 @@
+// msm.hip -- Element::vartime_multiscalar_mul as a real multi-scalar multiplication on gfx950.
+//
+// The reference (src/ark_curve/element/projective.rs:99-117) is a stub: a fold of
+// `acc + scalar * point`.  Same result, different schedule: Pippenger's bucket method with
+// signed c-bit windows, laid out for one-lane-per-bucket execution:
+//
+//   k_msm_prepare   one lane per (point, scalar): [decompress,] cached form of the point -> HBM,
+//                   scalar mod r -> W signed digits, histogram of |digit| per window (atomics)
+//   k_msm_scan      one workgroup per window: exclusive prefix sum of the histogram
+//   k_msm_scatter   one lane per point: its index (sign in bit 31) into each window's bucket run
+//   k_msm_buckets   one lane per bucket: sum of its run (cached additions, 8 M each)
+//   k_msm_chunks    one lane per 32 consecutive buckets: running-sum trick inside the chunk,
+//                   plus (lo - 1) * (chunk total) by double-and-add:  sum_b b * B_b
+//   k_msm_fold      32-to-1 folds until one point per window
+//   k_msm_final     Horner over the windows (c doublings per window), compress
+//
+// Group-element outputs are canonical as encodings, so the result bytes equal the reference's
+// whatever the summation order (the scatter order is non-deterministic; the sum is not).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/decaf377_amd.h"
+#include "curve.hpp"
+#include "device_util.hpp"
+#include "host_state.hpp"
+
+using namespace d377;
+
+namespace {
+
+constexpr int PT_WORDS = 4 * SLOT;      // one cached or extended point record: 192 B
+constexpr int CHUNK = 32;               // buckets per lane in k_msm_chunks
+constexpr int FOLD = 32;                // points per lane in k_msm_fold
+
+__device__ __forceinline__ void pt_store_cached(uint32_t* p, const gec& c) {
+  slot_store(p, c.ypx); slot_store(p + SLOT, c.ymx); slot_store(p + 2 * SLOT, c.z2); slot_store(p + 3 * SLOT, c.kt);
+}
+__device__ __forceinline__ gec pt_load_cached(const uint32_t* p, bool swap) {
+  gec c;
+  c.ypx = slot_load(p + (swap ? SLOT : 0));
+  c.ymx = slot_load(p + (swap ? 0 : SLOT));
+  c.z2 = slot_load(p + 2 * SLOT);
+  c.kt = slot_load(p + 3 * SLOT);
+  return c;
+}
+__device__ __forceinline__ void pt_store_ext(uint32_t* p, const ge& g) {
+  slot_store(p, g.x); slot_store(p + SLOT, g.y); slot_store(p + 2 * SLOT, g.z); slot_store(p + 3 * SLOT, g.t);
+}
+__device__ __forceinline__ ge pt_load_ext(const uint32_t* p) {
+  ge g;
+  g.x = slot_load(p); g.y = slot_load(p + SLOT); g.z = slot_load(p + 2 * SLOT); g.t = slot_load(p + 3 * SLOT);
+  return g;
+}
+
+// signed digit w of k (c bits per window, W windows): the top window is not wrapped
+__device__ __forceinline__ int msm_digit(const uint32_t k[8], int w, int c, int W, uint32_t& carry) {
+  const int bit = w * c;
+  const int wi = bit >> 5, sh = bit & 31;
+  uint64_t v = k[wi];
+  if (wi + 1 < 8) v |= (uint64_t)k[wi + 1] << 32;
+  uint32_t d = (uint32_t)((v >> sh) & ((1u << c) - 1u)) + carry;
+  carry = 0;
+  if (w + 1 < W && d >= (1u << (c - 1))) { carry = 1; return (int)d - (1 << c); }
+  return (int)d;
+}
+
+template <bool ENCODED>
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, int c, int W, int nb,
+              uint32_t* pts, int16_t* digits, uint32_t* count, uint8_t* status) {
+  D377_POW_LDS();
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    ge g;
+    uint32_t bad = 0;
+    if (ENCODED) {
+      uint32_t w[8];
+      load32(reinterpret_cast<const uint8_t*>(pts_in), i, w);
+      bad = ge_decompress(T, pt, w, &g);
+      status[i] = (uint8_t)bad;
+    } else {
+      g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), i);
+    }
+    pt_store_cached(pts + i * PT_WORDS, ge_to_cached(g));
+    uint32_t k[8];
+    load32(scalar32, i, k);
+    fr_reduce_words(k);
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+      int d = msm_digit(k, w, c, W, carry);
+      if (bad) d = 0;                                   // invalid points contribute nothing
+      digits[(size_t)w * n + i] = (int16_t)d;
+      if (d != 0) atomicAdd(&count[(size_t)w * (nb + 1) + (d < 0 ? -d : d)], 1u);
+    }
+  }
+}
+
+// exclusive scan of count[w][0..nb] -> offs[w][0..nb] (offs[w][nb] = total), cursor = offs
+__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* count, uint32_t* offs, uint32_t* cursor, int nb) {
+  __shared__ uint32_t part[1024];
+  const int w = blockIdx.x, t = threadIdx.x;
+  const int len = nb + 1;
+  const int per = (len + 1023) / 1024;
+  const uint32_t* cw = count + (size_t)w * len;
+  uint32_t s = 0;
+  for (int j = t * per; j < (t + 1) * per && j < len; ++j) s += (j < nb) ? cw[j] : 0u;   // slot nb is the sentinel
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = (t >= off) ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - s;
+  for (int j = t * per; j < (t + 1) * per && j < len; ++j) {
+    offs[(size_t)w * len + j] = run;
+    cursor[(size_t)w * len + j] = run;
+    run += (j < nb) ? cw[j] : 0u;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_msm_scatter(const int16_t* digits, size_t n, int W, int nb,
+                                                       uint32_t* cursor, uint32_t* idx) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+      const int d = digits[(size_t)w * n + i];
+      if (d == 0) continue;
+      const uint32_t b = (uint32_t)(d < 0 ? -d : d);
+      const uint32_t pos = atomicAdd(&cursor[(size_t)w * (nb + 1) + b], 1u);
+      idx[(size_t)w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_buckets(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, size_t n, int W, int nb, uint32_t* buckets) {
+  const size_t total = (size_t)W * nb;
+  for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < total; gi += (size_t)gridDim.x * BLOCK) {
+    const int w = (int)(gi / nb), b = (int)(gi % nb);
+    ge acc = ge_identity();
+    if (b != 0) {
+      const uint32_t lo = offs[(size_t)w * (nb + 1) + b], hi = offs[(size_t)w * (nb + 1) + b + 1];
+      // double-buffered gather: the next point's 192-byte record is in flight while this one is added
+      if (lo < hi) {
+        uint32_t e = idx[(size_t)w * n + lo];
+        gec q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * PT_WORDS, (e >> 31) != 0);
+#pragma unroll 1
+        for (uint32_t j = lo; j < hi; ++j) {
+          const bool neg = (e >> 31) != 0;
+          const gec cur = q;
+          if (j + 1 < hi) {
+            e = idx[(size_t)w * n + j + 1];
+            q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * PT_WORDS, (e >> 31) != 0);
+          }
+          acc = ge_add_cached(acc, cur, neg, true);
+        }
+      }
+    }
+    pt_store_ext(buckets + gi * PT_WORDS, acc);
+  }
+}
+
+// lane (w, t): buckets lo..hi of window w (lo = 1 + t*CHUNK): sum_b b * B_b over the chunk
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_chunks(const uint32_t* buckets, int W, int nb, int nchunks, uint32_t* chunks) {
+  const int total = W * nchunks;
+  for (int gi = blockIdx.x * BLOCK + threadIdx.x; gi < total; gi += gridDim.x * BLOCK) {
+    const int w = gi / nchunks, t = gi % nchunks;
+    const int lo = 1 + t * CHUNK;
+    int hi = lo + CHUNK - 1;
+    if (hi > nb - 1) hi = nb - 1;
+    ge run = ge_identity(), acc = ge_identity();
+#pragma unroll 1
+    for (int b = hi; b >= lo; --b) {
+      run = ge_add(run, pt_load_ext(buckets + ((size_t)w * nb + b) * PT_WORDS));
+      acc = ge_add(acc, run);                       // acc = sum (b - lo + 1) * B_b
+    }
+    // + (lo - 1) * run
+    const uint32_t s = (uint32_t)(lo - 1);
+    ge r = ge_identity();
+#pragma unroll 1
+    for (int bit = 15; bit >= 0; --bit) {
+      r = ge_double(r);
+      if ((s >> bit) & 1u) r = ge_add(r, run);
+    }
+    pt_store_ext(chunks + (size_t)gi * PT_WORDS, ge_add(acc, r));
+  }
+}
+
+// out[w][g] = sum of in[w][g*FOLD .. min((g+1)*FOLD, m))
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_fold(const uint32_t* in, int W, int m, int mout, uint32_t* out) {
+  const int total = W * mout;
+  for (int gi = blockIdx.x * BLOCK + threadIdx.x; gi < total; gi += gridDim.x * BLOCK) {
+    const int w = gi / mout, g = gi % mout;
+    int hi = (g + 1) * FOLD;
+    if (hi > m) hi = m;
+    ge acc = ge_identity();
+#pragma unroll 1
+    for (int j = g * FOLD; j < hi; ++j) acc = ge_add(acc, pt_load_ext(in + ((size_t)w * m + j) * PT_WORDS));
+    pt_store_ext(out + (size_t)gi * PT_WORDS, acc);
+  }
+}
+
+// Horner over the window sums S_w (one lane), result as Element record and as encoding
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, uint64_t* xyzt_out) {
+  D377_POW_LDS();
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  ge r = pt_load_ext(sums + (size_t)(W - 1) * PT_WORDS);
+#pragma unroll 1
+  for (int w = W - 2; w >= 0; --w) {
+#pragma unroll 1
+    for (int j = 0; j < c; ++j) r = ge_double(r);
+    r = ge_add(r, pt_load_ext(sums + (size_t)w * PT_WORDS));
+  }
+  if (xyzt_out) store_ge_mont256(xyzt_out, 0, r);
+  uint32_t w8[8];
+  ge_compress(T, pt, r, w8);
+  store32(enc_out, 0, w8);
+}
+
+// sum of m Element records (partial results of several GPUs / ranks), one lane
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_combine(SqrtTables T, const uint64_t* xyzt, size_t m, uint8_t* enc_out, uint64_t* xyzt_out) {
+  D377_POW_LDS();
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  ge r = ge_identity();
+#pragma unroll 1
+  for (size_t i = 0; i < m; ++i) r = ge_add(r, load_ge_mont256(xyzt, i));
+  if (xyzt_out) store_ge_mont256(xyzt_out, 0, r);
+  uint32_t w8[8];
+  ge_compress(T, pt, r, w8);
+  store32(enc_out, 0, w8);
+}
+
+// ------------------------------------------------------------------------------ host side ---
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Window width.  Only widths that tile the 252 scalar bits exactly are used (4, 6, 7, 9, 12, 14):
+// then the top window is as wide as the others and, because scalars are < r < 2^251, its unsigned
+// digits spread over the same 2^(c-1) buckets as the signed digits of the other windows.  A ragged
+// top window (e.g. c = 16: 11 significant bits) would pile n / 2^11 points on each of a few
+// buckets and leave single lanes summing runs 16 times longer than everyone else's.
+int pick_window(size_t n) {
+  int lg = 0;
+  while (((size_t)1 << (lg + 1)) <= n && lg < 40) ++lg;     // floor(log2 n), 0 for n <= 1
+  static const int widths[6] = {4, 6, 7, 9, 12, 14};
+  int c = 4;
+  for (int k = 0; k < 6; ++k)
+    if (widths[k] <= lg - 4) c = widths[k];
+  const char* env = getenv("D377_MSM_WINDOW");                // developer override for tests
+  if (env) { int v = atoi(env); if (v >= 2 && v <= 16) c = v; }
+  return c;
+}
+
+int grid_of(const DeviceState& d, size_t n) {
+  size_t blocks = (n + BLOCK - 1) / BLOCK;
+  size_t cap = (size_t)d.cus * 32;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+// everything on device pointers, enqueued on `s`
+int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,
+               uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
+  if (n >= ((size_t)1 << 31)) return fail(D377_ERR_ARG, "%s", "msm: n must be below 2^31");
+  const int c = pick_window(n);
+  const int W = (252 + c - 1) / c;
+  const int nb = (1 << (c - 1)) + 1;                         // bucket indices 0 .. 2^(c-1)
+  const int nchunks = (nb - 1 + CHUNK - 1) / CHUNK;
+  // workspace carve-up
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t o_pts = carve(n * PT_WORDS * 4);
+  const size_t o_dig = carve((size_t)W * n * 2);
+  const size_t o_cnt = carve((size_t)W * (nb + 1) * 4);
+  const size_t o_off = carve((size_t)W * (nb + 1) * 4);
+  const size_t o_cur = carve((size_t)W * (nb + 1) * 4);
+  const size_t o_idx = carve((size_t)W * n * 4);
+  const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
+  const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
+  const size_t o_f0 = carve((size_t)W * ((nchunks + FOLD - 1) / FOLD) * PT_WORDS * 4);
+  const size_t o_f1 = carve((size_t)W * PT_WORDS * 4 * 2);
+  if (off > d.msm.cap) {
+    if (d.msm.mem) HIP_TRY(hipFree(d.msm.mem));
+    d.msm.mem = nullptr; d.msm.cap = 0;
+    HIP_TRY(hipMalloc(&d.msm.mem, off + off / 8));
+    d.msm.cap = off + off / 8;
+  }
+  uint8_t* m = d.msm.mem;
+  uint32_t* pts = (uint32_t*)(m + o_pts);
+  int16_t* dig = (int16_t*)(m + o_dig);
+  uint32_t *cnt = (uint32_t*)(m + o_cnt), *offs = (uint32_t*)(m + o_off), *cur = (uint32_t*)(m + o_cur);
+  uint32_t* idx = (uint32_t*)(m + o_idx);
+  uint32_t *bkt = (uint32_t*)(m + o_bkt), *ch = (uint32_t*)(m + o_ch), *f0 = (uint32_t*)(m + o_f0), *f1 = (uint32_t*)(m + o_f1);
+  const SqrtTables T = d.tables();
+
+  HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)W * (nb + 1) * 4, s));
+  if (encoded)
+    hipLaunchKernelGGL(k_msm_prepare<true>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, nb, pts,
+                       dig, cnt, status);
+  else
+    hipLaunchKernelGGL(k_msm_prepare<false>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, nb, pts,
+                       dig, cnt, status);
+  hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, cnt, offs, cur, nb);
+  hipLaunchKernelGGL(k_msm_scatter, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, dig, n, W, nb, cur, idx);
+  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, pts, idx, offs, n, W, nb, bkt);
+  hipLaunchKernelGGL(k_msm_chunks, dim3(grid_of(d, (size_t)W * nchunks)), dim3(BLOCK), 0, s, bkt, W, nb, nchunks, ch);
+  // fold chunk results down to one point per window
+  const uint32_t* cur_in = ch;
+  int mcur = nchunks;
+  uint32_t* bufs[2] = {f0, f1};
+  int which = 0;
+  while (mcur > 1) {
+    const int mout = (mcur + FOLD - 1) / FOLD;
+    uint32_t* o = bufs[which];
+    hipLaunchKernelGGL(k_msm_fold, dim3(grid_of(d, (size_t)W * mout)), dim3(BLOCK), 0, s, cur_in, W, mcur, mout, o);
+    cur_in = o; mcur = mout; which ^= 1;
+  }
+  hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, T, cur_in, W, c, enc_out, xyzt_out);
+  HIP_TRY(hipGetLastError());
+  return D377_OK;
+}
+
+int msm_host(d377_ctx* ctx, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n, uint8_t* enc_out,
+             uint64_t* xyzt_out, uint8_t* status) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (!enc_out || (n && (!pts_in || !scalars)) || (encoded && n && !status)) return fail(D377_ERR_ARG, "%s", "null buffer");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const size_t nd = ctx->devs.size();
+  const size_t rec = encoded ? 32 : 128;
+  const size_t per = (n + nd - 1) / nd;
+  std::vector<uint64_t> partial(nd * 16, 0);
+  size_t used = 0;
+  int rc;
+  for (size_t k = 0; k < nd; ++k) {
+    DeviceState& d = ctx->devs[k];
+    const size_t lo = per * k;
+    if (k > 0 && lo >= n) break;
+    const size_t cnt = (lo >= n) ? 0 : ((lo + per <= n) ? per : n - lo);
+    HIP_TRY(hipSetDevice(d.id));
+    if ((rc = ensure(d, 0, cnt * rec + 16))) return rc;
+    if ((rc = ensure(d, 1, cnt * 32 + 16))) return rc;
+    if ((rc = ensure(d, 2, 32 + 128))) return rc;
+    if ((rc = ensure(d, 3, cnt + 16))) return rc;
+    if (cnt) {
+      HIP_TRY(hipMemcpyAsync(d.buf[0], (const uint8_t*)pts_in + lo * rec, cnt * rec, hipMemcpyHostToDevice, d.stream));
+      HIP_TRY(hipMemcpyAsync(d.buf[1], scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, d.stream));
+    }
+    if ((rc = msm_launch(d, d.stream, encoded, d.buf[0], d.buf[1], cnt, d.buf[2], (uint64_t*)(d.buf[2] + 32), d.buf[3])))
+      return rc;
+    HIP_TRY(hipMemcpyAsync(partial.data() + 16 * k, d.buf[2] + 32, 128, hipMemcpyDeviceToHost, d.stream));
+    if (encoded && cnt) HIP_TRY(hipMemcpyAsync(status + lo, d.buf[3], cnt, hipMemcpyDeviceToHost, d.stream));
+    if (nd == 1) HIP_TRY(hipMemcpyAsync(enc_out, d.buf[2], 32, hipMemcpyDeviceToHost, d.stream));
+    ++used;
+  }
+  for (size_t k = 0; k < used; ++k) {
+    HIP_TRY(hipSetDevice(ctx->devs[k].id));
+    HIP_TRY(hipStreamSynchronize(ctx->devs[k].stream));
+  }
+  if (nd > 1) {   // one small cross-device reduction: add the per-GPU partial sums on device 0
+    DeviceState& d = ctx->devs[0];
+    HIP_TRY(hipSetDevice(d.id));
+    if ((rc = ensure(d, 0, used * 128))) return rc;
+    HIP_TRY(hipMemcpyAsync(d.buf[0], partial.data(), used * 128, hipMemcpyHostToDevice, d.stream));
+    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, d.stream, d.tables(), (const uint64_t*)d.buf[0], used, d.buf[2],
+                       (uint64_t*)(d.buf[2] + 32));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(enc_out, d.buf[2], 32, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipMemcpyAsync(partial.data(), d.buf[2] + 32, 128, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+  }
+  if (xyzt_out) memcpy(xyzt_out, partial.data(), 128);
+  return D377_OK;
+}
+
+int msm_dev(d377_ctx* ctx, int dev, void* stream, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,
+            uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  if (!enc_out || (n && (!pts_in || !scalars)) || (encoded && n && !status)) return fail(D377_ERR_ARG, "%s", "null buffer");
+  if (!aligned16(pts_in) || !aligned16(scalars) || !aligned16(enc_out) || !aligned16(xyzt_out))
+    return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
+  DeviceState& d = ctx->devs[(size_t)dev];
+  HIP_TRY(hipSetDevice(d.id));
+  return msm_launch(d, (hipStream_t)stream, encoded, pts_in, scalars, n, enc_out, xyzt_out, status);
+}
+
+}  // namespace
+
+extern "C" {
+
+int d377_msm(d377_ctx* ctx, const uint64_t* xyzt, const uint8_t* scalar32, size_t n, uint8_t* enc32_out,
+             uint64_t* xyzt_out) {
+  return msm_host(ctx, false, xyzt, scalar32, n, enc32_out, xyzt_out, nullptr);
+}
+int d377_msm_encoded(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t n, uint8_t* enc32_out,
+                     uint64_t* xyzt_out, uint8_t* status) {
+  return msm_host(ctx, true, enc32, scalar32, n, enc32_out, xyzt_out, status);
+}
+int d377_msm_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, const uint8_t* scalar32, size_t n,
+                 uint8_t* enc32_out, uint64_t* xyzt_out) {
+  return msm_dev(ctx, dev, stream, false, xyzt, scalar32, n, enc32_out, xyzt_out, nullptr);
+}
+int d377_msm_encoded_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, const uint8_t* scalar32, size_t n,
+                         uint8_t* enc32_out, uint64_t* xyzt_out, uint8_t* status) {
+  return msm_dev(ctx, dev, stream, true, enc32, scalar32, n, enc32_out, xyzt_out, status);
+}
+int d377_sum_elements_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t m, uint8_t* enc32_out,
+                          uint64_t* xyzt_out) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  if (!enc32_out || (m && !xyzt)) return fail(D377_ERR_ARG, "%s", "null buffer");
+  DeviceState& d = ctx->devs[(size_t)dev];
+  HIP_TRY(hipSetDevice(d.id));
+  hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, (hipStream_t)stream, d.tables(), xyzt, m, enc32_out, xyzt_out);
+  HIP_TRY(hipGetLastError());
+  return D377_OK;
+}
+
+}  // extern "C"

@@ -127,6 +127,57 @@ class Context:
         return self._run("d377_batch_eq", [p_xyzt, q_xyzt], [((), np.uint8)], _rows(p_xyzt), outs)[0]
 
 
+    # -- multi-scalar multiplication -------------------------------------------------------------
+    def msm(self, points, scalar32, encoded=None):
+        """Element::vartime_multiscalar_mul (src/ark_curve/element/projective.rs:99-117).
+        points: [n, 16] u64 Elements or [n, 32] u8 Encodings (detected by the row width).
+        Returns (enc[32] u8, xyzt[16] u64, status[n] or None)."""
+        n = _rows(points)
+        if encoded is None:
+            encoded = int(points.shape[1]) == 32
+        if _is_torch(points):
+            import torch
+            dev = points.device
+            pts, sc = points.contiguous(), scalar32.contiguous()
+            enc = torch.empty((32,), dtype=torch.uint8, device=dev)
+            xyzt = torch.empty((16,), dtype=torch.int64, device=dev)
+            st = torch.empty((max(n, 1),), dtype=torch.uint8, device=dev) if encoded else None
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            di = self.device_ids.index(dev.index)
+            p = lambda t: ctypes.c_void_p(t.data_ptr())
+            if encoded:
+                _native.check(self._lib.d377_msm_encoded_dev(self._h, di, stream, p(pts), p(sc), ctypes.c_size_t(n),
+                                                             p(enc), p(xyzt), p(st)))
+                return enc, xyzt, st[:n]
+            _native.check(self._lib.d377_msm_dev(self._h, di, stream, p(pts), p(sc), ctypes.c_size_t(n), p(enc), p(xyzt)))
+            return enc, xyzt, None
+        pts = np.ascontiguousarray(points)
+        sc = np.ascontiguousarray(scalar32)
+        enc = np.zeros(32, np.uint8)
+        xyzt = np.zeros(16, np.uint64)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        if encoded:
+            st = np.zeros(max(n, 1), np.uint8)
+            _native.check(self._lib.d377_msm_encoded(self._h, p(pts), p(sc), ctypes.c_size_t(n), p(enc), p(xyzt), p(st)))
+            return enc, xyzt, st[:n]
+        _native.check(self._lib.d377_msm(self._h, p(pts), p(sc), ctypes.c_size_t(n), p(enc), p(xyzt)))
+        return enc, xyzt, None
+
+    def sum_elements(self, xyzt):
+        """Sum of m Element records held in HBM -> (enc[32], xyzt[16]); used to combine the
+        per-rank partial sums of a sharded MSM."""
+        import torch
+        m = _rows(xyzt)
+        dev = xyzt.device
+        enc = torch.empty((32,), dtype=torch.uint8, device=dev)
+        out = torch.empty((16,), dtype=torch.int64, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(self._lib.d377_sum_elements_dev(self._h, self.device_ids.index(dev.index), stream,
+                                                      ctypes.c_void_p(xyzt.contiguous().data_ptr()), ctypes.c_size_t(m),
+                                                      ctypes.c_void_p(enc.data_ptr()), ctypes.c_void_p(out.data_ptr())))
+        return enc, out
+
+
 _default = None
 
 
@@ -239,6 +290,13 @@ class Element:
     def hash_to_curve(r1, r2):
         """Element::hash_to_curve (src/ark_curve/elligator.rs:67-71), returned compressed."""
         return Encoding(r1._ctx().hash_to_curve(r1.data, r2.data), r1.ctx)
+
+    @staticmethod
+    def vartime_multiscalar_mul(scalars, points):
+        """Element::vartime_multiscalar_mul(scalars, points) -> Encoding of the sum
+        (src/ark_curve/element/projective.rs:99-117); `points` is an Element or Encoding batch."""
+        enc, _, _ = points._ctx().msm(points.data, scalars.data)
+        return Encoding(enc.reshape(1, 32) if not _is_torch(enc) else enc.reshape(1, 32), points.ctx)
 
     @staticmethod
     def generator_mul(scalars):

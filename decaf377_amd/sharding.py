@@ -86,3 +86,26 @@ def map_from_root(op, inputs, n, out_specs, device, src=0, group=None):
         outs = (outs,)
     assert len(outs) == len(out_specs)
     return [gather_records(o, n, src, group) for o in outs]
+
+
+def allgather_partials(partial, group=None):
+    """The one exchange step of a sharded multi-scalar multiplication: every rank contributes its
+    partial sum (one 128-byte Element record, int64[16]) and receives all of them, [world, 16]."""
+    world = dist.get_world_size(group)
+    bufs = [torch.empty_like(partial) for _ in range(world)]
+    dist.all_gather(bufs, partial.contiguous(), group=group)
+    return torch.stack(bufs, dim=0)
+
+
+def msm_sharded(ctx, points, scalars, group=None):
+    """vartime_multiscalar_mul over points sharded across ranks: local Pippenger MSM on this
+    rank's shard, all-gather of the per-rank partial sums (RCCL over xGMI for HBM tensors),
+    then every rank adds the `world` partial points and compresses.  Returns enc[32] (same on
+    every rank)."""
+    _, partial, _ = ctx.msm(points, scalars)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        enc, _ = ctx.sum_elements(partial.reshape(1, 16))
+        return enc
+    allp = allgather_partials(partial, group)
+    enc, _ = ctx.sum_elements(allp)
+    return enc

@@ -89,6 +89,19 @@ int d377_batch_add(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt
 int d377_batch_double(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);
 int d377_batch_eq(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint8_t* equal);
 
+/* Element::vartime_multiscalar_mul(scalars, points) = sum_i scalar_i * point_i
+ *                                                 src/ark_curve/element/projective.rs:99-117
+ * (a fold of scalar multiplications in the reference; a Pippenger bucket MSM here).  The sum is
+ * returned as its canonical Encoding (enc32_out, 32 bytes) and, if xyzt_out != NULL, as one
+ * Element record (some extended representative of the same group element).
+ * d377_msm takes in-memory Elements; d377_msm_encoded takes Encodings, reports invalid ones in
+ * status[] and leaves them out of the sum.  n < 2^31.  With a multi-GPU context each device sums a
+ * contiguous slice and the partial sums are added on the first device. */
+int d377_msm(d377_ctx* ctx, const uint64_t* xyzt, const uint8_t* scalar32, size_t n, uint8_t* enc32_out,
+             uint64_t* xyzt_out);
+int d377_msm_encoded(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t n, uint8_t* enc32_out,
+                     uint64_t* xyzt_out, uint8_t* status);
+
 /* Device-pointer forms (same semantics). */
 int d377_batch_sqrt_ratio_zeta_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* num32,
                                    const uint8_t* den32, size_t n, uint8_t* root32, uint8_t* was_square);
@@ -113,6 +126,15 @@ int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* 
                           uint64_t* out_xyzt);
 int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt,
                       size_t n, uint8_t* equal);
+
+/* MSM on device buffers (the workspace grows inside the context on first use of a larger n). */
+int d377_msm_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, const uint8_t* scalar32, size_t n,
+                 uint8_t* enc32_out, uint64_t* xyzt_out);
+int d377_msm_encoded_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, const uint8_t* scalar32,
+                         size_t n, uint8_t* enc32_out, uint64_t* xyzt_out, uint8_t* status);
+/* Sum of m Element records (e.g. the per-rank partial sums of a sharded MSM after an all-gather). */
+int d377_sum_elements_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t m,
+                          uint8_t* enc32_out, uint64_t* xyzt_out);
 
 #ifdef __cplusplus
 }

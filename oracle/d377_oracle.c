@@ -510,6 +510,18 @@ API void d377o_eq_xyzt(const uint64_t *p, const uint64_t *q, size_t n, uint8_t *
 }
 API void d377o_generator_xyzt(uint64_t *xyzt) { el_store(el_generator(), xyzt); }
 
+/* Element::vartime_multiscalar_mul, src/ark_curve/element/projective.rs:99-117:
+ * fold(Element::default(), |acc, (scalar, point)| acc + scalar * point), result compressed. */
+API void d377o_msm(const uint64_t *xyzt, const uint8_t *scalar32, size_t n, uint8_t *enc32_out, uint64_t *xyzt_out) {
+    element acc = el_identity();
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t k[4]; fr_from_le_bytes_mod_order(scalar32 + 32 * i, k);
+        acc = el_add(acc, el_scalar_mul(el_load(xyzt + 16 * i), k));
+    }
+    el_compress(acc, enc32_out);
+    if (xyzt_out) el_store(acc, xyzt_out);
+}
+
 /* ---- threaded driver for the timed CPU baseline (contiguous slices) ---- */
 typedef struct { int op; const uint8_t *a, *b; uint8_t *out, *status; size_t n; } job;
 static void *job_run(void *p) {

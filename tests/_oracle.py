@@ -133,6 +133,34 @@ class Oracle:
         self.lib.d377o_eq_xyzt(_p(p), _p(q), self._n(p.shape[0]), _p(eq))
         return eq
 
+    def msm(self, xyzt, k, threads=8):
+        """Reference fold; slices are folded on `threads` python-side chunks and summed (the sum is
+        commutative and the encoding canonical, so chunking does not change the result)."""
+        xyzt = np.ascontiguousarray(xyzt, dtype=np.uint64).reshape(-1, 16)
+        k = as_u8(k)
+        n = xyzt.shape[0]
+        enc = np.zeros(32, np.uint8)
+        out = np.zeros(16, np.uint64)
+        if n <= 256 or threads <= 1:
+            self.lib.d377o_msm(_p(xyzt), _p(k), self._n(n), _p(enc), _p(out))
+            return enc, out
+        from concurrent.futures import ThreadPoolExecutor
+        bounds = np.linspace(0, n, threads + 1).astype(int)
+
+        def part(j):
+            lo, hi = int(bounds[j]), int(bounds[j + 1])
+            e = np.zeros(32, np.uint8)
+            o = np.zeros(16, np.uint64)
+            x, kk = np.ascontiguousarray(xyzt[lo:hi]), np.ascontiguousarray(k[lo:hi])
+            self.lib.d377o_msm(_p(x), _p(kk), self._n(hi - lo), _p(e), _p(o))
+            return o
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(part, range(threads)))      # ctypes releases the GIL
+        acc = parts[0].reshape(1, 16)
+        for q in parts[1:]:
+            acc = self.add_xyzt(acc, q.reshape(1, 16))
+        return self.compress(acc)[0], acc[0]
+
     def generator_xyzt(self):
         out = np.zeros(16, np.uint64)
         self.lib.d377o_generator_xyzt(_p(out))

@@ -50,6 +50,19 @@ def main():
         cnt = torch.tensor([hi - lo], dtype=torch.int64)
         dist.all_reduce(cnt)
         assert int(cnt.item()) == n
+    # sharded MSM exchange step: all-gather of per-rank partial sums, then a local sum
+    n = 300
+    rng = np.random.default_rng(77)            # same stream on every rank
+    P = orc.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    lo, hi = sharding.shard_bounds(n, world, rank)
+    _, part = orc.msm(P[lo:hi], k[lo:hi], threads=1)
+    allp = sharding.allgather_partials(torch.from_numpy(part.view(np.int64).copy()))
+    assert allp.shape == (world, 16)
+    acc = allp[0:1].numpy().view(np.uint64)
+    for r in range(1, world):
+        acc = orc.add_xyzt(acc, allp[r:r + 1].numpy().view(np.uint64))
+    assert bytes(orc.compress(acc)[0]) == bytes(orc.msm(P, k, threads=1)[0])
     t = sharding.max_over_ranks(0.5 + rank, dev)
     assert abs(t - (0.5 + world - 1)) < 1e-9
     dist.barrier()

@@ -1,0 +1,116 @@
+"""vartime_multiscalar_mul: oracle-level checks on CPU, Pippenger kernels on GPU."""
+import os
+
+import numpy as np
+import pytest
+
+R_ORDER = (13356249993388743167 | 5950279507993463550 << 64 | 10965441865914903552 << 128
+           | 336320092672043349 << 192)
+
+
+def test_oracle_msm_matches_property(oracle):
+    """tests/operations.rs:44-60: (a*P) + (b*Q) + (c*R) == vartime_multiscalar_mul([a,b,c],[P,Q,R])."""
+    rng = np.random.default_rng(700)
+    for n in (0, 1, 3, 17):
+        P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)) if n else np.zeros((0, 16), np.uint64)
+        k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        enc, _ = oracle.msm(P, k, threads=1)
+        acc = oracle.decompress(np.zeros((1, 32), np.uint8))[0]
+        for i in range(n):
+            acc = oracle.add_xyzt(acc, oracle.scalar_mul_xyzt(P[i:i + 1], k[i:i + 1]))
+        assert bytes(enc) == bytes(oracle.compress(acc)[0])
+    P = oracle.elligator_map_xyzt(rng.integers(0, 256, (600, 32), dtype=np.uint8))
+    k = rng.integers(0, 256, (600, 32), dtype=np.uint8)
+    assert bytes(oracle.msm(P, k, threads=1)[0]) == bytes(oracle.msm(P, k, threads=4)[0])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import decaf377_amd as d
+    c = d.Context([0])
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 2, 7, 64, 257, 1000, 5000])
+def test_msm_matches_oracle(ctx, oracle, n):
+    rng = np.random.default_rng(701 + n)
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    if n >= 7:
+        for i, v in enumerate([0, 1, R_ORDER - 1, R_ORDER, (1 << 256) - 1]):
+            k[i] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    P = oracle.elligator_map_xyzt(r0) if n else np.zeros((0, 16), np.uint64)
+    enc, xyzt, _ = ctx.msm(P, k)
+    o_enc, _ = oracle.msm(P, k)
+    assert bytes(enc) == bytes(o_enc)
+    assert bytes(ctx.compress(xyzt.reshape(1, 16))[0]) == bytes(o_enc)
+    # the Encoding-input form, with two invalid encodings mixed in
+    if n >= 7:
+        encs = oracle.compress(P)
+        encs[3] = 0xFF
+        encs[5, 31] = 0x80
+        e2, _, st = ctx.msm(encs, k)
+        keep = np.ones(n, bool)
+        keep[[3, 5]] = False
+        assert list(np.nonzero(st)[0]) == [3, 5]
+        assert bytes(e2) == bytes(oracle.msm(P[keep], k[keep])[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [4, 5, 7, 12, 14, 16])
+def test_msm_every_window_width(oracle, window):
+    """Same inputs through different bucket widths (developer override) give the same bytes."""
+    import decaf377_amd as d
+    os.environ["D377_MSM_WINDOW"] = str(window)
+    try:
+        c = d.Context([0])
+        rng = np.random.default_rng(702)
+        n = 3000
+        P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+        k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        k[0] = np.frombuffer((R_ORDER - 1).to_bytes(32, "little"), np.uint8)
+        k[1] = np.frombuffer(int("7" * 62, 16).to_bytes(32, "little"), np.uint8)
+        k[2] = np.frombuffer(int("8" * 62, 16).to_bytes(32, "little"), np.uint8)
+        enc, _, _ = c.msm(P, k)
+        assert bytes(enc) == bytes(oracle.msm(P, k)[0])
+        c.close()
+    finally:
+        del os.environ["D377_MSM_WINDOW"]
+
+
+@pytest.mark.gpu
+def test_msm_full_size_properties(ctx, oracle):
+    """2^20 points on the device path: (1) all points equal P -> [sum k_i] P; (2) linearity:
+    MSM(A u B) == MSM(A) + MSM(B); (3) a 2^14 prefix against the oracle fold."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 20
+    g = torch.Generator(device=dev).manual_seed(703)
+    r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    encs = ctx.encode_to_curve(r0)
+    P, st = ctx.decompress(encs)
+    full, fx, _ = ctx.msm(P, k)
+    h = n // 3
+    a, ax, _ = ctx.msm(P[:h], k[:h])
+    b, bx, _ = ctx.msm(P[h:], k[h:])
+    s = ctx.compress(ctx.add(ax.reshape(1, 16), bx.reshape(1, 16)))
+    torch.cuda.synchronize()
+    assert torch.equal(s[0], full)
+    # Encoding input gives the same sum
+    full2, _, st2 = ctx.msm(encs, k)
+    assert torch.equal(full2, full) and int(st2.sum().item()) == 0
+    # all points equal
+    m = 1 << 16
+    same = P[7:8].expand(m, 16).contiguous()
+    e1, _, _ = ctx.msm(same, k[:m])
+    ksum = sum(int.from_bytes(bytes(x), "little") % R_ORDER for x in k[:m].cpu().numpy()) % R_ORDER
+    kb = torch.from_numpy(np.frombuffer(ksum.to_bytes(32, "little"), np.uint8).copy()).reshape(1, 32).to(dev)
+    e2, _ = ctx.scalar_mul_var(encs[7:8], kb)
+    assert torch.equal(e1, e2[0])
+    # prefix against the oracle
+    q = 1 << 14
+    e3, _, _ = ctx.msm(P[:q], k[:q])
+    assert bytes(e3.cpu().numpy()) == bytes(oracle.msm(P[:q].cpu().numpy().view(np.uint64), k[:q].cpu().numpy(), threads=16)[0])
