@@ -102,6 +102,19 @@ void sim_fq_from_bytes(const uint32_t* w, size_t n, uint32_t* mont256) {
 void sim_fq_to_bytes(const uint32_t* mont256, size_t n, uint32_t* w) {
   for (size_t i = 0; i < n; ++i) fe_to_bytes_words(fe_from_mont256_words(mont256 + 8 * i), w + 8 * i);
 }
+// raw limb-level entry points (9 x u32 per element) for the bound stress tests
+void sim_raw_mul(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) { fe x, y; memcpy(x.l, a + 9 * i, 36); memcpy(y.l, b + 9 * i, 36); fe r = fe_mul(x, y); memcpy(out + 9 * i, r.l, 36); }
+}
+void sim_raw_sqr(const uint32_t* a, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) { fe x; memcpy(x.l, a + 9 * i, 36); fe r = fe_sqr(x); memcpy(out + 9 * i, r.l, 36); }
+}
+void sim_raw_sub(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) { fe x, y; memcpy(x.l, a + 9 * i, 36); memcpy(y.l, b + 9 * i, 36); fe r = fe_sub(x, y); memcpy(out + 9 * i, r.l, 36); }
+}
+void sim_raw_canon(const uint32_t* a, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) { fe x; memcpy(x.l, a + 9 * i, 36); fe r = fe_canon(x); memcpy(out + 9 * i, r.l, 36); }
+}
 void sim_consts(uint32_t* sub8q, uint32_t* ql) { for (int i = 0; i < NL; ++i) { sub8q[i] = SUB8Q[i]; ql[i] = QL[i]; } }
 
 void sim_sqrt_ratio_zeta(const uint32_t* num, const uint32_t* den, size_t n, uint32_t* root, uint8_t* ws) {

@@ -166,3 +166,64 @@ def test_scalar_mul_matches_oracle(sim, oracle, vectors):
     red = np.zeros((n, 32), np.uint8)
     sim.sim_fr_reduce(_p(k), n_(n), _p(red))
     assert (red == oracle.fr_from_bytes_mod_order(k)).all()
+
+
+def _val(limbs):
+    return sum(int(v) << (29 * i) for i, v in enumerate(limbs))
+
+
+def test_limb_bounds_adversarial(sim):
+    """fq29.hpp's representation contract at its edges: every limb at the documented maximum
+    ("lazy" = 2^30 + 16, triple-lazy = 1.5 * 2^30 against a tight operand), so that each 64-bit
+    column accumulator is pushed as close to 2^64 as the contract allows.  Checked against exact
+    big-integer arithmetic: result = a*b / 2^261 mod q, limbs tight, value < a*b/2^261 + q."""
+    R = 1 << 261
+    Rinv = pow(R, -1, Q)
+    lazy = (1 << 30) + 16
+    tight = (1 << 29) + 8
+    triple = 3 * (1 << 29) + 24
+    top = (1 << 24)                         # limb 8 of a value around 13 q
+    rng = np.random.default_rng(15)
+    cases = []
+    for la, lb in [(lazy, lazy), (triple, tight), (tight, triple), (lazy, tight), (tight, tight)]:
+        cases.append(([la] * 8 + [top], [lb] * 8 + [top]))
+        cases.append(([la] * 8 + [0], [lb] * 8 + [0]))
+        for _ in range(200):                # random mixtures of extreme and random limbs
+            a = [la if rng.random() < 0.7 else int(rng.integers(0, la + 1)) for _ in range(8)] + [int(rng.integers(0, top))]
+            b = [lb if rng.random() < 0.7 else int(rng.integers(0, lb + 1)) for _ in range(8)] + [int(rng.integers(0, top))]
+            cases.append((a, b))
+    a = np.array([c[0] for c in cases], dtype=np.uint32)
+    b = np.array([c[1] for c in cases], dtype=np.uint32)
+    n = a.shape[0]
+    out = np.zeros((n, 9), np.uint32)
+    sim.sim_raw_mul(_p(a), _p(b), n_(n), _p(out))
+    for i in range(n):
+        va, vb, vr = _val(a[i]), _val(b[i]), _val(out[i])
+        assert vr % Q == va * vb * Rinv % Q, i
+        assert vr < va * vb // R + Q + 1
+        assert all(int(x) < (1 << 29) for x in out[i][:8])
+    sim.sim_raw_sqr(_p(a), n_(n), _p(out))
+    for i in range(n):
+        va, vr = _val(a[i]), _val(out[i])
+        if max(int(x) for x in a[i][:8]) > lazy:
+            continue                        # squaring takes lazy operands, not triple-lazy ones
+        assert vr % Q == va * va * Rinv % Q, i
+        assert all(int(x) < (1 << 29) for x in out[i][:8])
+    # subtraction: minuend lazy, subtrahend lazy with value < 8q -> exact value a - b + 8q, tight limbs
+    sub_a = np.array([[lazy] * 8 + [top]] * 4 + [[0] * 9] * 4, dtype=np.uint32)
+    sub_b = np.array([[lazy] * 8 + [0], [0] * 9, [tight] * 8 + [1 << 21], [lazy] * 8 + [(1 << 23)]] * 2, dtype=np.uint32)
+    out = np.zeros((8, 9), np.uint32)
+    sim.sim_raw_sub(_p(sub_a), _p(sub_b), n_(8), _p(out))
+    for i in range(8):
+        assert _val(sub_b[i]) < 8 * Q
+        assert _val(out[i]) == _val(sub_a[i]) - _val(sub_b[i]) + 8 * Q
+        assert all(int(x) < (1 << 29) + 8 for x in out[i][:8])
+    # canonicalisation of the representatives of zero and of small multiples of q
+    reps = []
+    for k in range(0, 9):
+        v = k * Q
+        reps.append([(v >> (29 * i)) & ((1 << 29) - 1) for i in range(8)] + [v >> 232])
+    reps = np.array(reps, dtype=np.uint32)
+    out = np.zeros((9, 9), np.uint32)
+    sim.sim_raw_canon(_p(reps), n_(9), _p(out))
+    assert not out.any()
