@@ -18,6 +18,8 @@ EXPORTS = [
     "d377_batch_scalar_mul_base", "d377_batch_scalar_mul_var", "d377_batch_encode_to_curve",
     "d377_batch_hash_to_curve", "d377_batch_add", "d377_batch_double", "d377_batch_eq",
     "d377_batch_add_dev", "d377_batch_double_dev", "d377_batch_eq_dev",
+    "d377_batch_fq_from_wide_bytes", "d377_batch_encode_to_curve_wide", "d377_batch_to_affine",
+    "d377_batch_fq_from_wide_bytes_dev", "d377_batch_encode_to_curve_wide_dev", "d377_batch_to_affine_dev",
     "d377_msm", "d377_msm_encoded", "d377_msm_dev", "d377_msm_encoded_dev", "d377_sum_elements_dev",
     "d377_batch_sqrt_ratio_zeta_dev", "d377_batch_decompress_dev", "d377_batch_compress_dev",
     "d377_batch_roundtrip_dev", "d377_batch_scalar_mul_base_dev", "d377_batch_scalar_mul_var_dev",
@@ -77,6 +79,15 @@ def load():
         dev = getattr(lib, name + "_dev")
         dev.argtypes = [vp, i32, vp] + args[1:]
         dev.restype = i32
+    lib.d377_batch_fq_from_wide_bytes.argtypes = [vp, vp, sz, sz, vp]
+    lib.d377_batch_encode_to_curve_wide.argtypes = [vp, vp, sz, sz, vp]
+    lib.d377_batch_to_affine.argtypes = [vp, vp, sz, vp]
+    lib.d377_batch_fq_from_wide_bytes_dev.argtypes = [vp, i32, vp, vp, sz, sz, vp]
+    lib.d377_batch_encode_to_curve_wide_dev.argtypes = [vp, i32, vp, vp, sz, sz, vp]
+    lib.d377_batch_to_affine_dev.argtypes = [vp, i32, vp, vp, sz, vp]
+    for name in ("d377_batch_fq_from_wide_bytes", "d377_batch_encode_to_curve_wide", "d377_batch_to_affine"):
+        getattr(lib, name).restype = i32
+        getattr(lib, name + "_dev").restype = i32
     lib.d377_msm.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.d377_msm_encoded.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     lib.d377_msm_dev.argtypes = [vp, i32, vp, vp, vp, sz, vp, vp]

@@ -206,6 +206,11 @@ D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, cons
 D377_HD fe fe_from_words_mod_order(const uint32_t w[8]) {
   return fe_mul(fe_from_words(w), fe_const(FE_R2));
 }
+// Fq::from_le_bytes_mod_order for 33..64 input bytes (src/fields/fq.rs:90-102): two 32-byte
+// chunks, value = lo + 2^256 * hi (hi zero-padded).  The result is a lazy sum of two products.
+D377_HD fe fe_from_wide_words(const uint32_t lo[8], const uint32_t hi[8]) {
+  return fe_add(fe_mul(fe_from_words(lo), fe_const(FE_R2)), fe_mul(fe_from_words(hi), fe_const(FE_R2_SHIFT256)));
+}
 // Montgomery-261 -> canonical 32 bytes (Fq::to_bytes_le)
 D377_HD void fe_to_bytes_words(const fe& a, uint32_t w[8]) { fe_to_words(fe_canon(a), w); }
 

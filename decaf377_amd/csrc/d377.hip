@@ -267,6 +267,45 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
   }
 }
 
+// wide byte strings (48 or 64 bytes per record) -> Fq, optionally straight into the Elligator map
+__device__ __forceinline__ fe load_wide(const uint8_t* in, size_t i, int len) {
+  const uint4* p = reinterpret_cast<const uint4*>(in + (size_t)len * i);
+  uint4 a = p[0], b = p[1], c = p[2];
+  uint4 d = make_uint4(0, 0, 0, 0);
+  if (len == 64) d = p[3];
+  const uint32_t lo[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const uint32_t hi[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+  return fe_from_wide_words(lo, hi);
+}
+__global__ void __launch_bounds__(BLOCK) k_fq_from_wide(const uint8_t* in, int len, size_t n, uint8_t* out32) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    fe_to_bytes_words(load_wide(in, i, len), w);
+    store32(out32, i, w);
+  }
+}
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(SqrtTables T, const uint8_t* in, int len,
+                                                                                size_t n, uint8_t* out32) {
+  D377_POW_LDS();
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    ge g = ge_elligator_map(T, pt, fe_carry(load_wide(in, i, len)));
+    ge_compress(T, pt, g, w);
+    store32(out32, i, w);
+  }
+}
+// (x/z, y/z) as Montgomery-256 limbs: CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81)
+__global__ void __launch_bounds__(BLOCK) k_to_affine(const uint64_t* xyzt, size_t n, uint64_t* xy) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    const ge g = load_ge_mont256(xyzt, i);
+    const fe zi = fe_invert(g.z);
+    uint8_t* b = reinterpret_cast<uint8_t*>(xy);
+    uint32_t w[8];
+    fe_to_mont256_words(fe_mul(g.x, zi), w); store32(b, 2 * i, w);
+    fe_to_mont256_words(fe_mul(g.y, zi), w); store32(b, 2 * i + 1, w);
+  }
+}
+
 __global__ void __launch_bounds__(BLOCK) k_add(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
     store_ge_mont256(out, i, ge_add(load_ge_mont256(p, i), load_ge_mont256(q, i)));
@@ -334,7 +373,7 @@ void free_device(DeviceState& d) {
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
-enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ };
+enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE };
 
 // launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null)
 int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
@@ -380,6 +419,19 @@ int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in
     case OP_EQ:
       hipLaunchKernelGGL(k_eq, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint64_t*)in1, n, (uint8_t*)out0);
       break;
+    case OP_WIDE48:
+    case OP_WIDE64:
+      hipLaunchKernelGGL(k_fq_from_wide, dim3(g), dim3(BLOCK), 0, s, (const uint8_t*)in0, op == OP_WIDE48 ? 48 : 64, n,
+                         (uint8_t*)out0);
+      break;
+    case OP_ENCODE_WIDE48:
+    case OP_ENCODE_WIDE64:
+      hipLaunchKernelGGL(k_encode_to_curve_wide, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
+                         op == OP_ENCODE_WIDE48 ? 48 : 64, n, (uint8_t*)out0);
+      break;
+    case OP_AFFINE:
+      hipLaunchKernelGGL(k_to_affine, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
+      break;
   }
   HIP_TRY(hipGetLastError());
   return D377_OK;
@@ -399,6 +451,11 @@ OpShape shape_of(Op op) {
     case OP_ADD: return {128, 128, 128, 0};
     case OP_DOUBLE: return {128, 0, 128, 0};
     case OP_EQ: return {128, 128, 1, 0};
+    case OP_WIDE48: return {48, 0, 32, 0};
+    case OP_WIDE64: return {64, 0, 32, 0};
+    case OP_ENCODE_WIDE48: return {48, 0, 32, 0};
+    case OP_ENCODE_WIDE64: return {64, 0, 32, 0};
+    case OP_AFFINE: return {128, 0, 64, 0};
   }
   return {0, 0, 0, 0};
 }
@@ -548,6 +605,36 @@ int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* 
 int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n,
                       uint8_t* equal) {
   return run_dev(ctx, dev, stream, OP_EQ, p_xyzt, q_xyzt, n, equal, nullptr);
+}
+
+static int wide_op(size_t len, Op o48, Op o64, Op* out) {
+  if (len == 48) { *out = o48; return D377_OK; }
+  if (len == 64) { *out = o64; return D377_OK; }
+  return fail(D377_ERR_ARG, "%s", "wide records must be 48 or 64 bytes (32-byte records use the plain entry points)");
+}
+int d377_batch_fq_from_wide_bytes(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* fq32_out) {
+  Op op; int rc = wide_op(len, OP_WIDE48, OP_WIDE64, &op);
+  return rc ? rc : run_host(ctx, op, bytes, nullptr, n, fq32_out, nullptr);
+}
+int d377_batch_encode_to_curve_wide(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* enc32_out) {
+  Op op; int rc = wide_op(len, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, &op);
+  return rc ? rc : run_host(ctx, op, bytes, nullptr, n, enc32_out, nullptr);
+}
+int d377_batch_to_affine(d377_ctx* ctx, const uint64_t* xyzt, size_t n, uint64_t* xy) {
+  return run_host(ctx, OP_AFFINE, xyzt, nullptr, n, xy, nullptr);
+}
+int d377_batch_fq_from_wide_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len, size_t n,
+                                      uint8_t* fq32_out) {
+  Op op; int rc = wide_op(len, OP_WIDE48, OP_WIDE64, &op);
+  return rc ? rc : run_dev(ctx, dev, stream, op, bytes, nullptr, n, fq32_out, nullptr);
+}
+int d377_batch_encode_to_curve_wide_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len, size_t n,
+                                        uint8_t* enc32_out) {
+  Op op; int rc = wide_op(len, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, &op);
+  return rc ? rc : run_dev(ctx, dev, stream, op, bytes, nullptr, n, enc32_out, nullptr);
+}
+int d377_batch_to_affine_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t n, uint64_t* xy) {
+  return run_dev(ctx, dev, stream, OP_AFFINE, xyzt, nullptr, n, xy, nullptr);
 }
 
 int d377_batch_sqrt_ratio_zeta_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* num32, const uint8_t* den32,

@@ -127,6 +127,37 @@ class Context:
         return self._run("d377_batch_eq", [p_xyzt, q_xyzt], [((), np.uint8)], _rows(p_xyzt), outs)[0]
 
 
+    # -- wide byte strings and affine normalisation -----------------------------------------------
+    def _wide(self, name, data):
+        n, length = int(data.shape[0]), int(data.shape[1])
+        if _is_torch(data):
+            import torch
+            dev = data.device
+            out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _native.check(getattr(self._lib, name + "_dev")(self._h, self.device_ids.index(dev.index), stream,
+                                                            ctypes.c_void_p(data.contiguous().data_ptr()),
+                                                            ctypes.c_size_t(length), ctypes.c_size_t(n),
+                                                            ctypes.c_void_p(out.data_ptr())))
+            return out
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        out = np.zeros((n, 32), np.uint8)
+        _native.check(getattr(self._lib, name)(self._h, data.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(length),
+                                               ctypes.c_size_t(n), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def fq_from_wide_bytes(self, data):
+        """Fq::from_le_bytes_mod_order on [n, 48|64] byte strings -> canonical [n, 32]."""
+        return self._wide("d377_batch_fq_from_wide_bytes", data)
+
+    def encode_to_curve_wide(self, data):
+        """encode_to_curve(Fq::from_le_bytes_mod_order(bytes)) for [n, 48|64] byte strings."""
+        return self._wide("d377_batch_encode_to_curve_wide", data)
+
+    def to_affine(self, xyzt, outs=None):
+        """CurveGroup::normalize_batch: [n, 16] Elements -> [n, 8] (x, y Montgomery limbs)."""
+        return self._run("d377_batch_to_affine", [xyzt], [((8,), np.uint64)], _rows(xyzt), outs)[0]
+
     # -- multi-scalar multiplication -------------------------------------------------------------
     def msm(self, points, scalar32, encoded=None):
         """Element::vartime_multiscalar_mul (src/ark_curve/element/projective.rs:99-117).

@@ -89,6 +89,14 @@ int d377_batch_add(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt
 int d377_batch_double(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);
 int d377_batch_eq(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint8_t* equal);
 
+/* Fq::from_le_bytes_mod_order on 48- or 64-byte strings (hash outputs)      src/fields/fq.rs:90-102
+ * -> canonical 32-byte Fq; and the same fused into encode_to_curve.  len must be 48 or 64. */
+int d377_batch_fq_from_wide_bytes(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* fq32_out);
+int d377_batch_encode_to_curve_wide(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* enc32_out);
+/* CurveGroup::normalize_batch / into_affine                                   src/ark_curve/element.rs:74-85
+ * xy: n x 8 u64 = affine x, y as 4 Montgomery limbs each. */
+int d377_batch_to_affine(d377_ctx* ctx, const uint64_t* xyzt, size_t n, uint64_t* xy);
+
 /* Element::vartime_multiscalar_mul(scalars, points) = sum_i scalar_i * point_i
  *                                                 src/ark_curve/element/projective.rs:99-117
  * (a fold of scalar multiplications in the reference; a Pippenger bucket MSM here).  The sum is
@@ -127,6 +135,11 @@ int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* 
 int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt,
                       size_t n, uint8_t* equal);
 
+int d377_batch_fq_from_wide_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len,
+                                      size_t n, uint8_t* fq32_out);
+int d377_batch_encode_to_curve_wide_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len,
+                                        size_t n, uint8_t* enc32_out);
+int d377_batch_to_affine_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t n, uint64_t* xy);
 /* MSM on device buffers (the workspace grows inside the context on first use of a larger n). */
 int d377_msm_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, const uint8_t* scalar32, size_t n,
                  uint8_t* enc32_out, uint64_t* xyzt_out);

@@ -510,6 +510,38 @@ API void d377o_eq_xyzt(const uint64_t *p, const uint64_t *q, size_t n, uint8_t *
 }
 API void d377o_generator_xyzt(uint64_t *xyzt) { el_store(el_generator(), xyzt); }
 
+/* Fq::from_le_bytes_mod_order for any length (src/fields/fq.rs:90-102): 32-byte chunks, folded
+ * from the most significant one with acc * FIELD_SIZE_POWER_OF_TWO + chunk (fq.rs:83-88 = 2^256 mod q). */
+static const fq FQ_FIELD_SIZE_POWER_OF_TWO = {{2726216793283724667ULL, 14712177743343147295ULL,
+                                               12091039717619697043ULL, 81024008013859129ULL}};
+static fq fq_from_le_bytes_mod_order_any(const uint8_t *b, size_t len) {
+    fq acc = FQ_ZERO;
+    size_t nchunks = (len + 31) / 32;
+    for (size_t c = nchunks; c-- > 0;) {
+        uint8_t padded[32] = {0};
+        size_t l = (c * 32 + 32 <= len) ? 32 : len - c * 32;
+        memcpy(padded, b + c * 32, l);
+        acc = fq_add(fq_mul(acc, FQ_FIELD_SIZE_POWER_OF_TWO), fq_from_le_bytes_mod_order(padded));
+    }
+    return acc;
+}
+API void d377o_fq_from_wide_bytes(const uint8_t *in, size_t len, size_t n, uint8_t *out32) {
+    for (size_t i = 0; i < n; ++i) fq_to_bytes(fq_from_le_bytes_mod_order_any(in + len * i, len), out32 + 32 * i);
+}
+API void d377o_encode_to_curve_wide(const uint8_t *in, size_t len, size_t n, uint8_t *out32) {
+    for (size_t i = 0; i < n; ++i)
+        el_compress(el_elligator_map(fq_from_le_bytes_mod_order_any(in + len * i, len)), out32 + 32 * i);
+}
+/* CurveGroup::normalize_batch / into_affine (src/ark_curve/element.rs:74-85): (x/z, y/z) as Montgomery limbs */
+API void d377o_to_affine(const uint64_t *xyzt, size_t n, uint64_t *xy) {
+    for (size_t i = 0; i < n; ++i) {
+        element e = el_load(xyzt + 16 * i);
+        fq zi = fq_inverse(e.z);
+        fq x = fq_mul(e.x, zi), y = fq_mul(e.y, zi);
+        memcpy(xy + 8 * i, x.l, 32); memcpy(xy + 8 * i + 4, y.l, 32);
+    }
+}
+
 /* Element::vartime_multiscalar_mul, src/ark_curve/element/projective.rs:99-117:
  * fold(Element::default(), |acc, (scalar, point)| acc + scalar * point), result compressed. */
 API void d377o_msm(const uint64_t *xyzt, const uint8_t *scalar32, size_t n, uint8_t *enc32_out, uint64_t *xyzt_out) {

@@ -161,6 +161,24 @@ class Oracle:
             acc = self.add_xyzt(acc, q.reshape(1, 16))
         return self.compress(acc)[0], acc[0]
 
+    def fq_from_wide_bytes(self, b, length):
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.uint8)).reshape(-1, length)
+        out = np.zeros((b.shape[0], 32), np.uint8)
+        self.lib.d377o_fq_from_wide_bytes(_p(b), self._n(length), self._n(b.shape[0]), _p(out))
+        return out
+
+    def encode_to_curve_wide(self, b, length):
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.uint8)).reshape(-1, length)
+        out = np.zeros((b.shape[0], 32), np.uint8)
+        self.lib.d377o_encode_to_curve_wide(_p(b), self._n(length), self._n(b.shape[0]), _p(out))
+        return out
+
+    def to_affine(self, xyzt):
+        xyzt = np.ascontiguousarray(xyzt, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros((xyzt.shape[0], 8), np.uint64)
+        self.lib.d377o_to_affine(_p(xyzt), self._n(xyzt.shape[0]), _p(out))
+        return out
+
     def generator_xyzt(self):
         out = np.zeros(16, np.uint64)
         self.lib.d377o_generator_xyzt(_p(out))

@@ -357,3 +357,29 @@ def test_full_size_var_base_2_22(ctx, torch_mod, oracle):
     idx = np.arange(0, n, 16411)
     o_out, o_st = oracle.scalar_mul_var(P[idx].cpu().numpy(), k[idx].cpu().numpy())
     assert (out[idx].cpu().numpy() == o_out).all() and not o_st.any()
+
+
+def test_wide_bytes_and_affine(ctx, oracle):
+    """SURVEY 8f-3/8f-4: Fq::from_le_bytes_mod_order on 48/64-byte strings (src/fields/fq.rs:90-102),
+    fused into encode_to_curve, and CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81)."""
+    import decaf377_amd as d
+    rng = np.random.default_rng(675)
+    n = 4099
+    for length in (48, 64):
+        raw = rng.integers(0, 256, (n, length), dtype=np.uint8)
+        raw[0] = 0
+        raw[1] = 0xFF
+        raw[2, :32] = 0
+        raw[3, 32:] = 0
+        fq = ctx.fq_from_wide_bytes(raw)
+        assert (fq == oracle.fq_from_wide_bytes(raw, length)).all()
+        ints = [int.from_bytes(bytes(r), "little") % Q for r in raw[:64]]
+        assert [int.from_bytes(bytes(r), "little") for r in fq[:64]] == ints
+        enc = ctx.encode_to_curve_wide(raw)
+        assert (enc == oracle.encode_to_curve_wide(raw, length)).all()
+        assert (enc == ctx.encode_to_curve(fq)).all()
+    with pytest.raises(d.NativeError):
+        ctx.fq_from_wide_bytes(rng.integers(0, 256, (4, 40), dtype=np.uint8))
+    P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    xy = ctx.to_affine(P)
+    assert (xy == oracle.to_affine(P)).all()
