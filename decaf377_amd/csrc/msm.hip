@@ -7,8 +7,10 @@
 //   k_msm_prepare   one lane per (point, scalar): [decompress,] cached form of the point -> HBM,
 //                   scalar mod r -> W signed digits, histogram of |digit| per window (atomics)
 //   k_msm_scan      one workgroup per window: exclusive prefix sum of the histogram
-//   k_msm_scatter   one lane per point: its index (sign in bit 31) into each window's bucket run
-//   k_msm_buckets   one lane per bucket: sum of its run (cached additions, 8 M each)
+//   k_msm_scatter   one lane per point: its index (sign in bit 31) into each window's bucket run,
+//                   at offset + the rank the histogram atomic returned (no second round of atomics)
+//   k_msm_segments  one lane per 32-point segment of a bucket run: cached additions (8 M each)
+//   k_msm_buckets   one lane per bucket: sum of its segment partials
 //   k_msm_chunks    one lane per 32 consecutive buckets: running-sum trick inside the chunk,
 //                   plus (lo - 1) * (chunk total) by double-and-add:  sum_b b * B_b
 //   k_msm_fold      32-to-1 folds until one point per window
@@ -34,6 +36,7 @@ namespace {
 constexpr int PT_WORDS = 4 * SLOT;      // one cached or extended point record: 192 B
 constexpr int CHUNK = 32;               // buckets per lane in k_msm_chunks
 constexpr int FOLD = 32;                // points per lane in k_msm_fold
+constexpr int SEG = 32;                 // points per lane in k_msm_segments
 
 __device__ __forceinline__ void pt_store_cached(uint32_t* p, const gec& c) {
   slot_store(p, c.ypx); slot_store(p + SLOT, c.ymx); slot_store(p + 2 * SLOT, c.z2); slot_store(p + 3 * SLOT, c.kt);
@@ -70,7 +73,7 @@ __device__ __forceinline__ int msm_digit(const uint32_t k[8], int w, int c, int 
 template <bool ENCODED>
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, int c, int W, int nb,
-              uint32_t* pts, int16_t* digits, uint32_t* count, uint8_t* status) {
+              uint32_t* pts, int16_t* digits, uint32_t* rank, uint32_t* count, uint8_t* status) {
   D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     ge g;
@@ -93,74 +96,125 @@ k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t 
       int d = msm_digit(k, w, c, W, carry);
       if (bad) d = 0;                                   // invalid points contribute nothing
       digits[(size_t)w * n + i] = (int16_t)d;
-      if (d != 0) atomicAdd(&count[(size_t)w * (nb + 1) + (d < 0 ? -d : d)], 1u);
+      // the histogram atomic also hands out this point's rank inside its bucket, so the scatter
+      // below needs no second round of atomics
+      if (d != 0) rank[(size_t)w * n + i] = atomicAdd(&count[(size_t)w * (nb + 1) + (d < 0 ? -d : d)], 1u);
     }
   }
 }
 
-// exclusive scan of count[w][0..nb] -> offs[w][0..nb] (offs[w][nb] = total), cursor = offs
-__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* count, uint32_t* offs, uint32_t* cursor, int nb) {
+// exclusive scan of count[w][0..nb] -> offs[w][0..nb] (offs[w][nb] = total), cursor = offs; and the
+// same for the number of SEG-point segments of every bucket run -> segoff[w][0..nb]
+__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* count, uint32_t* offs, uint32_t* cursor,
+                                                   uint32_t* segoff, int nb) {
   __shared__ uint32_t part[1024];
+  __shared__ uint32_t part2[1024];
   const int w = blockIdx.x, t = threadIdx.x;
   const int len = nb + 1;
   const int per = (len + 1023) / 1024;
   const uint32_t* cw = count + (size_t)w * len;
-  uint32_t s = 0;
-  for (int j = t * per; j < (t + 1) * per && j < len; ++j) s += (j < nb) ? cw[j] : 0u;   // slot nb is the sentinel
-  part[t] = s;
+  uint32_t s = 0, s2 = 0;
+  for (int j = t * per; j < (t + 1) * per && j < len; ++j) {
+    const uint32_t c = (j < nb) ? cw[j] : 0u;                 // slot nb is the sentinel
+    s += c;
+    s2 += (c + SEG - 1) / SEG;
+  }
+  part[t] = s; part2[t] = s2;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = (t >= off) ? part[t - off] : 0u;
+    uint32_t v = (t >= off) ? part[t - off] : 0u, v2 = (t >= off) ? part2[t - off] : 0u;
     __syncthreads();
-    part[t] += v;
+    part[t] += v; part2[t] += v2;
     __syncthreads();
   }
-  uint32_t run = part[t] - s;
+  uint32_t run = part[t] - s, run2 = part2[t] - s2;
   for (int j = t * per; j < (t + 1) * per && j < len; ++j) {
     offs[(size_t)w * len + j] = run;
     cursor[(size_t)w * len + j] = run;
-    run += (j < nb) ? cw[j] : 0u;
+    segoff[(size_t)w * len + j] = run2;
+    const uint32_t c = (j < nb) ? cw[j] : 0u;
+    run += c;
+    run2 += (c + SEG - 1) / SEG;
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_msm_scatter(const int16_t* digits, size_t n, int W, int nb,
-                                                       uint32_t* cursor, uint32_t* idx) {
+__global__ void __launch_bounds__(BLOCK) k_msm_scatter(const int16_t* digits, const uint32_t* rank, size_t n, int W, int nb,
+                                                       const uint32_t* offs, uint32_t* idx) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
 #pragma unroll 1
     for (int w = 0; w < W; ++w) {
       const int d = digits[(size_t)w * n + i];
       if (d == 0) continue;
       const uint32_t b = (uint32_t)(d < 0 ? -d : d);
-      const uint32_t pos = atomicAdd(&cursor[(size_t)w * (nb + 1) + b], 1u);
+      const uint32_t pos = offs[(size_t)w * (nb + 1) + b] + rank[(size_t)w * n + i];
       idx[(size_t)w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
     }
   }
 }
 
+// One lane per SEG-point segment of a bucket run (runs are Poisson-distributed around n / 2^(c-1);
+// one lane per whole bucket left lanes of a wave waiting for the longest run and quantised the
+// grid to ~1.1 residency rounds).  Lane gi finds its (window, bucket, segment) by a short search
+// in the segment prefix sums, adds its <= SEG cached points (next record in flight while the
+// current one is added) and writes one partial sum.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_buckets(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, size_t n, int W, int nb, uint32_t* buckets) {
+k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, const uint32_t* segoff, size_t n, int W,
+               int nb, size_t max_segs, uint32_t* partial) {
+  const int len = nb + 1;
+  for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_segs; gi += (size_t)gridDim.x * BLOCK) {
+    // window: running total of segments per window (W <= 63)
+    size_t base = 0;
+    int w = 0;
+    for (; w < W; ++w) {
+      const uint32_t tot = segoff[(size_t)w * len + nb];
+      if (gi < base + tot) break;
+      base += tot;
+    }
+    if (w == W) break;                                 // beyond the last real segment
+    const uint32_t local = (uint32_t)(gi - base);
+    const uint32_t* so = segoff + (size_t)w * len;
+    int lo_b = 0, hi_b = nb;                           // largest b with so[b] <= local
+    while (hi_b - lo_b > 1) {
+      const int mid = (lo_b + hi_b) >> 1;
+      if (so[mid] <= local) lo_b = mid; else hi_b = mid;
+    }
+    const int b = lo_b;
+    const uint32_t k = local - so[b];
+    const uint32_t run_lo = offs[(size_t)w * len + b], run_hi = offs[(size_t)w * len + b + 1];
+    uint32_t lo = run_lo + k * SEG, hi = lo + SEG;
+    if (hi > run_hi) hi = run_hi;
+    ge acc = ge_identity();
+    if (lo < hi) {
+      uint32_t e = idx[(size_t)w * n + lo];
+      gec q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * PT_WORDS, (e >> 31) != 0);
+#pragma unroll 1
+      for (uint32_t j = lo; j < hi; ++j) {
+        const bool neg = (e >> 31) != 0;
+        const gec cur = q;
+        if (j + 1 < hi) {
+          e = idx[(size_t)w * n + j + 1];
+          q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * PT_WORDS, (e >> 31) != 0);
+        }
+        acc = ge_add_cached(acc, cur, neg, true);
+      }
+    }
+    pt_store_ext(partial + gi * PT_WORDS, acc);
+  }
+}
+
+// one lane per bucket: sum of its (usually <= 5) segment partials
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_buckets(const uint32_t* partial, const uint32_t* segoff, int W, int nb, uint32_t* buckets) {
+  const int len = nb + 1;
   const size_t total = (size_t)W * nb;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < total; gi += (size_t)gridDim.x * BLOCK) {
     const int w = (int)(gi / nb), b = (int)(gi % nb);
+    size_t base = 0;
+    for (int k = 0; k < w; ++k) base += segoff[(size_t)k * len + nb];
+    const uint32_t s0 = segoff[(size_t)w * len + b], s1 = segoff[(size_t)w * len + b + 1];
     ge acc = ge_identity();
-    if (b != 0) {
-      const uint32_t lo = offs[(size_t)w * (nb + 1) + b], hi = offs[(size_t)w * (nb + 1) + b + 1];
-      // double-buffered gather: the next point's 192-byte record is in flight while this one is added
-      if (lo < hi) {
-        uint32_t e = idx[(size_t)w * n + lo];
-        gec q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * PT_WORDS, (e >> 31) != 0);
 #pragma unroll 1
-        for (uint32_t j = lo; j < hi; ++j) {
-          const bool neg = (e >> 31) != 0;
-          const gec cur = q;
-          if (j + 1 < hi) {
-            e = idx[(size_t)w * n + j + 1];
-            q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * PT_WORDS, (e >> 31) != 0);
-          }
-          acc = ge_add_cached(acc, cur, neg, true);
-        }
-      }
-    }
+    for (uint32_t j = s0; j < s1; ++j) acc = ge_add(acc, pt_load_ext(partial + (base + j) * PT_WORDS));
     pt_store_ext(buckets + gi * PT_WORDS, acc);
   }
 }
@@ -283,7 +337,11 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_cnt = carve((size_t)W * (nb + 1) * 4);
   const size_t o_off = carve((size_t)W * (nb + 1) * 4);
   const size_t o_cur = carve((size_t)W * (nb + 1) * 4);
+  const size_t o_seg = carve((size_t)W * (nb + 1) * 4);
+  const size_t max_segs = ((size_t)n * W) / SEG + (size_t)W * nb;      // sum of ceil(run / SEG) never exceeds this
+  const size_t o_par = carve(max_segs * PT_WORDS * 4);
   const size_t o_idx = carve((size_t)W * n * 4);
+  const size_t o_rank = carve((size_t)W * n * 4);
   const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
   const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
   const size_t o_f0 = carve((size_t)W * ((nchunks + FOLD - 1) / FOLD) * PT_WORDS * 4);
@@ -298,20 +356,24 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   uint32_t* pts = (uint32_t*)(m + o_pts);
   int16_t* dig = (int16_t*)(m + o_dig);
   uint32_t *cnt = (uint32_t*)(m + o_cnt), *offs = (uint32_t*)(m + o_off), *cur = (uint32_t*)(m + o_cur);
+  uint32_t *segoff = (uint32_t*)(m + o_seg), *partial = (uint32_t*)(m + o_par);
   uint32_t* idx = (uint32_t*)(m + o_idx);
+  uint32_t* rank = (uint32_t*)(m + o_rank);
   uint32_t *bkt = (uint32_t*)(m + o_bkt), *ch = (uint32_t*)(m + o_ch), *f0 = (uint32_t*)(m + o_f0), *f1 = (uint32_t*)(m + o_f1);
   const SqrtTables T = d.tables();
 
   HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)W * (nb + 1) * 4, s));
   if (encoded)
     hipLaunchKernelGGL(k_msm_prepare<true>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, nb, pts,
-                       dig, cnt, status);
+                       dig, rank, cnt, status);
   else
     hipLaunchKernelGGL(k_msm_prepare<false>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, nb, pts,
-                       dig, cnt, status);
-  hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, cnt, offs, cur, nb);
-  hipLaunchKernelGGL(k_msm_scatter, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, dig, n, W, nb, cur, idx);
-  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, pts, idx, offs, n, W, nb, bkt);
+                       dig, rank, cnt, status);
+  hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, cnt, offs, cur, segoff, nb);
+  hipLaunchKernelGGL(k_msm_scatter, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, dig, rank, n, W, nb, offs, idx);
+  hipLaunchKernelGGL(k_msm_segments, dim3(grid_of(d, max_segs)), dim3(BLOCK), 0, s, pts, idx, offs, segoff, n, W, nb,
+                     max_segs, partial);
+  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, partial, segoff, W, nb, bkt);
   hipLaunchKernelGGL(k_msm_chunks, dim3(grid_of(d, (size_t)W * nchunks)), dim3(BLOCK), 0, s, bkt, W, nb, nchunks, ch);
   // fold chunk results down to one point per window
   const uint32_t* cur_in = ch;
