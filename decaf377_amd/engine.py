@@ -83,7 +83,7 @@ class Context:
             return outs
         ins = [np.ascontiguousarray(a) for a in ins]
         if outs is None:
-            outs = [np.zeros((n,) + tail, dtype=dt) for tail, dt in outs_spec]
+            outs = [np.empty((n,) + tail, dtype=dt) for tail, dt in outs_spec]   # np.zeros would page-fault inside the D2H copy
         args = [self._h] + [a.ctypes.data_as(ctypes.c_void_p) for a in ins] + [ctypes.c_size_t(n)]
         args += [a.ctypes.data_as(ctypes.c_void_p) for a in outs]
         _native.check(getattr(self._lib, name)(*args))
