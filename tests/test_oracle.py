@@ -280,3 +280,13 @@ def test_threaded_driver_matches_serial(oracle):
     assert used == 4 and (out1 == out2).all() and (st1 == st2).all()
     out3, _, _ = oracle.run_threads("encode_to_curve", r0, None, 3)
     assert (out3 == enc).all()
+
+
+def test_oracle_sanitizer_selftest():
+    """AddressSanitizer + UBSan run of every oracle entry point (CPU build only; GPU ASan is not
+    available on this pool)."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-C", odir, "selftest"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(odir, "selftest")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ORACLE_SELFTEST_OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
