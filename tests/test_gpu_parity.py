@@ -383,3 +383,39 @@ def test_wide_bytes_and_affine(ctx, oracle):
     P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
     xy = ctx.to_affine(P)
     assert (xy == oracle.to_affine(P)).all()
+
+
+def test_api_contract_edges(ctx, torch_mod, oracle):
+    """Boundary behaviour of the C ABI: misaligned device records are refused, two contexts on one
+    device are independent, a ragged large batch grid-strides correctly, outputs never alias state."""
+    import decaf377_amd as d
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(676)
+    # misaligned device pointer -> D377_ERR_ARG, not a fault
+    buf = torch.zeros(32 * 64 + 8, dtype=torch.uint8, device=dev)
+    mis = buf[8:8 + 32 * 64].view(64, 32)
+    assert mis.data_ptr() % 16 == 8
+    with pytest.raises(d.NativeError):
+        ctx.encode_to_curve(mis)
+    # two contexts, interleaved calls, same answers
+    ctx2 = d.Context([0])
+    r0 = rng.integers(0, 256, (2048, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (2048, 32), dtype=np.uint8)
+    e1 = ctx.encode_to_curve(r0)
+    e2 = ctx2.encode_to_curve(r0)
+    o1, _ = ctx.scalar_mul_var(e1, k)
+    o2, _ = ctx2.scalar_mul_var(e2, k)
+    o1b, _ = ctx.scalar_mul_var(e1, k)
+    assert (e1 == e2).all() and (o1 == o2).all() and (o1 == o1b).all()
+    ctx2.close()
+    # ragged large batch on the device path: 2^21 + 3 elements
+    n = (1 << 21) + 3
+    g = torch.Generator(device=dev).manual_seed(677)
+    r = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    enc = ctx.encode_to_curve(r)
+    rt, st = ctx.roundtrip(enc)
+    torch.cuda.synchronize()
+    assert torch.equal(rt, enc) and int(st.sum().item()) == 0
+    tail = slice(n - 5, n)
+    assert (enc[tail].cpu().numpy() == oracle.encode_to_curve(r[tail].cpu().numpy())).all()
