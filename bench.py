@@ -178,7 +178,7 @@ def main():
         try:
             rec = json.load(open(tpath)).get("k_scalar_mul_var")
             if rec and rec.get("elements") == n:
-                traffic = rec["hbm_bytes_per_launch"]     # PMC, separate rocprofv3 passes (profiles/r01_v2_pmc.csv)
+                traffic = rec["hbm_bytes_per_launch"]     # PMC, separate rocprofv3 passes (profiles/r01_final_pmc.csv)
         except Exception:
             traffic = None
     line["roofline"] = {
