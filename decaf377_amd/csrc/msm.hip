@@ -34,7 +34,7 @@ using namespace d377;
 namespace {
 
 constexpr int PT_WORDS = 4 * SLOT;      // one cached or extended point record: 192 B
-constexpr int CHUNK = 32;               // buckets per lane in k_msm_chunks
+constexpr int CHUNK = 8;                // buckets per lane in k_msm_chunks (short chains: this phase is latency-bound)
 constexpr int FOLD = 32;                // points per lane in k_msm_fold
 constexpr int SEG = 32;                 // points per lane in k_msm_segments
 
