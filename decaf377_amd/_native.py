@@ -18,6 +18,8 @@ EXPORTS = [
     "d377_batch_scalar_mul_base", "d377_batch_scalar_mul_var", "d377_batch_encode_to_curve",
     "d377_batch_hash_to_curve", "d377_batch_add", "d377_batch_double", "d377_batch_eq",
     "d377_batch_add_dev", "d377_batch_double_dev", "d377_batch_eq_dev",
+    "d377_batch_neg", "d377_batch_is_identity", "d377_batch_neg_dev", "d377_batch_is_identity_dev",
+    "d377_identity", "d377_generator",
     "d377_batch_fq_from_wide_bytes", "d377_batch_encode_to_curve_wide", "d377_batch_to_affine",
     "d377_batch_fq_from_wide_bytes_dev", "d377_batch_encode_to_curve_wide_dev", "d377_batch_to_affine_dev",
     "d377_msm", "d377_msm_encoded", "d377_msm_dev", "d377_msm_encoded_dev", "d377_sum_elements_dev",
@@ -72,6 +74,8 @@ def load():
         "d377_batch_add": [vp, vp, vp, sz, vp],
         "d377_batch_double": [vp, vp, sz, vp],
         "d377_batch_eq": [vp, vp, vp, sz, vp],
+        "d377_batch_neg": [vp, vp, sz, vp],
+        "d377_batch_is_identity": [vp, vp, sz, vp],
     }
     for name, args in host.items():
         getattr(lib, name).argtypes = args
@@ -88,6 +92,10 @@ def load():
     for name in ("d377_batch_fq_from_wide_bytes", "d377_batch_encode_to_curve_wide", "d377_batch_to_affine"):
         getattr(lib, name).restype = i32
         getattr(lib, name + "_dev").restype = i32
+    lib.d377_identity.argtypes = [vp]
+    lib.d377_identity.restype = None
+    lib.d377_generator.argtypes = [vp]
+    lib.d377_generator.restype = None
     lib.d377_msm.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.d377_msm_encoded.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     lib.d377_msm_dev.argtypes = [vp, i32, vp, vp, vp, sz, vp, vp]

@@ -306,6 +306,15 @@ __global__ void __launch_bounds__(BLOCK) k_to_affine(const uint64_t* xyzt, size_
   }
 }
 
+__global__ void __launch_bounds__(BLOCK) k_neg(const uint64_t* p, size_t n, uint64_t* out) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+    store_ge_mont256(out, i, ge_neg(load_ge_mont256(p, i)));
+}
+// Element::is_identity: x == 0 (src/min_curve/element.rs:113-117)
+__global__ void __launch_bounds__(BLOCK) k_is_identity(const uint64_t* p, size_t n, uint8_t* out) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+    out[i] = fe_is_zero(load_ge_mont256(p, i).x) ? 1 : 0;
+}
 __global__ void __launch_bounds__(BLOCK) k_add(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
     store_ge_mont256(out, i, ge_add(load_ge_mont256(p, i), load_ge_mont256(q, i)));
@@ -373,7 +382,7 @@ void free_device(DeviceState& d) {
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
-enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE };
+enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE, OP_NEG, OP_IS_IDENTITY };
 
 // launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null)
 int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
@@ -432,6 +441,12 @@ int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in
     case OP_AFFINE:
       hipLaunchKernelGGL(k_to_affine, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
+    case OP_NEG:
+      hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
+      break;
+    case OP_IS_IDENTITY:
+      hipLaunchKernelGGL(k_is_identity, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint8_t*)out0);
+      break;
   }
   HIP_TRY(hipGetLastError());
   return D377_OK;
@@ -456,6 +471,8 @@ OpShape shape_of(Op op) {
     case OP_ENCODE_WIDE48: return {48, 0, 32, 0};
     case OP_ENCODE_WIDE64: return {64, 0, 32, 0};
     case OP_AFFINE: return {128, 0, 64, 0};
+    case OP_NEG: return {128, 0, 128, 0};
+    case OP_IS_IDENTITY: return {128, 0, 1, 0};
   }
   return {0, 0, 0, 0};
 }
@@ -502,7 +519,7 @@ int run_dev(d377_ctx* ctx, int dev, void* stream, Op op, const void* in0, const 
   if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
   const OpShape sh = shape_of(op);
   if (n && (!in0 || (sh.in1 && !in1) || !out0 || (sh.out1 && !out1))) return fail(D377_ERR_ARG, "%s", "null buffer");
-  if (!aligned16(in0) || !aligned16(in1) || (op != OP_EQ && !aligned16(out0)))
+  if (!aligned16(in0) || !aligned16(in1) || (op != OP_EQ && op != OP_IS_IDENTITY && !aligned16(out0)))
     return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
   DeviceState& d = ctx->devs[(size_t)dev];
   HIP_TRY(hipSetDevice(d.id));
@@ -605,6 +622,35 @@ int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* 
 int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n,
                       uint8_t* equal) {
   return run_dev(ctx, dev, stream, OP_EQ, p_xyzt, q_xyzt, n, equal, nullptr);
+}
+
+int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
+  return run_host(ctx, OP_NEG, p_xyzt, nullptr, n, out_xyzt, nullptr);
+}
+int d377_batch_is_identity(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint8_t* is_identity) {
+  return run_host(ctx, OP_IS_IDENTITY, p_xyzt, nullptr, n, is_identity, nullptr);
+}
+int d377_batch_neg_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
+  return run_dev(ctx, dev, stream, OP_NEG, p_xyzt, nullptr, n, out_xyzt, nullptr);
+}
+int d377_batch_is_identity_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n,
+                               uint8_t* is_identity) {
+  return run_dev(ctx, dev, stream, OP_IS_IDENTITY, p_xyzt, nullptr, n, is_identity, nullptr);
+}
+// Element::IDENTITY / Element::GENERATOR in the external layout (src/min_curve/element.rs:53-81): the
+// Montgomery (R = 2^256) limbs the reference writes down in its source
+void d377_identity(uint64_t xyzt[16]) {
+  static const uint64_t one[4] = {0x7d1c7ffffffffff3ULL, 0x7257f50f6ffffff2ULL, 0x16d81575512c0feeULL, 0x0d4bda322bbb9a9dULL};
+  for (int i = 0; i < 16; ++i) xyzt[i] = 0;
+  for (int i = 0; i < 4; ++i) { xyzt[4 + i] = one[i]; xyzt[8 + i] = one[i]; }
+}
+void d377_generator(uint64_t xyzt[16]) {
+  static const uint64_t g[16] = {
+      5825153684096051627ULL, 16988948339439369204ULL, 186539475124256708ULL, 1230075515893193738ULL,
+      9786171649960077610ULL, 13527783345193426398ULL, 10983305067350511165ULL, 1251302644532346138ULL,
+      0x7d1c7ffffffffff3ULL, 0x7257f50f6ffffff2ULL, 0x16d81575512c0feeULL, 0x0d4bda322bbb9a9dULL,
+      7466800842436274004ULL, 14314110021432015475ULL, 14108125795146788134ULL, 1305086759679105397ULL};
+  for (int i = 0; i < 16; ++i) xyzt[i] = g[i];
 }
 
 static int wide_op(size_t len, Op o48, Op o64, Op* out) {

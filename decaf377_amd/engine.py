@@ -126,6 +126,24 @@ class Context:
     def eq(self, p_xyzt, q_xyzt, outs=None):
         return self._run("d377_batch_eq", [p_xyzt, q_xyzt], [((), np.uint8)], _rows(p_xyzt), outs)[0]
 
+    def neg(self, p_xyzt, outs=None):
+        return self._run("d377_batch_neg", [p_xyzt], [((16,), np.uint64)], _rows(p_xyzt), outs)[0]
+
+    def is_identity(self, p_xyzt, outs=None):
+        return self._run("d377_batch_is_identity", [p_xyzt], [((), np.uint8)], _rows(p_xyzt), outs)[0]
+
+    def identity(self):
+        """Element::IDENTITY as one [16] u64 record (src/min_curve/element.rs:53-58)."""
+        out = np.zeros(16, np.uint64)
+        self._lib.d377_identity(out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
+    def generator(self):
+        """Element::GENERATOR as one [16] u64 record (src/min_curve/element.rs:61-81)."""
+        out = np.zeros(16, np.uint64)
+        self._lib.d377_generator(out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
 
     # -- wide byte strings and affine normalisation -----------------------------------------------
     def _wide(self, name, data):
@@ -299,6 +317,14 @@ class Element:
     def __add__(self, other):
         """Element + Element (src/min_curve/element.rs:291-322)."""
         return Element(self._ctx().add(self.data, other.data), self.ctx)
+
+    def __neg__(self):
+        """-Element (src/min_curve/element.rs:324-332)."""
+        return Element(self._ctx().neg(self.data), self.ctx)
+
+    def is_identity(self):
+        """Element::is_identity (src/min_curve/element.rs:113-117) -> u8[n]."""
+        return self._ctx().is_identity(self.data)
 
     def double(self):
         """Element::double (src/min_curve/element.rs:119-136)."""

@@ -110,6 +110,13 @@ int d377_msm(d377_ctx* ctx, const uint64_t* xyzt, const uint8_t* scalar32, size_
 int d377_msm_encoded(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t n, uint8_t* enc32_out,
                      uint64_t* xyzt_out, uint8_t* status);
 
+/* -Element (x, t negated), Element::is_identity (x == 0), and the constants Element::IDENTITY /
+ * Element::GENERATOR as one 16 x u64 record each      src/min_curve/element.rs:324-332, 113-117, 53-81 */
+int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);
+int d377_batch_is_identity(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint8_t* is_identity);
+void d377_identity(uint64_t xyzt[16]);
+void d377_generator(uint64_t xyzt[16]);
+
 /* Device-pointer forms (same semantics). */
 int d377_batch_sqrt_ratio_zeta_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* num32,
                                    const uint8_t* den32, size_t n, uint8_t* root32, uint8_t* was_square);
@@ -135,6 +142,9 @@ int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* 
 int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt,
                       size_t n, uint8_t* equal);
 
+int d377_batch_neg_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);
+int d377_batch_is_identity_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n,
+                               uint8_t* is_identity);
 int d377_batch_fq_from_wide_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len,
                                       size_t n, uint8_t* fq32_out);
 int d377_batch_encode_to_curve_wide_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len,

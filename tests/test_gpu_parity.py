@@ -419,3 +419,24 @@ def test_api_contract_edges(ctx, torch_mod, oracle):
     assert torch.equal(rt, enc) and int(st.sum().item()) == 0
     tail = slice(n - 5, n)
     assert (enc[tail].cpu().numpy() == oracle.encode_to_curve(r[tail].cpu().numpy())).all()
+
+
+def test_neg_identity_generator(ctx, oracle, kats):
+    """neg, is_identity, IDENTITY, GENERATOR (src/min_curve/element.rs:53-117,324-332)."""
+    gen, ident = ctx.generator(), ctx.identity()
+    assert (gen == oracle.generator_xyzt()).all()
+    assert [int(v) for v in gen[0:4]] == kats["generator"]["x_mont"]
+    assert bytes(ctx.compress(ident.reshape(1, 16))[0]) == bytes(32)
+    assert bytes(ctx.compress(gen.reshape(1, 16))[0]).hex() == kats["generator"]["hex"]
+    rng = np.random.default_rng(678)
+    n = 1500
+    P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    P[0], P[1] = ident, gen
+    N = ctx.neg(P)
+    s = ctx.add(P, N)                                  # P + (-P) = identity
+    assert ctx.is_identity(s).all()
+    assert ctx.is_identity(P)[0] == 1 and not ctx.is_identity(P)[1:].any()
+    assert (ctx.compress(s) == 0).all()
+    # -P has x and t negated, y and z unchanged (exact limbs)
+    assert (N[:, 4:12] == P[:, 4:12]).all()
+    assert ctx.eq(ctx.neg(N), P).all()
