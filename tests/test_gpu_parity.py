@@ -440,3 +440,32 @@ def test_neg_identity_generator(ctx, oracle, kats):
     # -P has x and t negated, y and z unchanged (exact limbs)
     assert (N[:, 4:12] == P[:, 4:12]).all()
     assert ctx.eq(ctx.neg(N), P).all()
+
+
+def test_multi_device_context_slicing(oracle):
+    """A context that owns several devices slices the batch into contiguous shards.
+    With one physical GPU the same device is listed twice / three times: that exercises the whole
+    multi-device host path (per-device tables, streams, slices, MSM partial-sum combine)."""
+    import decaf377_amd as d
+    rng = np.random.default_rng(679)
+    for ids in ([0, 0], [0, 0, 0]):
+        c = d.Context(ids)
+        assert c.device_ids == ids
+        for n in (1, 2, 5, 1001, 4096):
+            r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            enc = c.encode_to_curve(r0)
+            assert (enc == oracle.encode_to_curve(r0)).all()
+            raw = enc.copy()
+            raw[::7, 31] |= 0x80                      # some invalid encodings, spread over all shards
+            out, st = c.scalar_mul_var(raw, k)
+            o_out, o_st = oracle.scalar_mul_var(raw, k)
+            assert (out == o_out).all() and (st == o_st).all()
+            xyzt, st = c.decompress(enc)
+            e, _, _ = c.msm(xyzt, k)
+            assert bytes(e) == bytes(oracle.msm(xyzt, k)[0])
+            e2, _, st2 = c.msm(raw, k)
+            keep = o_st == 0
+            assert (st2 == o_st).all()
+            assert bytes(e2) == bytes(oracle.msm(xyzt[keep], k[keep])[0])
+        c.close()
