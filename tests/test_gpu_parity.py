@@ -469,3 +469,17 @@ def test_multi_device_context_slicing(oracle):
             assert (st2 == o_st).all()
             assert bytes(e2) == bytes(oracle.msm(xyzt[keep], k[keep])[0])
         c.close()
+
+
+def test_field_regression_seeds_gpu(ctx, oracle, kats):
+    """The same proptest regression seeds through the kernels."""
+    rs = kats["regression_seeds"]
+    z = np.zeros((3, rs["fq_wide_zero_len"]), np.uint8)
+    assert not ctx.fq_from_wide_bytes(z).any()
+    ks = np.zeros((2, 32), np.uint8)
+    ks[1] = np.frombuffer((1 << rs["fr_values_pow2"][0]).to_bytes(32, "little"), np.uint8)
+    out = ctx.scalar_mul_base(ks)
+    assert (out == oracle.scalar_mul_base(ks)).all() and not out[0].any()
+    g = np.tile(frombytes([kats["generator"]["hex"]]), (2, 1))
+    out2, st = ctx.scalar_mul_var(g, ks)
+    assert (out2 == out).all() and not st.any()

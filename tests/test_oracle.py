@@ -290,3 +290,18 @@ def test_oracle_sanitizer_selftest():
     subprocess.check_call(["make", "-C", odir, "selftest"], stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(odir, "selftest")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ORACLE_SELFTEST_OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_field_regression_seeds(oracle, kats):
+    """proptest-regressions/fields/{fq,fr}/arkworks.txt: 48 zero bytes reduce to 0; Fr = 2^192 and
+    Fr = 0 survive the byte round trip and act correctly as scalars."""
+    rs = kats["regression_seeds"]
+    z = np.zeros((1, rs["fq_wide_zero_len"]), np.uint8)
+    assert not oracle.fq_from_wide_bytes(z, rs["fq_wide_zero_len"]).any()
+    for e in rs["fr_values_pow2"]:
+        kb = np.frombuffer((1 << e).to_bytes(32, "little"), np.uint8)
+        assert bytes(oracle.fr_from_bytes_mod_order(kb)[0]) == (1 << e).to_bytes(32, "little")
+        assert oracle.fr_from_bytes_checked(kb)[0] == 0
+        enc = oracle.scalar_mul_base(kb)
+        assert bytes(enc[0]) == m.compress(m.scalar_mul(m.GENERATOR, 1 << e))
+    assert not oracle.scalar_mul_base(np.zeros((1, 32), np.uint8)).any()      # 0 * B = identity
