@@ -306,6 +306,50 @@ __global__ void __launch_bounds__(BLOCK) k_to_affine(const uint64_t* xyzt, size_
   }
 }
 
+// Fq operations on Montgomery-256 records (src/fields/fq/u64/wrapper.rs:99-132)
+__global__ void __launch_bounds__(BLOCK) k_fq_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out,
+                                                 uint8_t* status) {
+  const uint8_t* ab = reinterpret_cast<const uint8_t*>(a);
+  const uint8_t* bb = reinterpret_cast<const uint8_t*>(b);
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(ab, i, w);
+    const fe x = fe_from_mont256_words(w);
+    fe y = fe_zero(), r;
+    if (op <= D377_FQ_MUL) { load32(bb, i, w); y = fe_from_mont256_words(w); }
+    uint32_t st = 0;
+    switch (op) {
+      case D377_FQ_ADD: r = fe_carry(fe_add(x, y)); break;
+      case D377_FQ_SUB: r = fe_sub(x, y); break;
+      case D377_FQ_MUL: r = fe_mul(x, y); break;
+      case D377_FQ_SQUARE: r = fe_sqr(x); break;
+      case D377_FQ_NEG: r = fe_neg(x); break;
+      default: r = fe_invert(x); st = fe_is_zero(x) ? 1u : 0u; break;     // 0^(q-2) = 0: zero record, status 1
+    }
+    fe_to_mont256_words(r, w);
+    store32(reinterpret_cast<uint8_t*>(out), i, w);
+    if (status) status[i] = (uint8_t)st;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_fq_from_bytes_checked(const uint8_t* in, size_t n, uint64_t* out, uint8_t* status) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(in, i, w);
+    const bool bad = words_geq(w, FQ_MODULUS_W_LIT);
+    const fe x = fe_from_words_mod_order(w);
+    fe_to_mont256_words(x, w);
+    if (bad) store32_zero(reinterpret_cast<uint8_t*>(out), i); else store32(reinterpret_cast<uint8_t*>(out), i, w);
+    status[i] = bad ? 1 : 0;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_fq_to_bytes(const uint64_t* a, size_t n, uint8_t* out) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(reinterpret_cast<const uint8_t*>(a), i, w);
+    fe_to_bytes_words(fe_from_mont256_words(w), w);
+    store32(out, i, w);
+  }
+}
 __global__ void __launch_bounds__(BLOCK) k_neg(const uint64_t* p, size_t n, uint64_t* out) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
     store_ge_mont256(out, i, ge_neg(load_ge_mont256(p, i)));
@@ -382,9 +426,10 @@ void free_device(DeviceState& d) {
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
-enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE, OP_NEG, OP_IS_IDENTITY };
+enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE, OP_NEG, OP_IS_IDENTITY, OP_FQ_BIN, OP_FQ_UN, OP_FQ_CHECKED, OP_FQ_TO_BYTES };
 
 // launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null)
+thread_local int g_fq_op = 0;   // the D377_FQ_* selector of the OP_FQ_BIN / OP_FQ_UN launch in progress
 int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
   if (n == 0) return D377_OK;
   const SqrtTables T = d.tables();
@@ -441,6 +486,17 @@ int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in
     case OP_AFFINE:
       hipLaunchKernelGGL(k_to_affine, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
+    case OP_FQ_BIN:
+    case OP_FQ_UN:
+      hipLaunchKernelGGL(k_fq_op, dim3(g), dim3(BLOCK), 0, s, g_fq_op, (const uint64_t*)in0, (const uint64_t*)in1, n,
+                         (uint64_t*)out0, (uint8_t*)out1);
+      break;
+    case OP_FQ_CHECKED:
+      hipLaunchKernelGGL(k_fq_from_bytes_checked, dim3(g), dim3(BLOCK), 0, s, (const uint8_t*)in0, n, (uint64_t*)out0, (uint8_t*)out1);
+      break;
+    case OP_FQ_TO_BYTES:
+      hipLaunchKernelGGL(k_fq_to_bytes, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint8_t*)out0);
+      break;
     case OP_NEG:
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
@@ -471,6 +527,10 @@ OpShape shape_of(Op op) {
     case OP_ENCODE_WIDE48: return {48, 0, 32, 0};
     case OP_ENCODE_WIDE64: return {64, 0, 32, 0};
     case OP_AFFINE: return {128, 0, 64, 0};
+    case OP_FQ_BIN: return {32, 32, 32, 1};
+    case OP_FQ_UN: return {32, 0, 32, 1};
+    case OP_FQ_CHECKED: return {32, 0, 32, 1};
+    case OP_FQ_TO_BYTES: return {32, 0, 32, 0};
     case OP_NEG: return {128, 0, 128, 0};
     case OP_IS_IDENTITY: return {128, 0, 1, 0};
   }
@@ -624,6 +684,33 @@ int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xy
   return run_dev(ctx, dev, stream, OP_EQ, p_xyzt, q_xyzt, n, equal, nullptr);
 }
 
+int d377_batch_fq_op(d377_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* status) {
+  if (op < D377_FQ_ADD || op > D377_FQ_INVERSE) return fail(D377_ERR_ARG, "%s", "unknown Fq operation");
+  std::vector<uint8_t> scratch;
+  if (!status) { scratch.resize(n ? n : 1); status = scratch.data(); }
+  g_fq_op = op;
+  return run_host(ctx, op <= D377_FQ_MUL ? OP_FQ_BIN : OP_FQ_UN, a, op <= D377_FQ_MUL ? b : nullptr, n, out, status);
+}
+int d377_batch_fq_op_dev(d377_ctx* ctx, int dev, void* stream, int op, const uint64_t* a, const uint64_t* b, size_t n,
+                         uint64_t* out, uint8_t* status) {
+  if (op < D377_FQ_ADD || op > D377_FQ_INVERSE) return fail(D377_ERR_ARG, "%s", "unknown Fq operation");
+  if (op == D377_FQ_INVERSE && !status) return fail(D377_ERR_ARG, "%s", "INVERSE needs a status buffer");
+  g_fq_op = op;
+  // status is optional on the device path except for INVERSE; the kernel skips a null pointer
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  if (n && (!a || (op <= D377_FQ_MUL && !b) || !out)) return fail(D377_ERR_ARG, "%s", "null buffer");
+  if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
+  DeviceState& d = ctx->devs[(size_t)dev];
+  HIP_TRY(hipSetDevice(d.id));
+  return launch(d, (hipStream_t)stream, op <= D377_FQ_MUL ? OP_FQ_BIN : OP_FQ_UN, a, b, n, out, status);
+}
+int d377_batch_fq_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint64_t* out, uint8_t* status) {
+  return run_host(ctx, OP_FQ_CHECKED, bytes32, nullptr, n, out, status);
+}
+int d377_batch_fq_to_bytes(d377_ctx* ctx, const uint64_t* a, size_t n, uint8_t* bytes32) {
+  return run_host(ctx, OP_FQ_TO_BYTES, a, nullptr, n, bytes32, nullptr);
+}
 int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
   return run_host(ctx, OP_NEG, p_xyzt, nullptr, n, out_xyzt, nullptr);
 }

@@ -145,6 +145,33 @@ class Context:
         return out
 
 
+    # -- Fq on in-memory elements (4 Montgomery u64 limbs) ------------------------------------------
+    FQ_OPS = {"add": 0, "sub": 1, "mul": 2, "square": 3, "neg": 4, "inverse": 5}
+
+    def fq_op(self, op, a, b=None):
+        """Fq add/sub/mul (binary) and square/neg/inverse (unary) on [n, 4] u64 Montgomery records
+        (src/fields/fq/u64/wrapper.rs:99-132) -> (out [n, 4], status [n]); status 1 only for inverse(0)."""
+        code = self.FQ_OPS[op]
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        n = a.shape[0]
+        out = np.empty((n, 4), np.uint64)
+        st = np.zeros(max(n, 1), np.uint8)
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        bb = None
+        if code <= 2:
+            bb = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        _native.check(self._lib.d377_batch_fq_op(self._h, code, p(a), p(bb) if bb is not None else None,
+                                                 ctypes.c_size_t(n), p(out), p(st)))
+        return out, st[:n]
+
+    def fq_from_bytes_checked(self, bytes32):
+        """Fq::from_bytes_checked (src/fields/fq.rs:108-115) -> ([n, 4] u64, status[n])."""
+        return self._run("d377_batch_fq_from_bytes_checked", [bytes32], [((4,), np.uint64), ((), np.uint8)], _rows(bytes32))
+
+    def fq_to_bytes(self, a):
+        """Fq::to_bytes_le on [n, 4] u64 Montgomery records -> [n, 32] u8."""
+        return self._run("d377_batch_fq_to_bytes", [a], [((32,), np.uint8)], _rows(a))[0]
+
     # -- wide byte strings and affine normalisation -----------------------------------------------
     def _wide(self, name, data):
         n, length = int(data.shape[0]), int(data.shape[1])

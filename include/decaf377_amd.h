@@ -110,6 +110,23 @@ int d377_msm(d377_ctx* ctx, const uint64_t* xyzt, const uint8_t* scalar32, size_
 int d377_msm_encoded(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t n, uint8_t* enc32_out,
                      uint64_t* xyzt_out, uint8_t* status);
 
+/* Fq field operations on in-memory elements (4 Montgomery u64 limbs, R = 2^256, fully reduced), the
+ * unit everything above is built from             src/fields/fq/u64/wrapper.rs:99-132, fq/ops.rs
+ * op: D377_FQ_ADD / SUB / MUL (binary, b != NULL) and D377_FQ_SQUARE / NEG / INVERSE (unary, b NULL).
+ * INVERSE mirrors `Fq::inverse() -> Option<Fq>`: status[i] = 1 and a zero record for a zero input
+ * (status may be NULL for the other ops).  d377_batch_fq_from_bytes_checked mirrors
+ * Fq::from_bytes_checked (src/fields/fq.rs:108-115): status 1 for non-canonical strings. */
+#define D377_FQ_ADD 0
+#define D377_FQ_SUB 1
+#define D377_FQ_MUL 2
+#define D377_FQ_SQUARE 3
+#define D377_FQ_NEG 4
+#define D377_FQ_INVERSE 5
+int d377_batch_fq_op(d377_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out,
+                     uint8_t* status);
+int d377_batch_fq_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint64_t* out, uint8_t* status);
+int d377_batch_fq_to_bytes(d377_ctx* ctx, const uint64_t* a, size_t n, uint8_t* bytes32);
+
 /* -Element (x, t negated), Element::is_identity (x == 0), and the constants Element::IDENTITY /
  * Element::GENERATOR as one 16 x u64 record each      src/min_curve/element.rs:324-332, 113-117, 53-81 */
 int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);
@@ -142,6 +159,8 @@ int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* 
 int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt,
                       size_t n, uint8_t* equal);
 
+int d377_batch_fq_op_dev(d377_ctx* ctx, int dev, void* stream, int op, const uint64_t* a, const uint64_t* b, size_t n,
+                         uint64_t* out, uint8_t* status);
 int d377_batch_neg_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);
 int d377_batch_is_identity_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n,
                                uint8_t* is_identity);

@@ -483,3 +483,44 @@ def test_field_regression_seeds_gpu(ctx, oracle, kats):
     g = np.tile(frombytes([kats["generator"]["hex"]]), (2, 1))
     out2, st = ctx.scalar_mul_var(g, ks)
     assert (out2 == out).all() and not st.any()
+
+
+def test_fq_field_ops(ctx, oracle, kats):
+    """SURVEY 8a rows a1-a3 through the C ABI: Fq add/sub/mul/square/neg/inverse and byte I/O on the
+    reference's in-memory form, against the oracle and big-integer arithmetic; the reference's own
+    examples (src/fields/fq/arkworks.rs:603-673)."""
+    rng = np.random.default_rng(680)
+    n = 4096
+    raw = rng.integers(0, 256, (2, n, 32), dtype=np.uint8)
+    for j, e in enumerate([0, 1, Q - 1, Q, Q + 1, (1 << 256) - 1, 2, 1 << 192]):
+        raw[0, j] = ibytes(e)
+        raw[1, n - 1 - j] = ibytes(e)
+    a = oracle.fq_from_bytes_mod_order(raw[0])
+    b = oracle.fq_from_bytes_mod_order(raw[1])
+    ai = [int.from_bytes(bytes(x), "little") % Q for x in raw[0]]
+    bi = [int.from_bytes(bytes(x), "little") % Q for x in raw[1]]
+    val = lambda recs: [int.from_bytes(bytes(x), "little") for x in ctx.fq_to_bytes(recs)]
+    assert val(a) == ai
+    out, _ = ctx.fq_op("mul", a, b)
+    assert (out == oracle.fq_mul_mont(a, b)).all()
+    out, _ = ctx.fq_op("square", a)
+    assert (out == oracle.fq_mul_mont(a, a)).all()
+    assert val(ctx.fq_op("add", a, b)[0]) == [(x + y) % Q for x, y in zip(ai, bi)]
+    assert val(ctx.fq_op("sub", a, b)[0]) == [(x - y) % Q for x, y in zip(ai, bi)]
+    assert val(ctx.fq_op("neg", a)[0]) == [(-x) % Q for x in ai]
+    inv, st = ctx.fq_op("inverse", a)
+    assert list(st) == [1 if x == 0 else 0 for x in ai]
+    assert val(inv) == [pow(x, -1, Q) if x else 0 for x in ai]
+    prod, _ = ctx.fq_op("mul", a, inv)
+    assert val(prod) == [1 if x else 0 for x in ai]
+    # from_bytes_checked: canonical strings only (src/fields/fq.rs:108-115, :149-152)
+    recs, st = ctx.fq_from_bytes_checked(raw[0])
+    want_bad = [int.from_bytes(bytes(x), "little") >= Q for x in raw[0]]
+    assert list(st) == [int(v) for v in want_bad]
+    o_recs, o_st = oracle.fq_from_bytes_checked(raw[0])
+    assert (st == o_st).all() and (recs == o_recs).all()
+    # (-1)^2 == 1, (p + 1) reduces to 1
+    m1 = oracle.fq_from_bytes_mod_order(ibytes(Q - 1).reshape(1, 32))
+    assert val(ctx.fq_op("square", m1)[0]) == [1]
+    p1 = np.array(kats["fq_examples"]["p_plus_1_bytes"], dtype=np.uint8).reshape(1, 32)
+    assert val(oracle.fq_from_bytes_mod_order(p1)) == [1]
