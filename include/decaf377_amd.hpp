@@ -182,6 +182,27 @@ class Engine {
     check(d377_batch_eq(ctx_, u64(p), u64(q), p.size(), e.data()));
     return std::vector<bool>(e.begin(), e.end());
   }
+  /// -Element and Element::is_identity (src/min_curve/element.rs:324-332, 113-117)
+  std::vector<Element> neg(const std::vector<Element>& p) {
+    std::vector<Element> out(p.size());
+    check(d377_batch_neg(ctx_, u64(p), p.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  std::vector<bool> is_identity(const std::vector<Element>& p) {
+    std::vector<uint8_t> e(p.size());
+    check(d377_batch_is_identity(ctx_, u64(p), p.size(), e.data()));
+    return std::vector<bool>(e.begin(), e.end());
+  }
+  /// Element::vartime_multiscalar_mul(scalars, points) (src/ark_curve/element/projective.rs:99-117)
+  Element vartime_multiscalar_mul(const std::vector<Fr>& scalars, const std::vector<Element>& points) {
+    if (scalars.size() != points.size()) throw std::invalid_argument("length mismatch");
+    Element out;
+    Encoding enc;
+    check(d377_msm(ctx_, u64(points), u8(scalars), points.size(), enc.b.data(), out.xyzt.data()));
+    return out;
+  }
+  static Element identity() { Element e; d377_identity(e.xyzt.data()); return e; }     // Element::IDENTITY
+  static Element generator() { Element e; d377_generator(e.xyzt.data()); return e; }   // Element::GENERATOR
   d377_ctx* raw() { return ctx_; }
 
  private:

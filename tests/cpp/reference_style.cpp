@@ -126,6 +126,30 @@ static void scalar_mul_properties(Engine& e) {
   for (size_t i = 0; i < n; ++i) CHECK(h[i] == hs[i]);
 }
 
+// tests/operations.rs:44-60: (a*P) + (b*Q) + (c*R) == vartime_multiscalar_mul([a,b,c], [P,Q,R])
+static void vartime_multiscalar_mul_matches_scalar_mul(Engine& e) {
+  std::mt19937_64 rng(668);
+  for (int round = 0; round < 8; ++round) {
+    std::vector<Fq> r(3); std::vector<Fr> k(3);
+    for (auto& x : r) for (auto& b : x.b) b = (uint8_t)rng();
+    for (auto& x : k) for (auto& b : x.b) b = (uint8_t)rng();
+    auto enc = e.encode_to_curve(r);
+    auto dec = e.vartime_decompress(enc);
+    std::vector<Element> pts = {dec[0].unwrap(), dec[1].unwrap(), dec[2].unwrap()};
+    auto prods = e.scalar_mul(enc, k);
+    auto pd = e.vartime_decompress({prods[0].unwrap(), prods[1].unwrap(), prods[2].unwrap()});
+    auto sum = e.add(e.add({pd[0].unwrap()}, {pd[1].unwrap()}), {pd[2].unwrap()});
+    Element msm = e.vartime_multiscalar_mul(k, pts);
+    CHECK(e.eq(sum, {msm})[0]);
+  }
+  // P + (-P) is the identity; GENERATOR is the decoding of [8, 0, ...]
+  auto g = Engine::generator();
+  CHECK(e.is_identity(e.add({g}, e.neg({g})))[0]);
+  CHECK(e.is_identity({Engine::identity()})[0] && !e.is_identity({g})[0]);
+  std::array<uint8_t, 32> eight{}; eight[0] = 8;
+  CHECK(e.vartime_compress({g})[0] == Encoding(eight));
+}
+
 // src/ark_curve/invsqrt.rs:182-211
 static void sqrt_ratio_edge_cases(Engine& e) {
   auto r = e.sqrt_ratio_zeta({Fq::from_u64(0), Fq::from_u64(1)}, {Fq::from_u64(1), Fq::from_u64(0)});
@@ -140,6 +164,7 @@ int main() {
   test_encoding_matches_sage_encoding(e);
   round_trips_if_successful(e);
   scalar_mul_properties(e);
+  vartime_multiscalar_mul_matches_scalar_mul(e);
   sqrt_ratio_edge_cases(e);
   bool threw = false;
   try { Engine bad({99}); } catch (const DeviceError&) { threw = true; }
