@@ -253,6 +253,18 @@ def main():
             "matches_gpu_output": same,
         }
         assert same, "GPU output differs from the oracle on the cpu_baseline sample"
+        # BASELINE.json configs[0] (the reference's own CPU-runnable case, shape of benches/sqrt.rs):
+        # 2^16 Fq::sqrt_ratio_zeta on the CPU restatement, one thread, plus the GPU on the same pairs
+        nsq = 1 << 16
+        num_h, den_h = r0[:nsq].cpu().numpy(), scalars[:nsq].cpu().numpy()
+        t0 = time.perf_counter()
+        o_root, o_ws, _ = orc.run_threads("sqrt_ratio_zeta", num_h, den_h, 1)
+        dts = time.perf_counter() - t0
+        g_root, g_ws = ctx.sqrt_ratio_zeta(r0[:nsq], scalars[:nsq])
+        ok = bool((g_root.cpu().numpy() == o_root).all() and (g_ws.cpu().numpy() == o_ws).all())
+        assert ok, "GPU sqrt_ratio_zeta differs from the oracle"
+        line["cpu_baseline"]["config0_sqrt_ratio_zeta_2^16"] = {
+            "cpu_ns_per_call_1_thread": dts / nsq * 1e9, "cpu_per_sec_1_thread": nsq / dts, "matches_gpu_output": ok}
 
     if rank == 0:
         print(json.dumps(line))
