@@ -439,6 +439,25 @@ D377_HD ge ge_double_fast(const ge& p, bool with_t) {
   return r;
 }
 
+// Doubling for latency-bound single-lane tails (MSM Horner: 252 dependent doublings on one lane):
+// same formulas as ge_double_fast, but the four squarings and the four products are issued as
+// interleaved pairs (fe_sqr2 / fe_mul2), which is what a lone wave needs to keep the MAC pipe fed
+// (a lone wave: 823 vs 1217 cycles per squaring, 1142 vs 1439 per multiplication).
+D377_HD ge ge_double_latency(const ge& p) {
+  fe a, b, zz, s_;
+  fe_sqr2(p.x, p.y, a, b);
+  fe_sqr2(p.z, fe_add(p.x, p.y), zz, s_);
+  fe c = fe_dbl(zz);
+  fe h = fe_add(a, b);
+  fe e = fe_sub(h, s_);
+  fe g = fe_sub(a, b);
+  fe f = fe_add(g, c);
+  ge r;
+  fe_mul2(e, f, g, h, r.x, r.y);
+  fe_mul2(f, g, e, h, r.z, r.t);
+  return r;
+}
+
 D377_HD gec ge_to_cached(const ge& p) {
   gec c;
   c.ypx = fe_add(p.y, p.x);               // lazy

@@ -270,7 +270,7 @@ k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, 
 #pragma unroll 1
   for (int w = W - 2; w >= 0; --w) {
 #pragma unroll 1
-    for (int j = 0; j < c; ++j) r = ge_double(r);
+    for (int j = 0; j < c; ++j) r = ge_double_latency(r);
     r = ge_add(r, pt_load_ext(sums + (size_t)w * PT_WORDS));
   }
   if (xyzt_out) store_ge_mont256(xyzt_out, 0, r);

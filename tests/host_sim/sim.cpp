@@ -130,6 +130,15 @@ static ge ge_load256(const uint32_t* o) {
   ge g; g.x = fe_from_mont256_words(o); g.y = fe_from_mont256_words(o + 8); g.z = fe_from_mont256_words(o + 16); g.t = fe_from_mont256_words(o + 24);
   return g;
 }
+// ge_double (reference form), ge_double_fast and ge_double_latency on Montgomery-256 records
+void sim_double_variants(const uint32_t* xyzt, size_t n, uint32_t* ref, uint32_t* fast, uint32_t* lat) {
+  for (size_t i = 0; i < n; ++i) {
+    ge g = ge_load256(xyzt + 32 * i);
+    ge_store256(ge_double(g), ref + 32 * i);
+    ge_store256(ge_double_fast(g, true), fast + 32 * i);
+    ge_store256(ge_double_latency(g), lat + 32 * i);
+  }
+}
 void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
     RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);

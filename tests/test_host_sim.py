@@ -227,3 +227,19 @@ def test_limb_bounds_adversarial(sim):
     out = np.zeros((9, 9), np.uint32)
     sim.sim_raw_canon(_p(reps), n_(9), _p(out))
     assert not out.any()
+
+
+def test_doubling_variants_agree(sim, oracle):
+    """ge_double (reference formulas), ge_double_fast (sign-folded) and ge_double_latency (paired
+    squarings / products) give the same group element; the first equals the oracle limb for limb."""
+    rng = np.random.default_rng(16)
+    n = 512
+    P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    ref = np.zeros((n, 16), np.uint64)
+    fast = np.zeros((n, 16), np.uint64)
+    lat = np.zeros((n, 16), np.uint64)
+    sim.sim_double_variants(_p(P), n_(n), _p(ref), _p(fast), _p(lat))
+    assert (ref == oracle.double_xyzt(P)).all()
+    assert oracle.eq_xyzt(fast, ref).all() and oracle.eq_xyzt(lat, ref).all()
+    assert (oracle.compress(fast) == oracle.compress(ref)).all()
+    assert (lat == fast).all()          # same formulas, only the issue order differs
