@@ -1,7 +1,7 @@
 // curve.hpp -- per-lane decaf377 operations on top of fq29.hpp.
 //
 // Each function is the work ONE lane does for ONE group element; the kernels in
-// kernels.hip only add the batch indexing and the 32-byte record loads/stores.
+// d377.hip / msm.hip only add the batch indexing and the 32-byte record loads/stores.
 // Reference semantics (file:line relative to the reference crate):
 //   sqrt_ratio_zeta      src/ark_curve/invsqrt.rs:75-166 (Sarkar tables, same root)
 //   decompress           src/ark_curve/encoding.rs:32-83
