@@ -214,13 +214,20 @@ def main():
             ("sqrt_ratio_zeta", lambda: ctx.sqrt_ratio_zeta(r0[:ne], scalars[:ne], outs=[o1, s1])),
         ]:
             ker, _ = time_op(torch, fn, 3, 1)
+            ker_all = ker
+            if world > 1:                       # whole-job rate: slowest rank's kernel time
+                tt = torch.tensor([ker], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ker_all = float(tt.item())
             extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3),
+                           "per_sec_all_gpus": ne * world / (ker_all * 1e-3),
                            "algo_GBps": ALGO_BYTES[name] * ne / (ker * 1e-3) / 1e9}
         # vartime_multiscalar_mul (Pippenger MSM), 2^20 Elements -> one Encoding
         pm, _ = ctx.decompress(enc1)
         ker, _ = time_op(torch, lambda: ctx.msm(pm, scalars[:ne]), 3, 1)
         extra["msm_2^20"] = {"n": ne, "ms": ker, "per_sec": ne / (ker * 1e-3)}
-        extra["encodes_per_sec"] = extra["roundtrip"]["per_sec"]
+        extra["encodes_per_sec"] = extra["roundtrip"]["per_sec_all_gpus"]          # whole job, all GPUs
+        extra["elligator_encodes_per_sec"] = extra["encode_to_curve"]["per_sec_all_gpus"]
         line["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -235,6 +242,7 @@ def main():
         t0 = time.perf_counter()
         orc.run_threads("scalar_mul_var", p_h[:pilot], k_h[:pilot], 1)
         per_thread = pilot / (time.perf_counter() - t0)
+        one_thread_rate = per_thread
         ns = int(min(n, max(4096, per_thread * cores * 12.0)))
         p_h, k_h = p_h[:ns], k_h[:ns]
         t0 = time.perf_counter()
@@ -251,6 +259,7 @@ def main():
                       "Montgomery), gcc -O3 -march=x86-64-v3" % (ns, n, used),
             "seconds": dt,
             "matches_gpu_output": same,
+            "value_1_thread": one_thread_rate,
         }
         assert same, "GPU output differs from the oracle on the cpu_baseline sample"
         # BASELINE.json configs[0] (the reference's own CPU-runnable case, shape of benches/sqrt.rs):
