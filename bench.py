@@ -203,7 +203,7 @@ def main():
 
     if not args.no_extra:
         extra = {}
-        ne = 1 << 20
+        ne = min(1 << 20, n)
         enc1 = points[:ne]
         o1 = torch.empty((ne, 32), dtype=torch.uint8, device=dev)
         s1 = torch.empty((ne,), dtype=torch.uint8, device=dev)
