@@ -393,6 +393,11 @@ int init_device(DeviceState& d) {
     return fail(D377_ERR_NO_DEVICE, "device is %s, this library is built for gfx950 only", prop.gcnArchName);
   d.cus = prop.multiProcessorCount;
   HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&d.ev_in[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.ev_done[i], hipEventDisableTiming));
+  }
   HIP_TRY(hipMalloc(&d.gtab, (size_t)6 * 256 * GT_STRIDE * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&d.s_lookup, (size_t)1 << S_HASH_BITS));
   HIP_TRY(hipMalloc(&d.fbase, (size_t)FB_WINDOWS * FB_ENTRIES * FBW_ENTRY_WORDS * sizeof(uint32_t)));
@@ -421,7 +426,12 @@ void free_device(DeviceState& d) {
   (void)hipSetDevice(d.id);
   if (d.stream) (void)hipStreamSynchronize(d.stream);
   (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch);
-  for (int i = 0; i < 4; ++i) (void)hipFree(d.buf[i]);
+  for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); }
+  for (int i = 0; i < 2; ++i) {
+    if (d.ev_in[i]) (void)hipEventDestroy(d.ev_in[i]);
+    if (d.ev_done[i]) (void)hipEventDestroy(d.ev_done[i]);
+  }
+  if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
   (void)hipFree(d.msm.mem);
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
@@ -537,6 +547,53 @@ OpShape shape_of(Op op) {
   return {0, 0, 0, 0};
 }
 
+// Large batches on a single device are pipelined in chunks of 2^18 records: while chunk k runs on
+// the compute stream, chunk k+1's inputs are copied in and chunk k-1's outputs are copied out on
+// the copy stream (double-buffered staging), so PCIe time hides under the kernels.
+constexpr size_t PIPE_CHUNK = (size_t)1 << 18;
+
+int run_host_pipelined(DeviceState& d, Op op, const OpShape& sh, const void* in0, const void* in1, size_t n, void* out0,
+                       void* out1) {
+  HIP_TRY(hipSetDevice(d.id));
+  int rc;
+  if ((rc = ensure(d, 0, PIPE_CHUNK * sh.in0))) return rc;
+  if (sh.in1 && (rc = ensure(d, 1, PIPE_CHUNK * sh.in1))) return rc;
+  if ((rc = ensure(d, 2, PIPE_CHUNK * sh.out0))) return rc;
+  if (sh.out1 && (rc = ensure(d, 3, PIPE_CHUNK * sh.out1))) return rc;
+  if ((rc = ensure2(d, 0, PIPE_CHUNK * sh.in0))) return rc;
+  if (sh.in1 && (rc = ensure2(d, 1, PIPE_CHUNK * sh.in1))) return rc;
+  if ((rc = ensure2(d, 2, PIPE_CHUNK * sh.out0))) return rc;
+  if (sh.out1 && (rc = ensure2(d, 3, PIPE_CHUNK * sh.out1))) return rc;
+  const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+  auto bufs = [&](size_t k) -> uint8_t** { return (k & 1) ? d.buf2 : d.buf; };
+  auto drain = [&](size_t k) -> int {          // outputs of chunk k -> host (waits for its kernel)
+    const size_t lo = k * PIPE_CHUNK, cnt = (lo + PIPE_CHUNK <= n) ? PIPE_CHUNK : n - lo;
+    uint8_t** b = bufs(k);
+    HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.ev_done[k & 1], 0));
+    HIP_TRY(hipMemcpyAsync((uint8_t*)out0 + lo * sh.out0, b[2], cnt * sh.out0, hipMemcpyDeviceToHost, d.copy_stream));
+    if (sh.out1)
+      HIP_TRY(hipMemcpyAsync((uint8_t*)out1 + lo * sh.out1, b[3], cnt * sh.out1, hipMemcpyDeviceToHost, d.copy_stream));
+    HIP_TRY(hipStreamSynchronize(d.copy_stream));
+    return D377_OK;
+  };
+  for (size_t k = 0; k < nchunks; ++k) {
+    const size_t lo = k * PIPE_CHUNK, cnt = (lo + PIPE_CHUNK <= n) ? PIPE_CHUNK : n - lo;
+    uint8_t** b = bufs(k);
+    // this buffer set was last used by chunk k-2, which has been drained (host-synchronised) already
+    HIP_TRY(hipMemcpyAsync(b[0], (const uint8_t*)in0 + lo * sh.in0, cnt * sh.in0, hipMemcpyHostToDevice, d.copy_stream));
+    if (sh.in1)
+      HIP_TRY(hipMemcpyAsync(b[1], (const uint8_t*)in1 + lo * sh.in1, cnt * sh.in1, hipMemcpyHostToDevice, d.copy_stream));
+    HIP_TRY(hipEventRecord(d.ev_in[k & 1], d.copy_stream));
+    HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_in[k & 1], 0));
+    if ((rc = launch(d, d.stream, op, b[0], b[1], cnt, b[2], b[3]))) return rc;
+    HIP_TRY(hipEventRecord(d.ev_done[k & 1], d.stream));
+    if (k >= 1 && (rc = drain(k - 1))) return rc;
+  }
+  if ((rc = drain(nchunks - 1))) return rc;
+  HIP_TRY(hipStreamSynchronize(d.stream));
+  return D377_OK;
+}
+
 // host-pointer path: contiguous slices over the context's devices, async per device, then join
 int run_host(d377_ctx* ctx, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
   if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
@@ -545,6 +602,7 @@ int run_host(d377_ctx* ctx, Op op, const void* in0, const void* in1, size_t n, v
   if (n == 0) return D377_OK;
   std::lock_guard<std::mutex> lock(ctx->mu);
   const size_t nd = ctx->devs.size();
+  if (nd == 1 && n >= 2 * PIPE_CHUNK) return run_host_pipelined(ctx->devs[0], op, sh, in0, in1, n, out0, out1);
   const size_t per = (n + nd - 1) / nd;
   int rc = D377_OK;
   for (size_t k = 0; k < nd; ++k) {

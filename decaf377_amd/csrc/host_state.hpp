@@ -37,10 +37,15 @@ struct DeviceState {
   uint32_t* fbase = nullptr;
   uint32_t* vb_scratch = nullptr;
   int vb_blocks = 0;
-  hipStream_t stream = nullptr;          // used by the host-pointer entry points
-  // grow-only staging buffers for the host-pointer entry points
+  hipStream_t stream = nullptr;          // compute stream of the host-pointer entry points
+  hipStream_t copy_stream = nullptr;     // PCIe copies of the pipelined host path
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+  // grow-only staging buffers for the host-pointer entry points (set 1 = second half of the
+  // double buffer used when a large batch is pipelined chunk by chunk)
   uint8_t* buf[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t cap[4] = {0, 0, 0, 0};
+  uint8_t* buf2[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap2[4] = {0, 0, 0, 0};
   MsmWorkspace msm;
   SqrtTables tables() const { return SqrtTables{gtab, s_lookup}; }
 };
@@ -52,6 +57,15 @@ inline int ensure(DeviceState& d, int slot, size_t bytes) {
   size_t want = bytes + bytes / 4 + 4096;
   HIP_TRY(hipMalloc(&d.buf[slot], want));
   d.cap[slot] = want;
+  return D377_OK;
+}
+
+inline int ensure2(DeviceState& d, int slot, size_t bytes) {
+  if (bytes <= d.cap2[slot]) return D377_OK;
+  if (d.buf2[slot]) HIP_TRY(hipFree(d.buf2[slot]));
+  d.buf2[slot] = nullptr; d.cap2[slot] = 0;
+  HIP_TRY(hipMalloc(&d.buf2[slot], bytes + 4096));
+  d.cap2[slot] = bytes + 4096;
   return D377_OK;
 }
 

@@ -524,3 +524,30 @@ def test_fq_field_ops(ctx, oracle, kats):
     assert val(ctx.fq_op("square", m1)[0]) == [1]
     p1 = np.array(kats["fq_examples"]["p_plus_1_bytes"], dtype=np.uint8).reshape(1, 32)
     assert val(oracle.fq_from_bytes_mod_order(p1)) == [1]
+
+
+def test_pipelined_host_path(ctx, oracle):
+    """Host-pointer calls with >= 2^19 records are pipelined in 2^18-record chunks (copy stream +
+    compute stream, double-buffered staging): results must equal the unpipelined device path,
+    including a ragged tail and per-element status."""
+    import torch
+    rng = np.random.default_rng(681)
+    n = (1 << 19) + (1 << 18) + 77                     # 3 full chunks boundary + ragged tail
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    enc = ctx.encode_to_curve(r0)                      # pipelined host path
+    dev = torch.device("cuda:0")
+    enc_d = ctx.encode_to_curve(torch.from_numpy(r0).to(dev))
+    assert (enc == enc_d.cpu().numpy()).all()
+    raw = enc.copy()
+    raw[::1000, 31] |= 0x40                            # invalid encodings scattered over all chunks
+    out, st = ctx.scalar_mul_var(raw, k)
+    out_d, st_d = ctx.scalar_mul_var(torch.from_numpy(raw).to(dev), torch.from_numpy(k).to(dev))
+    assert (out == out_d.cpu().numpy()).all() and (st == st_d.cpu().numpy()).all()
+    assert st.sum() == len(range(0, n, 1000))
+    idx = np.concatenate([np.arange(0, n, 30011), [n - 1, (1 << 18) - 1, 1 << 18, (1 << 19) - 1, 1 << 19]])
+    o_out, o_st = oracle.scalar_mul_var(raw[idx], k[idx])
+    assert (out[idx] == o_out).all() and (st[idx] == o_st).all()
+    xyzt, st = ctx.decompress(enc)                     # 128-byte output records through the pipeline
+    assert not st.any()
+    assert (ctx.compress(xyzt) == enc).all()
