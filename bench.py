@@ -98,6 +98,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     if args.same_device:
         local = 0
+    ndev = torch.cuda.device_count()
+    if ndev and local >= ndev:          # a launcher that masks devices per rank leaves one visible GPU
+        local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
