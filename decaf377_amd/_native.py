@@ -18,6 +18,7 @@ EXPORTS = [
     "d377_batch_scalar_mul_base", "d377_batch_scalar_mul_var", "d377_batch_encode_to_curve",
     "d377_batch_hash_to_curve", "d377_batch_add", "d377_batch_double", "d377_batch_eq",
     "d377_batch_add_dev", "d377_batch_double_dev", "d377_batch_eq_dev",
+    "d377_batch_fr_from_le_bytes_mod_order", "d377_batch_fr_from_bytes_checked",
     "d377_batch_fq_op", "d377_batch_fq_op_dev", "d377_batch_fq_from_bytes_checked", "d377_batch_fq_to_bytes",
     "d377_batch_neg", "d377_batch_is_identity", "d377_batch_neg_dev", "d377_batch_is_identity_dev",
     "d377_identity", "d377_generator",
@@ -93,6 +94,10 @@ def load():
     for name in ("d377_batch_fq_from_wide_bytes", "d377_batch_encode_to_curve_wide", "d377_batch_to_affine"):
         getattr(lib, name).restype = i32
         getattr(lib, name + "_dev").restype = i32
+    lib.d377_batch_fr_from_le_bytes_mod_order.argtypes = [vp, vp, sz, vp]
+    lib.d377_batch_fr_from_bytes_checked.argtypes = [vp, vp, sz, vp, vp]
+    lib.d377_batch_fr_from_le_bytes_mod_order.restype = i32
+    lib.d377_batch_fr_from_bytes_checked.restype = i32
     lib.d377_batch_fq_op.argtypes = [vp, i32, vp, vp, sz, vp, vp]
     lib.d377_batch_fq_op_dev.argtypes = [vp, i32, vp, i32, vp, vp, sz, vp, vp]
     lib.d377_batch_fq_from_bytes_checked.argtypes = [vp, vp, sz, vp, vp]

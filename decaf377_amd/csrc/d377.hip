@@ -350,6 +350,21 @@ __global__ void __launch_bounds__(BLOCK) k_fq_to_bytes(const uint64_t* a, size_t
     store32(out, i, w);
   }
 }
+// Fr::from_le_bytes_mod_order / from_bytes_checked on 32-byte strings (src/fields/fr.rs:82-107)
+__global__ void __launch_bounds__(BLOCK) k_fr_bytes(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t k[8];
+    load32(in, i, k);
+    if (status) {                                   // checked: copy through when canonical
+      const bool bad = words_geq(k, FR_ORDER_W_LIT);
+      status[i] = bad ? 1 : 0;
+      if (bad) store32_zero(out, i); else store32(out, i, k);
+    } else {
+      fr_reduce_words(k);
+      store32(out, i, k);
+    }
+  }
+}
 __global__ void __launch_bounds__(BLOCK) k_neg(const uint64_t* p, size_t n, uint64_t* out) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
     store_ge_mont256(out, i, ge_neg(load_ge_mont256(p, i)));
@@ -436,7 +451,7 @@ void free_device(DeviceState& d) {
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
-enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE, OP_NEG, OP_IS_IDENTITY, OP_FQ_BIN, OP_FQ_UN, OP_FQ_CHECKED, OP_FQ_TO_BYTES };
+enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE, OP_NEG, OP_IS_IDENTITY, OP_FQ_BIN, OP_FQ_UN, OP_FQ_CHECKED, OP_FQ_TO_BYTES, OP_FR_MOD, OP_FR_CHECKED };
 
 // launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null)
 thread_local int g_fq_op = 0;   // the D377_FQ_* selector of the OP_FQ_BIN / OP_FQ_UN launch in progress
@@ -507,6 +522,12 @@ int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in
     case OP_FQ_TO_BYTES:
       hipLaunchKernelGGL(k_fq_to_bytes, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint8_t*)out0);
       break;
+    case OP_FR_MOD:
+      hipLaunchKernelGGL(k_fr_bytes, dim3(g), dim3(BLOCK), 0, s, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)nullptr);
+      break;
+    case OP_FR_CHECKED:
+      hipLaunchKernelGGL(k_fr_bytes, dim3(g), dim3(BLOCK), 0, s, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
+      break;
     case OP_NEG:
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
@@ -541,6 +562,8 @@ OpShape shape_of(Op op) {
     case OP_FQ_UN: return {32, 0, 32, 1};
     case OP_FQ_CHECKED: return {32, 0, 32, 1};
     case OP_FQ_TO_BYTES: return {32, 0, 32, 0};
+    case OP_FR_MOD: return {32, 0, 32, 0};
+    case OP_FR_CHECKED: return {32, 0, 32, 1};
     case OP_NEG: return {128, 0, 128, 0};
     case OP_IS_IDENTITY: return {128, 0, 1, 0};
   }
@@ -768,6 +791,12 @@ int d377_batch_fq_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size
 }
 int d377_batch_fq_to_bytes(d377_ctx* ctx, const uint64_t* a, size_t n, uint8_t* bytes32) {
   return run_host(ctx, OP_FQ_TO_BYTES, a, nullptr, n, bytes32, nullptr);
+}
+int d377_batch_fr_from_le_bytes_mod_order(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out) {
+  return run_host(ctx, OP_FR_MOD, bytes32, nullptr, n, fr32_out, nullptr);
+}
+int d377_batch_fr_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out, uint8_t* status) {
+  return run_host(ctx, OP_FR_CHECKED, bytes32, nullptr, n, fr32_out, status);
 }
 int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
   return run_host(ctx, OP_NEG, p_xyzt, nullptr, n, out_xyzt, nullptr);

@@ -145,6 +145,25 @@ class Context:
         return out
 
 
+    # -- Fr byte handling ---------------------------------------------------------------------------
+    def fr_from_le_bytes_mod_order(self, bytes32):
+        """Fr::from_le_bytes_mod_order on [n, 32] byte strings -> canonical [n, 32] (src/fields/fr.rs:82-94)."""
+        b = np.ascontiguousarray(bytes32, dtype=np.uint8)
+        out = np.empty_like(b)
+        _native.check(self._lib.d377_batch_fr_from_le_bytes_mod_order(
+            self._h, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b.shape[0]), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def fr_from_bytes_checked(self, bytes32):
+        """Fr::from_bytes_checked (src/fields/fr.rs:100-107) -> ([n, 32], status[n])."""
+        b = np.ascontiguousarray(bytes32, dtype=np.uint8)
+        out = np.empty_like(b)
+        st = np.zeros(max(b.shape[0], 1), np.uint8)
+        _native.check(self._lib.d377_batch_fr_from_bytes_checked(
+            self._h, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b.shape[0]),
+            out.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p)))
+        return out, st[:b.shape[0]]
+
     # -- Fq on in-memory elements (4 Montgomery u64 limbs) ------------------------------------------
     FQ_OPS = {"add": 0, "sub": 1, "mul": 2, "square": 3, "neg": 4, "inverse": 5}
 

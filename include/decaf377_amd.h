@@ -127,6 +127,12 @@ int d377_batch_fq_op(d377_ctx* ctx, int op, const uint64_t* a, const uint64_t* b
 int d377_batch_fq_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint64_t* out, uint8_t* status);
 int d377_batch_fq_to_bytes(d377_ctx* ctx, const uint64_t* a, size_t n, uint8_t* bytes32);
 
+/* Fr byte handling (the only part of Fr the hot path uses)            src/fields/fr.rs:82-107
+ * from_le_bytes_mod_order: 32 raw bytes -> canonical 32-byte scalar (value mod r);
+ * from_bytes_checked: status 1 for strings >= r (the record is copied through when canonical). */
+int d377_batch_fr_from_le_bytes_mod_order(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out);
+int d377_batch_fr_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out, uint8_t* status);
+
 /* -Element (x, t negated), Element::is_identity (x == 0), and the constants Element::IDENTITY /
  * Element::GENERATOR as one 16 x u64 record each      src/min_curve/element.rs:324-332, 113-117, 53-81 */
 int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);

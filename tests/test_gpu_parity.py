@@ -551,3 +551,21 @@ def test_pipelined_host_path(ctx, oracle):
     xyzt, st = ctx.decompress(enc)                     # 128-byte output records through the pipeline
     assert not st.any()
     assert (ctx.compress(xyzt) == enc).all()
+
+
+def test_fr_bytes(ctx, oracle, kats):
+    """Fr byte handling (src/fields/fr.rs:82-107, examples fr/arkworks.rs:590-660)."""
+    rng = np.random.default_rng(682)
+    n = 5000
+    raw = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for j, e in enumerate([0, 1, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1, 32 * R_ORDER, 53 * R_ORDER + 5, 1 << 192]):
+        raw[j] = ibytes(e)
+    red = ctx.fr_from_le_bytes_mod_order(raw)
+    assert (red == oracle.fr_from_bytes_mod_order(raw)).all()
+    assert [int.from_bytes(bytes(x), "little") for x in red[:64]] == [int.from_bytes(bytes(x), "little") % R_ORDER for x in raw[:64]]
+    out, st = ctx.fr_from_bytes_checked(raw)
+    assert (st == oracle.fr_from_bytes_checked(raw)).all()
+    ok = st == 0
+    assert (out[ok] == raw[ok]).all() and not out[~ok].any()
+    p1 = np.array(kats["fr_examples"]["p_plus_1_bytes"], dtype=np.uint8).reshape(1, 32)
+    assert bytes(ctx.fr_from_le_bytes_mod_order(p1)[0]) == (1).to_bytes(32, "little")
