@@ -180,6 +180,46 @@ def sqrt_ratio_zeta(num, den):
     return (q0p & 1) == 0, res
 
 
+# --- sqrt_ratio_zeta, min_curve backend (constant-time Tonelli-Shanks) ------
+# src/fields/fq.rs:62-67: QUADRATIC_NON_RESIDUE_TO_TRACE (Montgomery limbs as written there) = 11^m
+QNR_TO_TRACE = from_mont_limbs(
+    [4340692304772210610, 11102725085307959083, 15540458298643990566, 944526744080888988]
+)
+
+
+def _our_sqrt(x):
+    """src/min_curve/invsqrt.rs:11-57 (c1 = 47, c3 = (m-1)/2, c5 = QNR_TO_TRACE)."""
+    z = pow(x, SQRT_M_MINUS_ONE_DIV_TWO, Q)
+    t = z * z % Q * x % Q
+    z = z * x % Q
+    b = t
+    c = QNR_TO_TRACE
+    for i in range(SQRT_N, 1, -1):
+        for _ in range(1, i - 1):
+            b = b * b % Q
+        if b != 1:
+            z = z * c % Q
+        c = c * c % Q
+        if b != 1:
+            t = t * c % Q
+        b = t
+    return z
+
+
+def sqrt_ratio_zeta_min_curve(num, den):
+    """src/min_curve/invsqrt.rs:73-95 (`non_arkworks_sqrt_ratio_zeta`)."""
+    num %= Q
+    den %= Q
+    if num == 0:
+        return True, 0
+    if den == 0:
+        return False, 0
+    x = num * pow(den, -1, Q) % Q
+    if pow(x, (Q - 1) // 2, Q) == 1:
+        return True, _our_sqrt(x)
+    return False, _our_sqrt(ZETA * x % Q)
+
+
 # --- group (extended twisted Edwards, a=-1, d=3021) ------------------------
 IDENTITY = (0, 1, 1, 0)  # src/min_curve/element.rs:53-58 (x, y, z, t)
 GENERATOR = (B_X, B_Y, 1, B_T)

@@ -12,12 +12,14 @@
  *     src/fields/fq/u64/wrapper.rs:45-132.
  *   - Fq::sqrt_ratio_zeta, Sarkar-2020 table method: src/ark_curve/invsqrt.rs:14-166,
  *     constants src/ark_curve/constants.rs:20-58.
+ *   - Fq::non_arkworks_sqrt_ratio_zeta, the min_curve backend's constant-time Tonelli-Shanks
+ *     (seed 11^m): src/min_curve/invsqrt.rs:11-95, src/fields/fq.rs:62-67.
  *   - Encoding::vartime_decompress: src/ark_curve/encoding.rs:32-83
  *     (== src/min_curve/element.rs:248-288).
  *   - Element::vartime_compress(_to_field): src/ark_curve/encoding.rs:91-128.
  *   - Element::elligator_map / encode_to_curve / hash_to_curve:
  *     src/ark_curve/elligator.rs:15-76 (== src/min_curve/element.rs:190-244).
- *   - Element add / double / neg / eq: src/min_curve/element.rs:119-136,291-340.
+ *   - Element add / double / neg / eq / is_identity: src/min_curve/element.rs:113-136,291-340.
  *   - Element * Fr: src/min_curve/ops.rs:89-95 -> element.rs:138-157
  *     (LSB-first, 256 iterations of conditional add + double).
  *   - Fr / Fq byte handling: src/fields/fq.rs:90-115, src/fields/fr.rs:82-107.
@@ -295,6 +297,55 @@ static int fq_sqrt_ratio_zeta(fq num, fq den, fq *res) {
     return (q0p & 1) == 0;
 }
 
+/* ------------------------------------ min_curve backend: Tonelli-Shanks root --- */
+/* src/fields/fq.rs:62-67 QUADRATIC_NON_RESIDUE_TO_TRACE (= 11^m, Montgomery limbs as written there) */
+static const fq QNR_TO_TRACE = {{4340692304772210610ULL, 11102725085307959083ULL,
+                                 15540458298643990566ULL, 944526744080888988ULL}};
+/* src/fields/fq.rs MODULUS_MINUS_ONE_DIV_TWO_LIMBS = (q - 1) / 2 */
+static void q_minus_one_div_two(uint64_t e[4]) {
+    uint64_t t[4] = {Q[0] - 1, Q[1], Q[2], Q[3]};
+    for (int i = 0; i < 4; ++i) e[i] = (t[i] >> 1) | (i < 3 ? t[i + 1] << 63 : 0);
+}
+/* src/min_curve/invsqrt.rs:59-71 pow_le_limbs: LSB-first square-and-multiply */
+static fq fq_pow_le_limbs(fq a, const uint64_t *limbs, int n) {
+    fq acc = FQ_ONE, insert = a;
+    for (int l = 0; l < n; ++l)
+        for (int i = 0; i < 64; ++i) {
+            if ((limbs[l] >> i) & 1) acc = fq_mul(acc, insert);
+            insert = fq_mul(insert, insert);
+        }
+    return acc;
+}
+/* src/min_curve/invsqrt.rs:11-57 our_sqrt: constant-time Tonelli-Shanks of
+ * draft-irtf-cfrg-hash-to-curve appendix, c1 = 47, c3 = (m-1)/2, c5 = 11^m */
+static fq fq_our_sqrt(fq x) {
+    fq z = fq_pow_le_limbs(x, M_MINUS_ONE_DIV_TWO, 4);      /* step 1 */
+    fq t = fq_mul(fq_mul(z, z), x);                         /* step 2 */
+    z = fq_mul(z, x);                                       /* step 3 */
+    fq b = t;                                               /* step 4 */
+    fq c = QNR_TO_TRACE;                                    /* step 5 */
+    for (int i = SQRT_N; i >= 2; --i) {                     /* step 6 */
+        for (int j = 1; j <= i - 2; ++j) b = fq_mul(b, b);  /* steps 7-8 */
+        int b_ne_one = !fq_eq(b, FQ_ONE);
+        if (b_ne_one) z = fq_mul(z, c);                     /* step 9 (CMOV) */
+        c = fq_mul(c, c);                                   /* step 10 */
+        if (b_ne_one) t = fq_mul(t, c);                     /* step 11 (CMOV) */
+        b = t;                                              /* step 12 */
+    }
+    return z;
+}
+/* src/min_curve/invsqrt.rs:73-95 non_arkworks_sqrt_ratio_zeta */
+static int fq_sqrt_ratio_zeta_min_curve(fq num, fq den, fq *res) {
+    if (fq_is_zero(num)) { *res = num; return 1; }
+    if (fq_is_zero(den)) { *res = den; return 0; }
+    fq x = fq_mul(num, fq_inverse(den));                    /* num / den: Div = mul by inverse (fq/ops.rs:200-249) */
+    uint64_t e[4]; q_minus_one_div_two(e);
+    fq symbol = fq_pow_le_limbs(x, e, 4);
+    if (fq_eq(symbol, FQ_ONE)) { *res = fq_our_sqrt(x); return 1; }
+    *res = fq_our_sqrt(fq_mul(ZETA, x));
+    return 0;
+}
+
 /* -------------------------------------------------------------- group --- */
 typedef struct { fq x, y, z, t; } element;
 
@@ -509,6 +560,50 @@ API void d377o_eq_xyzt(const uint64_t *p, const uint64_t *q, size_t n, uint8_t *
     }
 }
 API void d377o_generator_xyzt(uint64_t *xyzt) { el_store(el_generator(), xyzt); }
+API void d377o_identity_xyzt(uint64_t *xyzt) { el_store(el_identity(), xyzt); }
+/* src/min_curve/element.rs:324-332 */
+API void d377o_neg_xyzt(const uint64_t *p, size_t n, uint64_t *out) {
+    for (size_t i = 0; i < n; ++i) {
+        element e = el_load(p + 16 * i);
+        e.x = fq_neg(e.x); e.t = fq_neg(e.t);
+        el_store(e, out + 16 * i);
+    }
+}
+/* src/min_curve/element.rs:113-117 */
+API void d377o_is_identity(const uint64_t *p, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t)fq_is_zero(el_load(p + 16 * i).x);
+}
+/* Fq operations on Montgomery limbs (src/fields/fq/u64/wrapper.rs:99-132); op codes as in
+ * include/decaf377_amd.h: 0 add, 1 sub, 2 mul, 3 square, 4 neg, 5 inverse (status 1 and a zero
+ * record for the inverse of zero: wrapper.rs:104-112 returns None) */
+API void d377o_fq_op(int op, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out, uint8_t *status) {
+    for (size_t i = 0; i < n; ++i) {
+        fq x, y = FQ_ZERO, r; memcpy(x.l, a + 4 * i, 32);
+        if (op <= 2) memcpy(y.l, b + 4 * i, 32);
+        uint8_t st = 0;
+        switch (op) {
+        case 0: r = fq_add(x, y); break;
+        case 1: r = fq_sub(x, y); break;
+        case 2: r = fq_mul(x, y); break;
+        case 3: r = fq_square(x); break;
+        case 4: r = fq_neg(x); break;
+        default: if (fq_is_zero(x)) { r = FQ_ZERO; st = 1; } else r = fq_inverse(x); break;
+        }
+        memcpy(out + 4 * i, r.l, 32);
+        if (status) status[i] = st;
+    }
+}
+/* the min_curve backend's root (src/min_curve/invsqrt.rs:73-95) */
+API void d377o_sqrt_ratio_zeta_min_curve(const uint8_t *num32, const uint8_t *den32, size_t n,
+                                         uint8_t *root32, uint8_t *was_square) {
+    for (size_t i = 0; i < n; ++i) {
+        fq r;
+        int ws = fq_sqrt_ratio_zeta_min_curve(fq_from_le_bytes_mod_order(num32 + 32 * i),
+                                              fq_from_le_bytes_mod_order(den32 + 32 * i), &r);
+        fq_to_bytes(r, root32 + 32 * i);
+        was_square[i] = (uint8_t)ws;
+    }
+}
 
 /* Fq::from_le_bytes_mod_order for any length (src/fields/fq.rs:90-102): 32-byte chunks, folded
  * from the most significant one with acc * FIELD_SIZE_POWER_OF_TWO + chunk (fq.rs:83-88 = 2^256 mod q). */
@@ -564,10 +659,11 @@ static void *job_run(void *p) {
     case 2: d377o_scalar_mul_var(j->a, j->b, j->n, j->out, j->status); break;
     case 3: d377o_encode_to_curve(j->a, j->n, j->out); break;
     case 4: d377o_sqrt_ratio_zeta(j->a, j->b, j->n, j->out, j->status); break;
+    case 5: d377o_sqrt_ratio_zeta_min_curve(j->a, j->b, j->n, j->out, j->status); break;
     }
     return NULL;
 }
-/* op: 0 roundtrip, 1 scalar_mul_base, 2 scalar_mul_var, 3 encode_to_curve, 4 sqrt_ratio_zeta */
+/* op: 0 roundtrip, 1 scalar_mul_base, 2 scalar_mul_var, 3 encode_to_curve, 4 sqrt_ratio_zeta, 5 the min_curve root */
 API int d377o_run_threads(int op, const uint8_t *a, const uint8_t *b, size_t n,
                           uint8_t *out, uint8_t *status, int threads) {
     d377o_init();

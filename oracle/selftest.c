@@ -33,6 +33,10 @@ int main(void) {
     d377o_fq_from_wide_bytes(wide, 48, N, out);
     d377o_encode_to_curve_wide(wide, 64, 8, out);
     d377o_to_affine(xyzt, N, xy);
+    d377o_sqrt_ratio_zeta_min_curve(r0, k, 8, out, st);
+    { uint64_t neg[N * 16], fa[N * 4]; uint8_t idn[N];
+      d377o_neg_xyzt(xyzt, N, neg); d377o_is_identity(neg, N, idn);
+      for (int op = 0; op < 6; ++op) d377o_fq_op(op, xyzt, xyzt + 4 * N, N, fa, st); }
     uint8_t e1[32]; uint64_t x1[16];
     d377o_msm(xyzt, k, 16, e1, x1);
     fill(enc, sizeof enc);                       /* raw strings: mostly invalid encodings */

@@ -29,7 +29,8 @@ def as_u8(x, n=None):
 
 
 class Oracle:
-    OPS = {"roundtrip": 0, "scalar_mul_base": 1, "scalar_mul_var": 2, "encode_to_curve": 3, "sqrt_ratio_zeta": 4}
+    OPS = {"roundtrip": 0, "scalar_mul_base": 1, "scalar_mul_var": 2, "encode_to_curve": 3, "sqrt_ratio_zeta": 4,
+           "sqrt_ratio_zeta_min_curve": 5}
 
     def __init__(self):
         self.lib = ctypes.CDLL(build_oracle())
@@ -45,6 +46,15 @@ class Oracle:
         root = np.zeros((n, 32), np.uint8)
         ws = np.zeros(n, np.uint8)
         self.lib.d377o_sqrt_ratio_zeta(_p(num), _p(den), self._n(n), _p(root), _p(ws))
+        return root, ws
+
+    def sqrt_ratio_zeta_min_curve(self, num, den):
+        """The min_curve backend's root (constant-time Tonelli-Shanks, src/min_curve/invsqrt.rs:73-95)."""
+        num, den = as_u8(num), as_u8(den)
+        n = num.shape[0]
+        root = np.zeros((n, 32), np.uint8)
+        ws = np.zeros(n, np.uint8)
+        self.lib.d377o_sqrt_ratio_zeta_min_curve(_p(num), _p(den), self._n(n), _p(root), _p(ws))
         return root, ws
 
     def decompress(self, enc):
@@ -132,6 +142,32 @@ class Oracle:
         eq = np.zeros(p.shape[0], np.uint8)
         self.lib.d377o_eq_xyzt(_p(p), _p(q), self._n(p.shape[0]), _p(eq))
         return eq
+
+    def neg_xyzt(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros_like(p)
+        self.lib.d377o_neg_xyzt(_p(p), self._n(p.shape[0]), _p(out))
+        return out
+
+    def is_identity(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros(p.shape[0], np.uint8)
+        self.lib.d377o_is_identity(_p(p), self._n(p.shape[0]), _p(out))
+        return out
+
+    def identity_xyzt(self):
+        out = np.zeros(16, np.uint64)
+        self.lib.d377o_identity_xyzt(_p(out))
+        return out
+
+    def fq_op(self, op, a, b=None):
+        """op: 0 add, 1 sub, 2 mul, 3 square, 4 neg, 5 inverse -> (Montgomery limbs, status)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        bb = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4) if b is not None else None
+        out = np.zeros_like(a)
+        st = np.zeros(a.shape[0], np.uint8)
+        self.lib.d377o_fq_op(ctypes.c_int(op), _p(a), _p(bb) if bb is not None else None, self._n(a.shape[0]), _p(out), _p(st))
+        return out, st
 
     def msm(self, xyzt, k, threads=8):
         """Reference fold; slices are folded on `threads` python-side chunks and summed (the sum is

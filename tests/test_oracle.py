@@ -305,3 +305,63 @@ def test_field_regression_seeds(oracle, kats):
         enc = oracle.scalar_mul_base(kb)
         assert bytes(enc[0]) == m.compress(m.scalar_mul(m.GENERATOR, 1 << e))
     assert not oracle.scalar_mul_base(np.zeros((1, 32), np.uint8)).any()      # 0 * B = identity
+
+
+# --- the min_curve backend's root, neg / is_identity / Fq ops (SURVEY 8a rows a4', a9, a1, a3) ---
+def test_min_curve_root(oracle):
+    """src/min_curve/invsqrt.rs:11-95: the C restatement equals the big-integer one; the root squares to
+    num/den (or zeta*num/den), and equals the Sarkar root up to sign with identical flags."""
+    assert m.QNR_TO_TRACE == pow(11, m.SQRT_M, m.Q)            # 11 is the least non-residue
+    rng = np.random.default_rng(47)
+    n = 96
+    num = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    den = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    num[0] = 0
+    den[1] = 0
+    num[2] = 0
+    den[2] = 0
+    num[3] = np.frombuffer((1 << 248).to_bytes(32, "little"), np.uint8)   # proptest-regressions/invsqrt.txt:7
+    den[3] = num[3]
+    root, ws = oracle.sqrt_ratio_zeta_min_curve(num, den)
+    root_a, ws_a = oracle.sqrt_ratio_zeta(num, den)
+    assert (ws == ws_a).all()
+    assert list(ws[:3]) == [1, 0, 1] and not root[:3].any()
+    differs = 0
+    for i in range(n):
+        u = int.from_bytes(bytes(num[i]), "little") % m.Q
+        v = int.from_bytes(bytes(den[i]), "little") % m.Q
+        fl, r = m.sqrt_ratio_zeta_min_curve(u, v)
+        got = int.from_bytes(bytes(root[i]), "little")
+        assert (int(ws[i]) == 1) == fl and got == r, i
+        if u and v:
+            assert got * got % m.Q * v % m.Q == (u if fl else m.ZETA * u % m.Q), i
+        ra = int.from_bytes(bytes(root_a[i]), "little")
+        assert got in (ra, (m.Q - ra) % m.Q)
+        differs += got != ra
+    assert 20 < differs < 76          # the two backends disagree on the sign about half the time
+
+
+def test_neg_is_identity_fq_ops(oracle):
+    """src/min_curve/element.rs:113-117,324-332 and src/fields/fq/u64/wrapper.rs:99-132 vs big integers."""
+    rng = np.random.default_rng(9)
+    r0 = rng.integers(0, 256, (32, 32), dtype=np.uint8)
+    P = oracle.elligator_map_xyzt(r0)
+    P[0] = oracle.identity_xyzt()
+    N = oracle.neg_xyzt(P)
+    for i in range(32):
+        x, y, z, t = (mont(P[i, 4 * j:4 * j + 4]) for j in range(4))
+        assert [mont(N[i, 4 * j:4 * j + 4]) for j in range(4)] == [(-x) % m.Q, y, z, (-t) % m.Q]
+    ident = oracle.is_identity(P)
+    assert ident[0] == 1 and not ident[1:].any()
+    assert oracle.is_identity(oracle.add_xyzt(P, N)).all()
+    a = oracle.fq_from_bytes_mod_order(rng.integers(0, 256, (64, 32), dtype=np.uint8))
+    b = oracle.fq_from_bytes_mod_order(rng.integers(0, 256, (64, 32), dtype=np.uint8))
+    a[0] = 0
+    for op, f in enumerate([lambda x, y: x + y, lambda x, y: x - y, lambda x, y: x * y, lambda x, y: x * x,
+                            lambda x, y: -x, lambda x, y: pow(x, -1, m.Q) if x else 0]):
+        out, st = oracle.fq_op(op, a, b)
+        for i in range(64):
+            x, y = mont(a[i]), mont(b[i])
+            assert mont(out[i]) == f(x, y) % m.Q, (op, i)
+            assert int(st[i]) == (1 if op == 5 and x == 0 else 0)
+        assert all(int.from_bytes(out[i].tobytes(), "little") < m.Q for i in range(64))     # fully reduced limbs
