@@ -32,8 +32,12 @@ struct SqrtTables {
 
 #include "s_hash.inc"        // defines D377_S_HASH_K (searched offline, verified at init)
 
-D377_HD uint32_t s_hash(const fe& x) {
+D377_HD uint32_t s_hash_raw(const fe& x) {     // table construction: explicit representations
   return ((x.l[0] ^ (x.l[1] << 3)) * D377_S_HASH_K) >> (32 - S_HASH_BITS);
+}
+D377_HD uint32_t s_hash(const fe& x) {         // lookups: the key must be one of x, x + q with x < 2^248
+  D377_B(bound_require(x.vq < 1.0535, "s_lookup key must be below q + 2^248"));
+  return s_hash_raw(x);
 }
 
 D377_HD fe gt_load(const SqrtTables& T, int table, uint32_t idx) {
@@ -48,6 +52,7 @@ D377_HD fe gt_load(const SqrtTables& T, int table, uint32_t idx) {
 #else
   for (int i = 0; i < NL; ++i) r.l[i] = p[i];
 #endif
+  fe_assume_carried(r, 1.1);      // the init kernels store strict products: value < 1.02q
   return r;
 }
 
@@ -128,8 +133,9 @@ D377_HD fe fe_pow_m12(const fe& x, PT& pt) {
   return fe_sqr_n(acc, D377_POW_TRAIL);
 }
 
-// zero test for a value that is a fe_mul/fe_sqr output (tight, < 2q): 0 or q
-D377_HD bool fe_mulout_is_zero(const fe& a) {
+// zero test for a strict product (product limbs, value < 2q): 0 or q
+D377_HD bool fe_strict_is_zero(const fe& a) {
+  D377_B(bound_require(a.vq < 2.0, "fe_strict_is_zero needs a value below 2q"));
   uint32_t o = 0, d = 0;
 #pragma unroll
   for (int i = 0; i < NL; ++i) { o |= a.l[i]; d |= a.l[i] ^ QL[i]; }
@@ -137,14 +143,16 @@ D377_HD bool fe_mulout_is_zero(const fe& a) {
 }
 
 // ---- sqrt_ratio_zeta ----------------------------------------------------------------------
-// src/ark_curve/invsqrt.rs:75-166.  `den` must be a multiplication output (tight, < 2q).
+// src/ark_curve/invsqrt.rs:75-166.  `den` (and `num`) must be strict products (value < 2q: the zero
+// tests compare with 0 and q).  The values that go through s_lookup are strict products of strict
+// products, so that each has at most the two representations x and x + q (x < 2^248) the table holds.
 // NUM_IS_ONE: the callers on the group path always pass num = 1 (encoding.rs:57,100;
 // elligator.rs:26); the generic form is used by the raw batch entry point.
 template <bool NUM_IS_ONE, class PT>
 D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, const fe& den, fe* res) {
-  const bool den_zero = fe_mulout_is_zero(den);
+  const bool den_zero = fe_strict_is_zero(den);
   bool num_zero = false;
-  if (!NUM_IS_ONE) num_zero = fe_mulout_is_zero(num);
+  if (!NUM_IS_ONE) num_zero = fe_strict_is_zero(num);
 
   fe s = fe_pow_2_47_m1(den);                       // invsqrt.rs:88-89
   fe t_ = fe_mul(fe_sqr(s), den);                   // :90
@@ -157,29 +165,29 @@ D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, cons
   fe x3 = fe_sqr_n(x4, 8);
   fe x2 = fe_sqr_n(x3, 8);
   fe x1 = fe_sqr_n(x2, 8);
-  fe x0 = fe_sqr_n(x1, 7);                          // :110
+  fe x0 = fe_sqr_strict(fe_sqr_strict(fe_sqr_n(x1, 5)));   // :110  (x1^(2^7))
 
   const uint64_t q0p = T.s_lookup[s_hash(x0)];      // :113
   uint64_t t = q0p;
-  fe a1 = fe_mul(x1, gt_load(T, 4, (uint32_t)(t & 0xFF)));                       // :117-119
+  fe a1 = fe_mul_strict(x1, gt_load(T, 4, (uint32_t)(t & 0xFF)));                // :117-119
   t += (uint64_t)T.s_lookup[s_hash(a1)] << 7;
-  fe a2 = fe_mul(fe_mul(x2, gt_load(T, 3, (uint32_t)(t & 0xFF))),
-                 gt_load(T, 4, (uint32_t)((t >> 8) & 0xFF)));                    // :122-126
+  fe a2 = fe_mul_strict(fe_mul(x2, gt_load(T, 3, (uint32_t)(t & 0xFF))),
+                        gt_load(T, 4, (uint32_t)((t >> 8) & 0xFF)));             // :122-126
   t += (uint64_t)T.s_lookup[s_hash(a2)] << 15;
-  fe a3 = fe_mul(fe_mul(fe_mul(x3, gt_load(T, 2, (uint32_t)(t & 0xFF))),
-                        gt_load(T, 3, (uint32_t)((t >> 8) & 0xFF))),
-                 gt_load(T, 4, (uint32_t)((t >> 16) & 0xFF)));                   // :129-134
+  fe a3 = fe_mul_strict(fe_mul(fe_mul(x3, gt_load(T, 2, (uint32_t)(t & 0xFF))),
+                               gt_load(T, 3, (uint32_t)((t >> 8) & 0xFF))),
+                        gt_load(T, 4, (uint32_t)((t >> 16) & 0xFF)));            // :129-134
   t += (uint64_t)T.s_lookup[s_hash(a3)] << 23;
-  fe a4 = fe_mul(fe_mul(fe_mul(fe_mul(x4, gt_load(T, 1, (uint32_t)(t & 0xFF))),
-                               gt_load(T, 2, (uint32_t)((t >> 8) & 0xFF))),
-                        gt_load(T, 3, (uint32_t)((t >> 16) & 0xFF))),
-                 gt_load(T, 4, (uint32_t)((t >> 24) & 0xFF)));                   // :137-143
+  fe a4 = fe_mul_strict(fe_mul(fe_mul(fe_mul(x4, gt_load(T, 1, (uint32_t)(t & 0xFF))),
+                                      gt_load(T, 2, (uint32_t)((t >> 8) & 0xFF))),
+                               gt_load(T, 3, (uint32_t)((t >> 16) & 0xFF))),
+                        gt_load(T, 4, (uint32_t)((t >> 24) & 0xFF)));            // :137-143
   t += (uint64_t)T.s_lookup[s_hash(a4)] << 31;
-  fe a5 = fe_mul(fe_mul(fe_mul(fe_mul(fe_mul(x5, gt_load(T, 0, (uint32_t)(t & 0xFF))),
-                                      gt_load(T, 1, (uint32_t)((t >> 8) & 0xFF))),
-                               gt_load(T, 2, (uint32_t)((t >> 16) & 0xFF))),
-                        gt_load(T, 3, (uint32_t)((t >> 24) & 0xFF))),
-                 gt_load(T, 4, (uint32_t)((t >> 32) & 0xFF)));                   // :146-153
+  fe a5 = fe_mul_strict(fe_mul(fe_mul(fe_mul(fe_mul(x5, gt_load(T, 0, (uint32_t)(t & 0xFF))),
+                                             gt_load(T, 1, (uint32_t)((t >> 8) & 0xFF))),
+                                      gt_load(T, 2, (uint32_t)((t >> 16) & 0xFF))),
+                               gt_load(T, 3, (uint32_t)((t >> 24) & 0xFF))),
+                        gt_load(T, 4, (uint32_t)((t >> 32) & 0xFF)));            // :146-153
   t += (uint64_t)T.s_lookup[s_hash(a5)] << 39;
 
   t = (t + 1) >> 1;                                                              // :155
@@ -206,6 +214,9 @@ D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, cons
 D377_HD fe fe_from_words_mod_order(const uint32_t w[8]) {
   return fe_mul(fe_from_words(w), fe_const(FE_R2));
 }
+D377_HD fe fe_from_words_mod_order_strict(const uint32_t w[8]) {   // value < 2q (sqrt_ratio_zeta operands)
+  return fe_mul_strict(fe_from_words(w), fe_const(FE_R2));
+}
 // Fq::from_le_bytes_mod_order for 33..64 input bytes (src/fields/fq.rs:90-102): two 32-byte
 // chunks, value = lo + 2^256 * hi (hi zero-padded).  The result is a lazy sum of two products.
 D377_HD fe fe_from_wide_words(const uint32_t lo[8], const uint32_t hi[8]) {
@@ -216,6 +227,7 @@ D377_HD void fe_to_bytes_words(const fe& a, uint32_t w[8]) { fe_to_words(fe_cano
 
 // full reduction of a tight value < 2q to [0, q)
 D377_HD fe fe_reduce_once(const fe& a) {
+  D377_B(bound_require(a.vq < 2.0, "fe_reduce_once needs a value below 2q"));
   fe d;
   uint32_t borrow = 0;
 #pragma unroll
@@ -224,7 +236,13 @@ D377_HD fe fe_reduce_once(const fe& a) {
     borrow = t >> 31;
     d.l[i] = (i < NL - 1) ? (t & MASK29) : t;
   }
-  return fe_select(borrow != 0, a, d);
+#if defined(D377_BOUNDS)
+  for (int i = 0; i < NL; ++i) d.ub[i] = a.ub[i];
+  d.vq = 1.0;
+#endif
+  fe r = fe_select(borrow != 0, a, d);
+  D377_B(r.vq = 1.0);
+  return r;
 }
 // q - c for canonical c != 0 (plain integers, tight limbs)
 D377_HD fe fe_canon_negate(const fe& c) {
@@ -236,13 +254,18 @@ D377_HD fe fe_canon_negate(const fe& c) {
     borrow = t >> 31;
     d.l[i] = (i < NL - 1) ? (t & MASK29) : t;
   }
+#if defined(D377_BOUNDS)
+  for (int i = 0; i < NL - 1; ++i) d.ub[i] = MASK29;
+  d.ub[NL - 1] = QL[NL - 1];
+  d.vq = 1.0;
+#endif
   return d;
 }
 
 // the reference's external element layout: 4 x u64 Montgomery limbs, R = 2^256
 // (Fq::from_montgomery_limbs, src/fields/fq/u64/wrapper.rs:82-85), as 8 x u32 words.
 D377_HD void fe_to_mont256_words(const fe& a, uint32_t w[8]) {
-  fe_to_words(fe_reduce_once(fe_mul(a, fe_const(FE_TO_MONT256))), w);
+  fe_to_words(fe_reduce_once(fe_mul_strict(a, fe_const(FE_TO_MONT256))), w);
 }
 D377_HD fe fe_from_mont256_words(const uint32_t w[8]) {
   return fe_mul(fe_from_words(w), fe_const(FE_FROM_MONT256));
@@ -314,10 +337,10 @@ D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8],
   fe s = fe_mul(fe_from_words(w), fe_const(FE_R2));
   fe ss = fe_sqr(s);                                      // :50
   fe u1 = fe_sub(fe_const(FE_ONE), ss);                   // :51
-  fe u1sq = fe_sqr(u1);
+  fe u1sq = fe_sqr_strict(u1);                            // strict: keeps den below 2q for the zero test
   fe u2 = fe_sub(u1sq, fe_mul(fe_const(FE_4D), ss));      // :54
   fe v;
-  const bool was_square = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul(u2, u1sq), &v);   // :57
+  const bool was_square = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(u2, u1sq), &v);   // :57
   bad |= (uint32_t)!was_square;                           // :58-60
   fe two_s_u1 = fe_mul(fe_dbl(s), u1);                    // :63
   if (fe_is_negative(fe_mul(two_s_u1, v))) v = fe_neg(v); // :64-67
@@ -334,7 +357,7 @@ D377_HD void ge_compress(const SqrtTables& T, PT& pt, const ge& p, uint32_t w[8]
   const fe a_minus_d = fe_const(FE_A_MINUS_D);
   fe u1 = fe_mul(fe_add(p.x, p.t), fe_sub(p.x, p.t));                       // :97
   fe v;
-  (void)fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul(fe_mul(u1, a_minus_d), fe_sqr(p.x)), &v);  // :101
+  (void)fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(fe_mul(u1, a_minus_d), fe_sqr(p.x)), &v);  // :101
   fe u2 = fe_abs(fe_mul(v, u1));                                            // :104
   fe u3 = fe_sub(fe_mul(u2, p.z), p.t);                                     // :107
   fe s = fe_mul(fe_mul(fe_mul(a_minus_d, v), u3), p.x);                     // :110
@@ -352,7 +375,7 @@ D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0) {
   fe den = fe_mul(fe_sub(fe_mul(dd, r), dma), fe_sub(fe_mul(dma, r), dd));        // :22
   fe num = fe_mul(fe_add(r, one), fe_const(FE_A_MINUS_2D));                       // :23
   fe isri;
-  const bool iss = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul(num, den), &isri);   // :25-26
+  const bool iss = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(num, den), &isri);   // :25-26
   isri = fe_select(iss, isri, fe_mul(isri, r0));                                  // twiddle, :28-38
   fe s = fe_mul(isri, num);                                                       // :40
   fe p = fe_mul(fe_mul(fe_mul(isri, s), fe_sub(r, one)), fe_const(FE_A_MINUS_2D_SQ));
@@ -426,12 +449,12 @@ struct gec { fe ypx, ymx, z2, kt; };      // cached extended point
 
 D377_HD ge ge_double_fast(const ge& p, bool with_t) {
   fe a = fe_sqr(p.x), b = fe_sqr(p.y);
-  fe c = fe_dbl(fe_sqr(p.z));             // lazy
+  fe c = fe_sqr2x(p.z);                   // 2 Z^2 for the price of Z^2
   fe s_ = fe_sqr(fe_add(p.x, p.y));
   fe h = fe_add(a, b);                    // H' lazy
-  fe e = fe_sub(h, s_);                   // E' = A + B - (X+Y)^2, tight
-  fe g = fe_sub(a, b);                    // G' tight
-  fe f = fe_add(g, c);                    // F' = G' + 2Z^2 (limbs < 1.5 * 2^30, times a tight operand only)
+  fe e = fe_sub(h, s_);                   // E' = A + B - (X+Y)^2, carried
+  fe g = fe_sub(a, b);                    // G' carried
+  fe f = fe_add(g, c);                    // F' = G' + 2Z^2, lazy
   ge r;
   r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g);
   r.t = p.t;
@@ -439,29 +462,33 @@ D377_HD ge ge_double_fast(const ge& p, bool with_t) {
   return r;
 }
 
-// Doubling for latency-bound single-lane tails (MSM Horner: 252 dependent doublings on one lane):
-// same formulas as ge_double_fast, but the four squarings and the four products are issued as
-// interleaved pairs (fe_sqr2 / fe_mul2), which is what a lone wave needs to keep the MAC pipe fed
-// (a lone wave: 823 vs 1217 cycles per squaring, 1142 vs 1439 per multiplication).
-D377_HD ge ge_double_latency(const ge& p) {
-  fe a, b, zz, s_;
-  fe_sqr2(p.x, p.y, a, b);
-  fe_sqr2(p.z, fe_add(p.x, p.y), zz, s_);
-  fe c = fe_dbl(zz);
-  fe h = fe_add(a, b);
-  fe e = fe_sub(h, s_);
-  fe g = fe_sub(a, b);
-  fe f = fe_add(g, c);
+// -[2]P: the doubling of the scalar-multiplication loops.  E = 2XY is taken as the product
+// X * (2Y) with its true sign while F', G', H' are the sign-folded (negated) forms, so the
+// result is (-X3, Y3, Z3, -T3) = -[2]P -- and the (X+Y)^2 squaring with its offset subtraction
+// and carry pass (222 instructions) becomes one addition and one product (205).  An even number
+// of these in a row (the 4 per window) restores the sign.
+D377_HD ge ge_double_neg(const ge& p, bool with_t) {
+  fe a = fe_sqr(p.x), b = fe_sqr(p.y);
+  fe c = fe_sqr2x(p.z);
+  fe e = fe_mul(p.x, fe_dbl(p.y));        // 2XY
+  fe h = fe_add(a, b);                    // lazy
+  fe g = fe_sub(a, b);                    // carried
+  fe f = fe_add(g, c);                    // lazy
   ge r;
-  fe_mul2(e, f, g, h, r.x, r.y);
-  fe_mul2(f, g, e, h, r.z, r.t);
+  r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g);
+  r.t = p.t;
+  if (with_t) r.t = fe_mul(e, h);
   return r;
 }
 
+// one lane running alone (the MSM's Horner tail): same formulas; the hand-written multiplier has no
+// pad instructions, so a lone wave issues it as fast as it can issue anything (~4.6 cycles each)
+D377_HD ge ge_double_latency(const ge& p) { return ge_double_fast(p, true); }
+
 D377_HD gec ge_to_cached(const ge& p) {
   gec c;
-  c.ypx = fe_add(p.y, p.x);               // lazy
-  c.ymx = fe_sub(p.y, p.x);
+  c.ypx = fe_carry(fe_add(p.y, p.x));     // carried, like ymx: a negative digit swaps the two
+  c.ymx = fe_sub(p.y, p.x);               // carried
   c.z2 = fe_dbl(p.z);                     // lazy
   c.kt = fe_mul(fe_const(FE_K), p.t);
   return c;
@@ -469,8 +496,9 @@ D377_HD gec ge_to_cached(const ge& p) {
 
 // p + (neg ? -q : q).  The caller has already swapped q.ypx / q.ymx for a negative digit (the
 // table loader does it by address); the sign of 2dT is applied here by swapping F and G.
+// p's coordinates are products; q.ymx is carried, so Y - X needs no carry pass before it.
 D377_HD ge ge_add_cached(const ge& p, const gec& q, bool neg, bool with_t) {
-  fe a = fe_mul(fe_sub(p.y, p.x), q.ymx);
+  fe a = fe_mul(fe_sub_nc(p.y, p.x), q.ymx);
   fe b = fe_mul(fe_add(p.y, p.x), q.ypx);
   fe c = fe_mul(p.t, q.kt);
   fe d = fe_mul(p.z, q.z2);
@@ -531,7 +559,7 @@ D377_HD ge ge_scalar_mul_w4(const ge& p, const uint32_t digits[8], Tab& tab) {
     const bool neg = d < 0;
     const gec e = tab.load(neg ? -d : d, neg);
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) r = ge_double_fast(r, j == 3);
+    for (int j = 0; j < 4; ++j) r = ge_double_neg(r, j == 3);   // (-2)^4 = 16
     r = ge_add_cached(r, e, neg, i == 0);       // only the compressor needs the last T
   }
   return r;

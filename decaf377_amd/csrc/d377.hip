@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(BLOCK) k_init_gtab(uint32_t* gtab) {
   const int t = idx >> 8, nu = idx & 255;
   fe base = fe_sqr_n(fe_const(FE_SQRT_G), 8 * t);
   fe v = nu == 0 ? fe_const(FE_ONE) : fe_pow_u32(base, (uint32_t)nu);
+  v = fe_mul_strict(v, fe_const(FE_ONE));       // same value, below 1.02q: keeps the s_lookup keys within x, x + q
   uint32_t* p = gtab + (size_t)idx * GT_STRIDE;
 #pragma unroll
   for (int i = 0; i < NL; ++i) p[i] = v.l[i];
@@ -90,8 +91,8 @@ __global__ void __launch_bounds__(BLOCK) k_init_slookup(uint8_t* s_lookup, uint3
   const int nu = threadIdx.x;
   fe b39 = fe_sqr_n(fe_const(FE_SQRT_G_INV), 39);
   fe v = nu == 0 ? fe_const(FE_ONE) : fe_pow_u32(b39, (uint32_t)nu);
-  fe c = fe_reduce_once(v);
-  keys[2 * nu] = s_hash(c);
+  fe c = fe_reduce_once(fe_mul_strict(v, fe_const(FE_ONE)));
+  keys[2 * nu] = s_hash_raw(c);
   uint32_t h2 = 0xFFFFFFFFu;
   if (c.l[NL - 1] < (1u << 16)) {        // x < 2^248: x + q is a possible product representation
     fe cq = fe_add(c, fe_const(Q_LIMBS));
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(BLOCK) k_init_slookup(uint8_t* s_lookup, uint3
       uint32_t t = cq.l[i] + carry;
       if (i < NL - 1) { n.l[i] = t & MASK29; carry = t >> RB; } else n.l[i] = t;
     }
-    h2 = s_hash(n);
+    h2 = s_hash_raw(n);
   }
   keys[2 * nu + 1] = h2;
   for (int i = threadIdx.x; i < (1 << S_HASH_BITS); i += BLOCK) s_lookup[i] = 0;
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtT
     load32(num32, i, wn);
     load32(den32, i, wd);
     fe r;
-    const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, fe_from_words_mod_order(wn), fe_from_words_mod_order(wd), &r);
+    const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, fe_from_words_mod_order_strict(wn), fe_from_words_mod_order_strict(wd), &r);
     fe_to_bytes_words(r, wr);
     store32(root32, i, wr);
     was_square[i] = ws ? 1 : 0;

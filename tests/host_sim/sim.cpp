@@ -34,6 +34,7 @@ struct HostFTab {
   gea load(int i, int j, bool swap) const {
     gea g; const uint32_t* q = p + ((size_t)i * FB_ENTRIES + j) * 27;
     for (int k = 0; k < 9; ++k) { g.ypx.l[k] = q[(swap ? 9 : 0) + k]; g.ymx.l[k] = q[(swap ? 0 : 9) + k]; g.kt.l[k] = q[18 + k]; }
+    fe_assume_carried(g.ypx, 26.0); fe_assume_carried(g.ymx, 26.0); fe_assume_carried(g.kt, 9.0);
     return g;
   }
 };
@@ -47,6 +48,7 @@ int sim_init() {
     fe base = fe_sqr_n(g, pw[t]);
     for (int nu = 0; nu < 256; ++nu) {
       fe v = nu == 0 ? one : fe_pow_u64(base, (uint64_t)nu);
+      v = fe_mul_strict(v, one);
       for (int i = 0; i < NL; ++i) g_gtab[((size_t)t * 256 + nu) * GT_STRIDE + i] = v.l[i];
     }
   }
@@ -55,12 +57,12 @@ int sim_init() {
   fe b39 = fe_sqr_n(ginv, 39);
   for (int nu = 0; nu < 256; ++nu) {
     fe v = nu == 0 ? one : fe_pow_u64(b39, (uint64_t)nu);
-    fe c = fe_reduce_once(v);                      // canonical Montgomery value in [0, q)
+    fe c = fe_reduce_once(fe_mul_strict(v, one));  // canonical Montgomery value in [0, q)
     fe cq = full_norm(fe_add(c, fe_const(Q_LIMBS)));   // the other tight representation
     const int nrep = (c.l[NL - 1] < (1u << 16)) ? 2 : 1;   // x + q only when x < 2^248
     for (int rep = 0; rep < nrep; ++rep) {
       fe k = rep ? cq : c;
-      uint32_t h = s_hash(k);
+      uint32_t h = s_hash_raw(k);
       if (owner[h] >= 0 && owner[h] != nu) ++coll;
       owner[h] = nu; g_slook[h] = (uint8_t)nu;
     }
@@ -103,23 +105,39 @@ void sim_fq_to_bytes(const uint32_t* mont256, size_t n, uint32_t* w) {
   for (size_t i = 0; i < n; ++i) fe_to_bytes_words(fe_from_mont256_words(mont256 + 8 * i), w + 8 * i);
 }
 // raw limb-level entry points (9 x u32 per element) for the bound stress tests
-void sim_raw_mul(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
-  for (size_t i = 0; i < n; ++i) { fe x, y; memcpy(x.l, a + 9 * i, 36); memcpy(y.l, b + 9 * i, 36); fe r = fe_mul(x, y); memcpy(out + 9 * i, r.l, 36); }
+static fe raw_load(const uint32_t* p) {      // bounds = the actual limbs (these tests feed the extremes themselves)
+  fe x; memcpy(x.l, p, 36);
+#if defined(D377_BOUNDS)
+  for (int i = 0; i < NL; ++i) x.ub[i] = x.l[i];
+  x.vq = ((double)x.l[NL - 1] + 2.0) / Q_TOP;
+#endif
+  return x;
 }
-void sim_raw_sqr(const uint32_t* a, size_t n, uint32_t* out) {
-  for (size_t i = 0; i < n; ++i) { fe x; memcpy(x.l, a + 9 * i, 36); fe r = fe_sqr(x); memcpy(out + 9 * i, r.l, 36); }
+// mode: 0 fe_mul, 1 fe_mul_strict, 2 fe_sqr, 3 fe_sqr_strict, 4 fe_sqr2x
+void sim_raw_mul(int mode, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) {
+    fe x = raw_load(a + 9 * i), y = raw_load(b + 9 * i), r;
+    switch (mode) {
+      case 0: r = fe_mul(x, y); break;
+      case 1: r = fe_mul_strict(x, y); break;
+      case 2: r = fe_sqr(x); break;
+      case 3: r = fe_sqr_strict(x); break;
+      default: r = fe_sqr2x(x); break;
+    }
+    memcpy(out + 9 * i, r.l, 36);
+  }
 }
-void sim_raw_sub(const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
-  for (size_t i = 0; i < n; ++i) { fe x, y; memcpy(x.l, a + 9 * i, 36); memcpy(y.l, b + 9 * i, 36); fe r = fe_sub(x, y); memcpy(out + 9 * i, r.l, 36); }
+void sim_raw_sub(int nc, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) { fe x = raw_load(a + 9 * i), y = raw_load(b + 9 * i); fe r = nc ? fe_sub_nc(x, y) : fe_sub(x, y); memcpy(out + 9 * i, r.l, 36); }
 }
 void sim_raw_canon(const uint32_t* a, size_t n, uint32_t* out) {
-  for (size_t i = 0; i < n; ++i) { fe x; memcpy(x.l, a + 9 * i, 36); fe r = fe_canon(x); memcpy(out + 9 * i, r.l, 36); }
+  for (size_t i = 0; i < n; ++i) { fe x = raw_load(a + 9 * i); fe r = fe_canon(x); memcpy(out + 9 * i, r.l, 36); }
 }
-void sim_consts(uint32_t* sub8q, uint32_t* ql) { for (int i = 0; i < NL; ++i) { sub8q[i] = SUB8Q[i]; ql[i] = QL[i]; } }
+void sim_consts(uint32_t* sub16q, uint32_t* sub16q_nc, uint32_t* ql) { for (int i = 0; i < NL; ++i) { sub16q[i] = SUB32Q[i]; sub16q_nc[i] = SUB16Q_NC[i]; ql[i] = QL[i]; } }
 
 void sim_sqrt_ratio_zeta(const uint32_t* num, const uint32_t* den, size_t n, uint32_t* root, uint8_t* ws) {
   for (size_t i = 0; i < n; ++i) {
-    RegPowTab pt; fe r; bool w = fe_sqrt_ratio_zeta<false>(g_T, pt, fe_from_words_mod_order(num + 8 * i), fe_from_words_mod_order(den + 8 * i), &r);
+    RegPowTab pt; fe r; bool w = fe_sqrt_ratio_zeta<false>(g_T, pt, fe_from_words_mod_order_strict(num + 8 * i), fe_from_words_mod_order_strict(den + 8 * i), &r);
     fe_to_bytes_words(r, root + 8 * i); ws[i] = w;
   }
 }
@@ -131,12 +149,22 @@ static ge ge_load256(const uint32_t* o) {
   return g;
 }
 // ge_double (reference form), ge_double_fast and ge_double_latency on Montgomery-256 records
-void sim_double_variants(const uint32_t* xyzt, size_t n, uint32_t* ref, uint32_t* fast, uint32_t* lat) {
+void sim_double_variants(const uint32_t* xyzt, size_t n, uint32_t* ref, uint32_t* fast, uint32_t* negd) {
   for (size_t i = 0; i < n; ++i) {
     ge g = ge_load256(xyzt + 32 * i);
     ge_store256(ge_double(g), ref + 32 * i);
     ge_store256(ge_double_fast(g, true), fast + 32 * i);
-    ge_store256(ge_double_latency(g), lat + 32 * i);
+    ge_store256(ge_double_neg(g, true), negd + 32 * i);      // -[2]P
+  }
+}
+// reference-form addition and negation (the API kernels k_add / k_neg / k_hash_to_curve use them)
+void sim_group_misc(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* sum, uint32_t* neg) {
+  for (size_t i = 0; i < n; ++i) {
+    ge a = ge_load256(p + 32 * i), b = ge_load256(q + 32 * i);
+    ge_store256(ge_add(a, b), sum + 32 * i);
+    ge_store256(ge_neg(a), neg + 32 * i);
+    (void)fe_eq(fe_mul(a.x, b.y), fe_mul(b.x, a.y));
+    (void)fe_invert(a.z);
   }
 }
 void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
