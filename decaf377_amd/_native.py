@@ -28,6 +28,7 @@ EXPORTS = [
     "d377_batch_sqrt_ratio_zeta_dev", "d377_batch_decompress_dev", "d377_batch_compress_dev",
     "d377_batch_roundtrip_dev", "d377_batch_scalar_mul_base_dev", "d377_batch_scalar_mul_var_dev",
     "d377_batch_encode_to_curve_dev", "d377_batch_hash_to_curve_dev",
+    "d377_batch_sqrt_ratio_zeta_ex", "d377_batch_sqrt_ratio_zeta_ex_dev", "d377_batch_sharded_dev",
 ]
 
 _lib = None
@@ -103,6 +104,11 @@ def load():
     lib.d377_batch_fq_from_bytes_checked.argtypes = [vp, vp, sz, vp, vp]
     lib.d377_batch_fq_to_bytes.argtypes = [vp, vp, sz, vp]
     for name in ("d377_batch_fq_op", "d377_batch_fq_op_dev", "d377_batch_fq_from_bytes_checked", "d377_batch_fq_to_bytes"):
+        getattr(lib, name).restype = i32
+    lib.d377_batch_sqrt_ratio_zeta_ex.argtypes = [vp, i32, vp, vp, sz, vp, vp]
+    lib.d377_batch_sqrt_ratio_zeta_ex_dev.argtypes = [vp, i32, vp, i32, vp, vp, sz, vp, vp]
+    lib.d377_batch_sharded_dev.argtypes = [vp, i32, vp, i32, vp, vp, sz, vp, vp]
+    for name in ("d377_batch_sqrt_ratio_zeta_ex", "d377_batch_sqrt_ratio_zeta_ex_dev", "d377_batch_sharded_dev"):
         getattr(lib, name).restype = i32
     lib.d377_identity.argtypes = [vp]
     lib.d377_identity.restype = None

@@ -148,8 +148,13 @@ D377_HD bool fe_strict_is_zero(const fe& a) {
 // products, so that each has at most the two representations x and x + q (x < 2^248) the table holds.
 // NUM_IS_ONE: the callers on the group path always pass num = 1 (encoding.rs:57,100;
 // elligator.rs:26); the generic form is used by the raw batch entry point.
+// min_curve_root: return the root the min_curve backend's constant-time Tonelli-Shanks returns
+// (src/min_curve/invsqrt.rs:11-95, seed 11^m) instead of the arkworks backend's Sarkar root: the two
+// differ by a sign that is a function of the discrete log t the table phase has already found
+// (constants.inc, D377_TS_U), so no second square root is computed.
 template <bool NUM_IS_ONE, class PT>
-D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, const fe& den, fe* res) {
+D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, const fe& den, fe* res,
+                                bool min_curve_root = false) {
   const bool den_zero = fe_strict_is_zero(den);
   bool num_zero = false;
   if (!NUM_IS_ONE) num_zero = fe_strict_is_zero(num);
@@ -190,6 +195,9 @@ D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, cons
                         gt_load(T, 4, (uint32_t)((t >> 32) & 0xFF)));            // :146-153
   t += (uint64_t)T.s_lookup[s_hash(a5)] << 39;
 
+  // sign of the Tonelli-Shanks (11^m) root relative to this one: bit 46 of u * (u^-1 * (t >> 1) mod 2^46)
+  const uint64_t e2 = (D377_TS_U_INV * (t >> 1)) & ((1ull << 46) - 1);
+  const bool flip = min_curve_root && (((D377_TS_U * e2) >> 46) & 1ull) != 0;
   t = (t + 1) >> 1;                                                              // :155
   const bool nonsq = (q0p & 1) != 0;
   fe r = fe_select(nonsq, fe_mul(uv, fe_const(FE_NONSQUARE)), uv);               // :156-157
@@ -200,6 +208,7 @@ D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, cons
   r = fe_mul(r, gt_load(T, 4, (uint32_t)((t >> 32) & 0xFF)));
   r = fe_mul(r, gt_load(T, 5, (uint32_t)((t >> 40) & 0xFF)));                    // :158-163
 
+  if (min_curve_root) r = fe_select(flip, fe_neg(r), r);
   bool was_square = !nonsq;
   // early-outs of invsqrt.rs:81-86, applied as selects so the wave stays converged
   if (den_zero) { r = fe_zero(); was_square = false; }

@@ -8,9 +8,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/decaf377_amd.h"
@@ -149,14 +153,15 @@ __global__ void __launch_bounds__(BLOCK) k_init_fbase(uint32_t* fb) {
 // --------------------------------------------------------------------------- batch kernels ---
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtTables T, const uint8_t* num32,
                                                            const uint8_t* den32, size_t n,
-                                                           uint8_t* root32, uint8_t* was_square) {
+                                                           uint8_t* root32, uint8_t* was_square, int min_curve_root) {
   D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t wn[8], wd[8], wr[8];
     load32(num32, i, wn);
     load32(den32, i, wd);
     fe r;
-    const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, fe_from_words_mod_order_strict(wn), fe_from_words_mod_order_strict(wd), &r);
+    const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, fe_from_words_mod_order_strict(wn), fe_from_words_mod_order_strict(wd), &r,
+                                              min_curve_root != 0);
     fe_to_bytes_words(r, wr);
     store32(root32, i, wr);
     was_square[i] = ws ? 1 : 0;
@@ -392,6 +397,15 @@ __global__ void __launch_bounds__(BLOCK) k_eq(const uint64_t* p, const uint64_t*
 }
 
 // ------------------------------------------------------------------------------ host side ---
+}  // namespace
+
+int d377::debug_device_delay_ms() {
+  const char* e = getenv("D377_DEBUG_DEVICE_DELAY_MS");
+  return e ? atoi(e) : 0;
+}
+
+namespace {
+
 int grid_for(const DeviceState& d, size_t n) {
   // >> 256 workgroups when the batch allows it; capped so huge batches grid-stride
   size_t blocks = (n + BLOCK - 1) / BLOCK;
@@ -399,6 +413,18 @@ int grid_for(const DeviceState& d, size_t n) {
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
+}
+
+int init_tables(DeviceState& d, uint32_t* keys, int* coll) {
+  hipLaunchKernelGGL(k_init_gtab, dim3(6), dim3(BLOCK), 0, d.stream, d.gtab);
+  hipLaunchKernelGGL(k_init_slookup, dim3(1), dim3(BLOCK), 0, d.stream, d.s_lookup, keys, coll);
+  hipLaunchKernelGGL(k_init_fbase, dim3((FB_WINDOWS * FB_ENTRIES + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, d.stream, d.fbase);
+  HIP_TRY(hipGetLastError());
+  int h_coll = -1;
+  HIP_TRY(hipMemcpyAsync(&h_coll, coll, sizeof(int), hipMemcpyDeviceToHost, d.stream));
+  HIP_TRY(hipStreamSynchronize(d.stream));
+  if (h_coll != 0) return fail(D377_ERR_INIT, "s_lookup perfect hash self-check failed (%s)", "collisions");
+  return D377_OK;
 }
 
 int init_device(DeviceState& d) {
@@ -414,6 +440,9 @@ int init_device(DeviceState& d) {
     HIP_TRY(hipEventCreateWithFlags(&d.ev_in[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.ev_done[i], hipEventDisableTiming));
   }
+  HIP_TRY(hipEventCreateWithFlags(&d.ev_shard, hipEventDisableTiming));
+  int rc;
+  if ((rc = d.vb_guard.init()) || (rc = d.msm.guard.init())) return rc;
   HIP_TRY(hipMalloc(&d.gtab, (size_t)6 * 256 * GT_STRIDE * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&d.s_lookup, (size_t)1 << S_HASH_BITS));
   HIP_TRY(hipMalloc(&d.fbase, (size_t)FB_WINDOWS * FB_ENTRIES * FBW_ENTRY_WORDS * sizeof(uint32_t)));
@@ -423,47 +452,46 @@ int init_device(DeviceState& d) {
   uint32_t* keys = nullptr;
   int* coll = nullptr;
   HIP_TRY(hipMalloc(&keys, 512 * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(&coll, sizeof(int)));
-  hipLaunchKernelGGL(k_init_gtab, dim3(6), dim3(BLOCK), 0, d.stream, d.gtab);
-  hipLaunchKernelGGL(k_init_slookup, dim3(1), dim3(BLOCK), 0, d.stream, d.s_lookup, keys, coll);
-  hipLaunchKernelGGL(k_init_fbase, dim3((FB_WINDOWS * FB_ENTRIES + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, d.stream, d.fbase);
-  HIP_TRY(hipGetLastError());
-  int h_coll = -1;
-  HIP_TRY(hipMemcpyAsync(&h_coll, coll, sizeof(int), hipMemcpyDeviceToHost, d.stream));
-  HIP_TRY(hipStreamSynchronize(d.stream));
-  HIP_TRY(hipFree(keys));
-  HIP_TRY(hipFree(coll));
-  if (h_coll != 0) return fail(D377_ERR_INIT, "s_lookup perfect hash self-check failed (%s)", "collisions");
-  return D377_OK;
+  if (hipMalloc(&coll, sizeof(int)) != hipSuccess) { (void)hipFree(keys); return fail(D377_ERR_HIP, "%s", "hipMalloc failed"); }
+  rc = init_tables(d, keys, coll);
+  (void)hipFree(keys);
+  (void)hipFree(coll);
+  return rc;
 }
 
 void free_device(DeviceState& d) {
   if (d.id < 0) return;
   (void)hipSetDevice(d.id);
   if (d.stream) (void)hipStreamSynchronize(d.stream);
+  if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
+  (void)d.vb_guard.drain();
+  (void)d.msm.guard.drain();
   (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch);
-  for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); }
+  for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); (void)hipFree(d.shard[i]); }
   for (int i = 0; i < 2; ++i) {
     if (d.ev_in[i]) (void)hipEventDestroy(d.ev_in[i]);
     if (d.ev_done[i]) (void)hipEventDestroy(d.ev_done[i]);
   }
+  if (d.ev_shard) (void)hipEventDestroy(d.ev_shard);
+  d.vb_guard.destroy();
+  d.msm.guard.destroy();
   if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
   (void)hipFree(d.msm.mem);
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
-enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE, OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE, OP_NEG, OP_IS_IDENTITY, OP_FQ_BIN, OP_FQ_UN, OP_FQ_CHECKED, OP_FQ_TO_BYTES, OP_FR_MOD, OP_FR_CHECKED };
-
-// launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null)
-thread_local int g_fq_op = 0;   // the D377_FQ_* selector of the OP_FQ_BIN / OP_FQ_UN launch in progress
-int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
+// launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null).
+// aux: the D377_FQ_* selector of OP_FQ_BIN / OP_FQ_UN, the D377_SQRT_ROOT_* convention of OP_SQRT.
+// The caller holds ctx->mu (the scratch guards are host state).
+int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
   if (n == 0) return D377_OK;
   const SqrtTables T = d.tables();
   const int g = grid_for(d, n);
+  int rc;
   switch (op) {
     case OP_SQRT:
       hipLaunchKernelGGL(k_sqrt_ratio_zeta, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
-                         (uint8_t*)out0, (uint8_t*)out1);
+                         (uint8_t*)out0, (uint8_t*)out1, aux);
       break;
     case OP_DECOMPRESS:
       hipLaunchKernelGGL(k_decompress, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint64_t*)out0, (uint8_t*)out1);
@@ -479,8 +507,10 @@ int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in
       break;
     case OP_MUL_VAR: {
       int gv = g < d.vb_blocks ? g : d.vb_blocks;    // never more lanes than scratch tables
+      if ((rc = d.vb_guard.acquire(s))) return rc;   // the window tables are one per device: queue behind their last user
       hipLaunchKernelGGL(k_scalar_mul_var, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
                          (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch);
+      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     }
     case OP_ENCODE:
@@ -514,7 +544,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, const void* in0, const void* in
       break;
     case OP_FQ_BIN:
     case OP_FQ_UN:
-      hipLaunchKernelGGL(k_fq_op, dim3(g), dim3(BLOCK), 0, s, g_fq_op, (const uint64_t*)in0, (const uint64_t*)in1, n,
+      hipLaunchKernelGGL(k_fq_op, dim3(g), dim3(BLOCK), 0, s, aux, (const uint64_t*)in0, (const uint64_t*)in1, n,
                          (uint64_t*)out0, (uint8_t*)out1);
       break;
     case OP_FQ_CHECKED:
@@ -571,108 +601,198 @@ OpShape shape_of(Op op) {
   return {0, 0, 0, 0};
 }
 
-// Large batches on a single device are pipelined in chunks of 2^18 records: while chunk k runs on
-// the compute stream, chunk k+1's inputs are copied in and chunk k-1's outputs are copied out on
-// the copy stream (double-buffered staging), so PCIe time hides under the kernels.
+// Large batches are pipelined in chunks of 2^18 records: while chunk k runs on the compute stream,
+// chunk k+1's inputs are copied in and chunk k-1's outputs are copied out on the copy stream
+// (double-buffered staging), so PCIe time hides under the kernels.
 constexpr size_t PIPE_CHUNK = (size_t)1 << 18;
 
-int run_host_pipelined(DeviceState& d, Op op, const OpShape& sh, const void* in0, const void* in1, size_t n, void* out0,
-                       void* out1) {
-  HIP_TRY(hipSetDevice(d.id));
-  int rc;
-  if ((rc = ensure(d, 0, PIPE_CHUNK * sh.in0))) return rc;
-  if (sh.in1 && (rc = ensure(d, 1, PIPE_CHUNK * sh.in1))) return rc;
-  if ((rc = ensure(d, 2, PIPE_CHUNK * sh.out0))) return rc;
-  if (sh.out1 && (rc = ensure(d, 3, PIPE_CHUNK * sh.out1))) return rc;
-  if ((rc = ensure2(d, 0, PIPE_CHUNK * sh.in0))) return rc;
-  if (sh.in1 && (rc = ensure2(d, 1, PIPE_CHUNK * sh.in1))) return rc;
-  if ((rc = ensure2(d, 2, PIPE_CHUNK * sh.out0))) return rc;
-  if (sh.out1 && (rc = ensure2(d, 3, PIPE_CHUNK * sh.out1))) return rc;
-  const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
-  auto bufs = [&](size_t k) -> uint8_t** { return (k & 1) ? d.buf2 : d.buf; };
-  auto drain = [&](size_t k) -> int {          // outputs of chunk k -> host (waits for its kernel)
-    const size_t lo = k * PIPE_CHUNK, cnt = (lo + PIPE_CHUNK <= n) ? PIPE_CHUNK : n - lo;
-    uint8_t** b = bufs(k);
-    HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.ev_done[k & 1], 0));
-    HIP_TRY(hipMemcpyAsync((uint8_t*)out0 + lo * sh.out0, b[2], cnt * sh.out0, hipMemcpyDeviceToHost, d.copy_stream));
-    if (sh.out1)
-      HIP_TRY(hipMemcpyAsync((uint8_t*)out1 + lo * sh.out1, b[3], cnt * sh.out1, hipMemcpyDeviceToHost, d.copy_stream));
-    HIP_TRY(hipStreamSynchronize(d.copy_stream));
+int run_one_pipelined(DeviceState& d, Op op, int aux, const OpShape& sh, const void* in0, const void* in1, size_t n,
+                      void* out0, void* out1) {
+  int rc = D377_OK;
+  SyncOnError guard{&rc, d.id, d.stream, d.copy_stream};
+  auto body = [&]() -> int {
+    int r;
+    if ((r = ensure(d, 0, PIPE_CHUNK * sh.in0))) return r;
+    if (sh.in1 && (r = ensure(d, 1, PIPE_CHUNK * sh.in1))) return r;
+    if ((r = ensure(d, 2, PIPE_CHUNK * sh.out0))) return r;
+    if (sh.out1 && (r = ensure(d, 3, PIPE_CHUNK * sh.out1))) return r;
+    if ((r = ensure2(d, 0, PIPE_CHUNK * sh.in0))) return r;
+    if (sh.in1 && (r = ensure2(d, 1, PIPE_CHUNK * sh.in1))) return r;
+    if ((r = ensure2(d, 2, PIPE_CHUNK * sh.out0))) return r;
+    if (sh.out1 && (r = ensure2(d, 3, PIPE_CHUNK * sh.out1))) return r;
+    const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+    auto bufs = [&](size_t k) -> uint8_t** { return (k & 1) ? d.buf2 : d.buf; };
+    auto drain = [&](size_t k) -> int {          // outputs of chunk k -> host (waits for its kernel)
+      const size_t lo = k * PIPE_CHUNK, cnt = (lo + PIPE_CHUNK <= n) ? PIPE_CHUNK : n - lo;
+      uint8_t** b = bufs(k);
+      HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.ev_done[k & 1], 0));
+      HIP_TRY(hipMemcpyAsync((uint8_t*)out0 + lo * sh.out0, b[2], cnt * sh.out0, hipMemcpyDeviceToHost, d.copy_stream));
+      if (sh.out1)
+        HIP_TRY(hipMemcpyAsync((uint8_t*)out1 + lo * sh.out1, b[3], cnt * sh.out1, hipMemcpyDeviceToHost, d.copy_stream));
+      HIP_TRY(hipStreamSynchronize(d.copy_stream));
+      return D377_OK;
+    };
+    for (size_t k = 0; k < nchunks; ++k) {
+      const size_t lo = k * PIPE_CHUNK, cnt = (lo + PIPE_CHUNK <= n) ? PIPE_CHUNK : n - lo;
+      uint8_t** b = bufs(k);
+      // this buffer set was last used by chunk k-2, which has been drained (host-synchronised) already
+      HIP_TRY(hipMemcpyAsync(b[0], (const uint8_t*)in0 + lo * sh.in0, cnt * sh.in0, hipMemcpyHostToDevice, d.copy_stream));
+      if (sh.in1)
+        HIP_TRY(hipMemcpyAsync(b[1], (const uint8_t*)in1 + lo * sh.in1, cnt * sh.in1, hipMemcpyHostToDevice, d.copy_stream));
+      HIP_TRY(hipEventRecord(d.ev_in[k & 1], d.copy_stream));
+      HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_in[k & 1], 0));
+      if ((r = launch(d, d.stream, op, aux, b[0], b[1], cnt, b[2], b[3]))) return r;
+      HIP_TRY(hipEventRecord(d.ev_done[k & 1], d.stream));
+      if (k >= 1 && (r = drain(k - 1))) return r;
+    }
+    if ((r = drain(nchunks - 1))) return r;
+    HIP_TRY(hipStreamSynchronize(d.stream));
     return D377_OK;
   };
-  for (size_t k = 0; k < nchunks; ++k) {
-    const size_t lo = k * PIPE_CHUNK, cnt = (lo + PIPE_CHUNK <= n) ? PIPE_CHUNK : n - lo;
-    uint8_t** b = bufs(k);
-    // this buffer set was last used by chunk k-2, which has been drained (host-synchronised) already
-    HIP_TRY(hipMemcpyAsync(b[0], (const uint8_t*)in0 + lo * sh.in0, cnt * sh.in0, hipMemcpyHostToDevice, d.copy_stream));
-    if (sh.in1)
-      HIP_TRY(hipMemcpyAsync(b[1], (const uint8_t*)in1 + lo * sh.in1, cnt * sh.in1, hipMemcpyHostToDevice, d.copy_stream));
-    HIP_TRY(hipEventRecord(d.ev_in[k & 1], d.copy_stream));
-    HIP_TRY(hipStreamWaitEvent(d.stream, d.ev_in[k & 1], 0));
-    if ((rc = launch(d, d.stream, op, b[0], b[1], cnt, b[2], b[3]))) return rc;
-    HIP_TRY(hipEventRecord(d.ev_done[k & 1], d.stream));
-    if (k >= 1 && (rc = drain(k - 1))) return rc;
-  }
-  if ((rc = drain(nchunks - 1))) return rc;
-  HIP_TRY(hipStreamSynchronize(d.stream));
-  return D377_OK;
+  rc = body();
+  return rc;
 }
 
-// host-pointer path: contiguous slices over the context's devices, async per device, then join
-int run_host(d377_ctx* ctx, Op op, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
+// one device, one contiguous slice of a host batch: copies in, kernel, copies out, synchronised
+int run_one(DeviceState& d, Op op, int aux, const OpShape& sh, const void* in0, const void* in1, size_t n, void* out0,
+            void* out1) {
+  if (n == 0) return D377_OK;
+  HIP_TRY(hipSetDevice(d.id));
+  if (n >= 2 * PIPE_CHUNK) return run_one_pipelined(d, op, aux, sh, in0, in1, n, out0, out1);
+  int rc = D377_OK;
+  SyncOnError guard{&rc, d.id, d.stream, nullptr};
+  auto body = [&]() -> int {
+    int r;
+    if ((r = ensure(d, 0, n * sh.in0))) return r;
+    if (sh.in1 && (r = ensure(d, 1, n * sh.in1))) return r;
+    if ((r = ensure(d, 2, n * sh.out0))) return r;
+    if (sh.out1 && (r = ensure(d, 3, n * sh.out1))) return r;
+    HIP_TRY(hipMemcpyAsync(d.buf[0], in0, n * sh.in0, hipMemcpyHostToDevice, d.stream));
+    if (sh.in1) HIP_TRY(hipMemcpyAsync(d.buf[1], in1, n * sh.in1, hipMemcpyHostToDevice, d.stream));
+    if ((r = launch(d, d.stream, op, aux, d.buf[0], d.buf[1], n, d.buf[2], d.buf[3]))) return r;
+    HIP_TRY(hipMemcpyAsync(out0, d.buf[2], n * sh.out0, hipMemcpyDeviceToHost, d.stream));
+    if (sh.out1) HIP_TRY(hipMemcpyAsync(out1, d.buf[3], n * sh.out1, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    return D377_OK;
+  };
+  rc = body();
+  return rc;
+}
+
+// host-pointer path: contiguous slices over the context's devices.  With several devices each slice is
+// driven by its own host thread: copies from pageable caller memory block the issuing thread, so a single
+// thread would run the devices one after another.
+int run_host(d377_ctx* ctx, Op op, int aux, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
   if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
   const OpShape sh = shape_of(op);
   if (n && (!in0 || (sh.in1 && !in1) || !out0 || (sh.out1 && !out1))) return fail(D377_ERR_ARG, "%s", "null buffer");
   if (n == 0) return D377_OK;
   std::lock_guard<std::mutex> lock(ctx->mu);
   const size_t nd = ctx->devs.size();
-  if (nd == 1 && n >= 2 * PIPE_CHUNK) return run_host_pipelined(ctx->devs[0], op, sh, in0, in1, n, out0, out1);
+  if (nd == 1) return run_one(ctx->devs[0], op, aux, sh, in0, in1, n, out0, out1);
   const size_t per = (n + nd - 1) / nd;
-  int rc = D377_OK;
+  std::vector<int> rcs(nd, D377_OK);
+  std::vector<std::string> errs(nd);
+  std::vector<std::thread> workers;
+  const int delay = debug_device_delay_ms();
   for (size_t k = 0; k < nd; ++k) {
-    DeviceState& d = ctx->devs[k];
     const size_t lo = per * k;
     if (lo >= n) break;
     const size_t cnt = (lo + per <= n) ? per : n - lo;
-    HIP_TRY(hipSetDevice(d.id));
-    if ((rc = ensure(d, 0, cnt * sh.in0))) return rc;
-    if (sh.in1 && (rc = ensure(d, 1, cnt * sh.in1))) return rc;
-    if ((rc = ensure(d, 2, cnt * sh.out0))) return rc;
-    if (sh.out1 && (rc = ensure(d, 3, cnt * sh.out1))) return rc;
-    HIP_TRY(hipMemcpyAsync(d.buf[0], (const uint8_t*)in0 + lo * sh.in0, cnt * sh.in0, hipMemcpyHostToDevice, d.stream));
-    if (sh.in1)
-      HIP_TRY(hipMemcpyAsync(d.buf[1], (const uint8_t*)in1 + lo * sh.in1, cnt * sh.in1, hipMemcpyHostToDevice, d.stream));
-    if ((rc = launch(d, d.stream, op, d.buf[0], d.buf[1], cnt, d.buf[2], d.buf[3]))) return rc;
-    HIP_TRY(hipMemcpyAsync((uint8_t*)out0 + lo * sh.out0, d.buf[2], cnt * sh.out0, hipMemcpyDeviceToHost, d.stream));
-    if (sh.out1)
-      HIP_TRY(hipMemcpyAsync((uint8_t*)out1 + lo * sh.out1, d.buf[3], cnt * sh.out1, hipMemcpyDeviceToHost, d.stream));
+    workers.emplace_back([&, k, lo, cnt]() {
+      if (delay > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay));
+      rcs[k] = run_one(ctx->devs[k], op, aux, sh, (const uint8_t*)in0 + lo * sh.in0,
+                       sh.in1 ? (const uint8_t*)in1 + lo * sh.in1 : nullptr, cnt, (uint8_t*)out0 + lo * sh.out0,
+                       sh.out1 ? (uint8_t*)out1 + lo * sh.out1 : nullptr);
+      if (rcs[k] != D377_OK) errs[k] = d377_g_err;       // the worker's thread-local text
+    });
   }
-  for (size_t k = 0; k < nd; ++k) {
-    DeviceState& d = ctx->devs[k];
-    HIP_TRY(hipSetDevice(d.id));
-    HIP_TRY(hipStreamSynchronize(d.stream));
-  }
+  for (auto& w : workers) w.join();                      // every device has drained before we return, error or not
+  for (size_t k = 0; k < nd; ++k)
+    if (rcs[k] != D377_OK) return fail(rcs[k], "%s", errs[k].c_str());
   return D377_OK;
 }
 
-int run_dev(d377_ctx* ctx, int dev, void* stream, Op op, const void* in0, const void* in1, size_t n, void* out0,
-            void* out1) {
+int check_dev_args(d377_ctx* ctx, int dev, Op op, const void* in0, const void* in1, size_t n, const void* out0,
+                   const void* out1) {
   if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
   if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
   const OpShape sh = shape_of(op);
-  if (n && (!in0 || (sh.in1 && !in1) || !out0 || (sh.out1 && !out1))) return fail(D377_ERR_ARG, "%s", "null buffer");
-  if (!aligned16(in0) || !aligned16(in1) || (op != OP_EQ && op != OP_IS_IDENTITY && !aligned16(out0)))
+  const bool out1_optional = (op == OP_FQ_BIN || op == OP_FQ_UN);
+  if (n && (!in0 || (sh.in1 && !in1) || !out0 || (sh.out1 && !out1 && !out1_optional))) return fail(D377_ERR_ARG, "%s", "null buffer");
+  if (!aligned16(in0) || !aligned16(in1) || (sh.out0 >= 16 && !aligned16(out0)))
     return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
+  return D377_OK;
+}
+
+int run_dev(d377_ctx* ctx, int dev, void* stream, Op op, int aux, const void* in0, const void* in1, size_t n, void* out0,
+            void* out1) {
+  int rc = check_dev_args(ctx, dev, op, in0, in1, n, out0, out1);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceState& d = ctx->devs[(size_t)dev];
   HIP_TRY(hipSetDevice(d.id));
-  return launch(d, (hipStream_t)stream, op, in0, in1, n, out0, out1);
+  return launch(d, (hipStream_t)stream, op, aux, in0, in1, n, out0, out1);
+}
+
+// A batch that lives in the HBM of device `root`: the other devices of the context get contiguous
+// slices by peer copies over xGMI, run the same kernel, and copy their outputs back; the root's own
+// slice runs in place.  Nothing synchronises with the host: completion is ordered on `stream`.
+int run_sharded_dev(d377_ctx* ctx, int root, void* stream, Op op, int aux, const void* in0, const void* in1, size_t n,
+                    void* out0, void* out1) {
+  int rc = check_dev_args(ctx, root, op, in0, in1, n, out0, out1);
+  if (rc) return rc;
+  if (n == 0) return D377_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const OpShape sh = shape_of(op);
+  const size_t nd = ctx->devs.size();
+  DeviceState& R = ctx->devs[(size_t)root];
+  hipStream_t s = (hipStream_t)stream;
+  // slices are multiples of 16 records so every slice of a 1-byte-per-record array stays 16-byte aligned
+  size_t per = (n + nd - 1) / nd;
+  per = (per + 15) & ~(size_t)15;
+  HIP_TRY(hipSetDevice(R.id));
+  HIP_TRY(hipEventRecord(R.ev_shard, s));                 // the inputs are ready at this point of `stream`
+  std::vector<size_t> used;
+  for (size_t k = 0; k < nd; ++k) {
+    const size_t lo = per * k;
+    if (lo >= n) break;
+    const size_t cnt = (lo + per <= n) ? per : n - lo;
+    if ((int)k == root) continue;
+    DeviceState& d = ctx->devs[k];
+    HIP_TRY(hipSetDevice(d.id));
+    if ((rc = ensure_shard(d, 0, cnt * sh.in0))) return rc;
+    if (sh.in1 && (rc = ensure_shard(d, 1, cnt * sh.in1))) return rc;
+    if ((rc = ensure_shard(d, 2, cnt * sh.out0))) return rc;
+    if (sh.out1 && (rc = ensure_shard(d, 3, cnt * sh.out1))) return rc;
+    HIP_TRY(hipStreamWaitEvent(d.stream, R.ev_shard, 0));
+    HIP_TRY(hipMemcpyPeerAsync(d.shard[0], d.id, (const uint8_t*)in0 + lo * sh.in0, R.id, cnt * sh.in0, d.stream));
+    if (sh.in1) HIP_TRY(hipMemcpyPeerAsync(d.shard[1], d.id, (const uint8_t*)in1 + lo * sh.in1, R.id, cnt * sh.in1, d.stream));
+    if ((rc = launch(d, d.stream, op, aux, d.shard[0], d.shard[1], cnt, d.shard[2], d.shard[3]))) return rc;
+    HIP_TRY(hipMemcpyPeerAsync((uint8_t*)out0 + lo * sh.out0, R.id, d.shard[2], d.id, cnt * sh.out0, d.stream));
+    if (sh.out1 && out1) HIP_TRY(hipMemcpyPeerAsync((uint8_t*)out1 + lo * sh.out1, R.id, d.shard[3], d.id, cnt * sh.out1, d.stream));
+    HIP_TRY(hipEventRecord(d.ev_shard, d.stream));
+    used.push_back(k);
+  }
+  HIP_TRY(hipSetDevice(R.id));
+  {
+    const size_t lo = per * (size_t)root;
+    if (lo < n) {
+      const size_t cnt = (lo + per <= n) ? per : n - lo;
+      if ((rc = launch(R, s, op, aux, (const uint8_t*)in0 + lo * sh.in0, sh.in1 ? (const uint8_t*)in1 + lo * sh.in1 : nullptr,
+                       cnt, (uint8_t*)out0 + lo * sh.out0, (sh.out1 && out1) ? (uint8_t*)out1 + lo * sh.out1 : nullptr)))
+        return rc;
+    }
+  }
+  for (size_t k : used) HIP_TRY(hipStreamWaitEvent(s, ctx->devs[k].ev_shard, 0));   // `stream` continues once every slice is back
+  return D377_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* d377_version(void) { return "decaf377_amd 0.1.0 (gfx950)"; }
+const char* d377_version(void) { return "decaf377_amd 0.2.0 (gfx950)"; }
 const char* d377_last_error(void) { return d377_g_err; }
 
 int d377_device_count(void) {
@@ -698,11 +818,25 @@ int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out) {
     ctx->devs[k].id = ids[k];
     int rc = init_device(ctx->devs[k]);
     if (rc != D377_OK) {
+      char saved[sizeof d377_g_err];
+      memcpy(saved, d377_g_err, sizeof saved);
       for (auto& d : ctx->devs) free_device(d);
       delete ctx;
+      memcpy(d377_g_err, saved, sizeof saved);
       return rc;
     }
   }
+  // peer access between the context's devices (xGMI): the sharded device-pointer path copies slices directly
+  for (size_t a = 0; a < ids.size(); ++a)
+    for (size_t b = 0; b < ids.size(); ++b) {
+      if (ids[a] == ids[b]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, ids[a], ids[b]) == hipSuccess && can) {
+        (void)hipSetDevice(ids[a]);
+        hipError_t e = hipDeviceEnablePeerAccess(ids[b], 0);
+        if (e != hipSuccess) (void)hipGetLastError();      // already enabled is fine; copies fall back to staging otherwise
+      }
+    }
   *out = ctx;
   return D377_OK;
 }
@@ -718,99 +852,101 @@ int d377_ctx_device_id(const d377_ctx* ctx, int dev) {
   return ctx->devs[(size_t)dev].id;
 }
 
+static int sqrt_root_ok(int root) {
+  if (root == D377_SQRT_ROOT_ARK || root == D377_SQRT_ROOT_MIN_CURVE) return D377_OK;
+  return fail(D377_ERR_ARG, "%s", "unknown square-root convention (D377_SQRT_ROOT_ARK / D377_SQRT_ROOT_MIN_CURVE)");
+}
 int d377_batch_sqrt_ratio_zeta(d377_ctx* ctx, const uint8_t* num32, const uint8_t* den32, size_t n, uint8_t* root32,
                                uint8_t* was_square) {
-  return run_host(ctx, OP_SQRT, num32, den32, n, root32, was_square);
+  return run_host(ctx, OP_SQRT, D377_SQRT_ROOT_ARK, num32, den32, n, root32, was_square);
+}
+int d377_batch_sqrt_ratio_zeta_ex(d377_ctx* ctx, int root, const uint8_t* num32, const uint8_t* den32, size_t n,
+                                  uint8_t* root32, uint8_t* was_square) {
+  int rc = sqrt_root_ok(root);
+  return rc ? rc : run_host(ctx, OP_SQRT, root, num32, den32, n, root32, was_square);
 }
 int d377_batch_decompress(d377_ctx* ctx, const uint8_t* enc32, size_t n, uint64_t* xyzt, uint8_t* status) {
-  return run_host(ctx, OP_DECOMPRESS, enc32, nullptr, n, xyzt, status);
+  return run_host(ctx, OP_DECOMPRESS, 0, enc32, nullptr, n, xyzt, status);
 }
 int d377_batch_compress(d377_ctx* ctx, const uint64_t* xyzt, size_t n, uint8_t* enc32) {
-  return run_host(ctx, OP_COMPRESS, xyzt, nullptr, n, enc32, nullptr);
+  return run_host(ctx, OP_COMPRESS, 0, xyzt, nullptr, n, enc32, nullptr);
 }
 int d377_batch_roundtrip(d377_ctx* ctx, const uint8_t* enc32, size_t n, uint8_t* enc32_out, uint8_t* status) {
-  return run_host(ctx, OP_ROUNDTRIP, enc32, nullptr, n, enc32_out, status);
+  return run_host(ctx, OP_ROUNDTRIP, 0, enc32, nullptr, n, enc32_out, status);
 }
 int d377_batch_scalar_mul_base(d377_ctx* ctx, const uint8_t* scalar32, size_t n, uint8_t* enc32_out) {
-  return run_host(ctx, OP_MUL_BASE, scalar32, nullptr, n, enc32_out, nullptr);
+  return run_host(ctx, OP_MUL_BASE, 0, scalar32, nullptr, n, enc32_out, nullptr);
 }
 int d377_batch_scalar_mul_var(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t n,
                               uint8_t* enc32_out, uint8_t* status) {
-  return run_host(ctx, OP_MUL_VAR, enc32, scalar32, n, enc32_out, status);
+  return run_host(ctx, OP_MUL_VAR, 0, enc32, scalar32, n, enc32_out, status);
 }
 int d377_batch_encode_to_curve(d377_ctx* ctx, const uint8_t* fq32, size_t n, uint8_t* enc32_out) {
-  return run_host(ctx, OP_ENCODE, fq32, nullptr, n, enc32_out, nullptr);
+  return run_host(ctx, OP_ENCODE, 0, fq32, nullptr, n, enc32_out, nullptr);
 }
 int d377_batch_hash_to_curve(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t* r2_32, size_t n, uint8_t* enc32_out) {
-  return run_host(ctx, OP_HASH, r1_32, r2_32, n, enc32_out, nullptr);
+  return run_host(ctx, OP_HASH, 0, r1_32, r2_32, n, enc32_out, nullptr);
 }
 
 int d377_batch_add(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint64_t* out_xyzt) {
-  return run_host(ctx, OP_ADD, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
+  return run_host(ctx, OP_ADD, 0, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
 }
 int d377_batch_double(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
-  return run_host(ctx, OP_DOUBLE, p_xyzt, nullptr, n, out_xyzt, nullptr);
+  return run_host(ctx, OP_DOUBLE, 0, p_xyzt, nullptr, n, out_xyzt, nullptr);
 }
 int d377_batch_eq(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint8_t* equal) {
-  return run_host(ctx, OP_EQ, p_xyzt, q_xyzt, n, equal, nullptr);
+  return run_host(ctx, OP_EQ, 0, p_xyzt, q_xyzt, n, equal, nullptr);
 }
 int d377_batch_add_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n,
                        uint64_t* out_xyzt) {
-  return run_dev(ctx, dev, stream, OP_ADD, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
+  return run_dev(ctx, dev, stream, OP_ADD, 0, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
 }
 int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
-  return run_dev(ctx, dev, stream, OP_DOUBLE, p_xyzt, nullptr, n, out_xyzt, nullptr);
+  return run_dev(ctx, dev, stream, OP_DOUBLE, 0, p_xyzt, nullptr, n, out_xyzt, nullptr);
 }
 int d377_batch_eq_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n,
                       uint8_t* equal) {
-  return run_dev(ctx, dev, stream, OP_EQ, p_xyzt, q_xyzt, n, equal, nullptr);
+  return run_dev(ctx, dev, stream, OP_EQ, 0, p_xyzt, q_xyzt, n, equal, nullptr);
 }
 
 int d377_batch_fq_op(d377_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out, uint8_t* status) {
   if (op < D377_FQ_ADD || op > D377_FQ_INVERSE) return fail(D377_ERR_ARG, "%s", "unknown Fq operation");
   std::vector<uint8_t> scratch;
   if (!status) { scratch.resize(n ? n : 1); status = scratch.data(); }
-  g_fq_op = op;
-  return run_host(ctx, op <= D377_FQ_MUL ? OP_FQ_BIN : OP_FQ_UN, a, op <= D377_FQ_MUL ? b : nullptr, n, out, status);
+  return run_host(ctx, op <= D377_FQ_MUL ? OP_FQ_BIN : OP_FQ_UN, op, a, op <= D377_FQ_MUL ? b : nullptr, n, out, status);
 }
 int d377_batch_fq_op_dev(d377_ctx* ctx, int dev, void* stream, int op, const uint64_t* a, const uint64_t* b, size_t n,
                          uint64_t* out, uint8_t* status) {
   if (op < D377_FQ_ADD || op > D377_FQ_INVERSE) return fail(D377_ERR_ARG, "%s", "unknown Fq operation");
   if (op == D377_FQ_INVERSE && !status) return fail(D377_ERR_ARG, "%s", "INVERSE needs a status buffer");
-  g_fq_op = op;
   // status is optional on the device path except for INVERSE; the kernel skips a null pointer
-  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
-  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
-  if (n && (!a || (op <= D377_FQ_MUL && !b) || !out)) return fail(D377_ERR_ARG, "%s", "null buffer");
-  if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
-  DeviceState& d = ctx->devs[(size_t)dev];
-  HIP_TRY(hipSetDevice(d.id));
-  return launch(d, (hipStream_t)stream, op <= D377_FQ_MUL ? OP_FQ_BIN : OP_FQ_UN, a, b, n, out, status);
+  return run_dev(ctx, dev, stream, op <= D377_FQ_MUL ? OP_FQ_BIN : OP_FQ_UN, op, a, op <= D377_FQ_MUL ? b : nullptr, n, out,
+                 status);
 }
 int d377_batch_fq_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint64_t* out, uint8_t* status) {
-  return run_host(ctx, OP_FQ_CHECKED, bytes32, nullptr, n, out, status);
+  return run_host(ctx, OP_FQ_CHECKED, 0, bytes32, nullptr, n, out, status);
 }
 int d377_batch_fq_to_bytes(d377_ctx* ctx, const uint64_t* a, size_t n, uint8_t* bytes32) {
-  return run_host(ctx, OP_FQ_TO_BYTES, a, nullptr, n, bytes32, nullptr);
+  return run_host(ctx, OP_FQ_TO_BYTES, 0, a, nullptr, n, bytes32, nullptr);
 }
 int d377_batch_fr_from_le_bytes_mod_order(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out) {
-  return run_host(ctx, OP_FR_MOD, bytes32, nullptr, n, fr32_out, nullptr);
+  return run_host(ctx, OP_FR_MOD, 0, bytes32, nullptr, n, fr32_out, nullptr);
 }
 int d377_batch_fr_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out, uint8_t* status) {
-  return run_host(ctx, OP_FR_CHECKED, bytes32, nullptr, n, fr32_out, status);
+  return run_host(ctx, OP_FR_CHECKED, 0, bytes32, nullptr, n, fr32_out, status);
 }
 int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
-  return run_host(ctx, OP_NEG, p_xyzt, nullptr, n, out_xyzt, nullptr);
+  return run_host(ctx, OP_NEG, 0, p_xyzt, nullptr, n, out_xyzt, nullptr);
 }
 int d377_batch_is_identity(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint8_t* is_identity) {
-  return run_host(ctx, OP_IS_IDENTITY, p_xyzt, nullptr, n, is_identity, nullptr);
+  return run_host(ctx, OP_IS_IDENTITY, 0, p_xyzt, nullptr, n, is_identity, nullptr);
 }
 int d377_batch_neg_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
-  return run_dev(ctx, dev, stream, OP_NEG, p_xyzt, nullptr, n, out_xyzt, nullptr);
+  return run_dev(ctx, dev, stream, OP_NEG, 0, p_xyzt, nullptr, n, out_xyzt, nullptr);
 }
 int d377_batch_is_identity_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n,
                                uint8_t* is_identity) {
-  return run_dev(ctx, dev, stream, OP_IS_IDENTITY, p_xyzt, nullptr, n, is_identity, nullptr);
+  return run_dev(ctx, dev, stream, OP_IS_IDENTITY, 0, p_xyzt, nullptr, n, is_identity, nullptr);
 }
 // Element::IDENTITY / Element::GENERATOR in the external layout (src/min_curve/element.rs:53-81): the
 // Montgomery (R = 2^256) limbs the reference writes down in its source
@@ -835,59 +971,81 @@ static int wide_op(size_t len, Op o48, Op o64, Op* out) {
 }
 int d377_batch_fq_from_wide_bytes(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* fq32_out) {
   Op op; int rc = wide_op(len, OP_WIDE48, OP_WIDE64, &op);
-  return rc ? rc : run_host(ctx, op, bytes, nullptr, n, fq32_out, nullptr);
+  return rc ? rc : run_host(ctx, op, 0, bytes, nullptr, n, fq32_out, nullptr);
 }
 int d377_batch_encode_to_curve_wide(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* enc32_out) {
   Op op; int rc = wide_op(len, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, &op);
-  return rc ? rc : run_host(ctx, op, bytes, nullptr, n, enc32_out, nullptr);
+  return rc ? rc : run_host(ctx, op, 0, bytes, nullptr, n, enc32_out, nullptr);
 }
 int d377_batch_to_affine(d377_ctx* ctx, const uint64_t* xyzt, size_t n, uint64_t* xy) {
-  return run_host(ctx, OP_AFFINE, xyzt, nullptr, n, xy, nullptr);
+  return run_host(ctx, OP_AFFINE, 0, xyzt, nullptr, n, xy, nullptr);
 }
 int d377_batch_fq_from_wide_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len, size_t n,
                                       uint8_t* fq32_out) {
   Op op; int rc = wide_op(len, OP_WIDE48, OP_WIDE64, &op);
-  return rc ? rc : run_dev(ctx, dev, stream, op, bytes, nullptr, n, fq32_out, nullptr);
+  return rc ? rc : run_dev(ctx, dev, stream, op, 0, bytes, nullptr, n, fq32_out, nullptr);
 }
 int d377_batch_encode_to_curve_wide_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len, size_t n,
                                         uint8_t* enc32_out) {
   Op op; int rc = wide_op(len, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, &op);
-  return rc ? rc : run_dev(ctx, dev, stream, op, bytes, nullptr, n, enc32_out, nullptr);
+  return rc ? rc : run_dev(ctx, dev, stream, op, 0, bytes, nullptr, n, enc32_out, nullptr);
 }
 int d377_batch_to_affine_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t n, uint64_t* xy) {
-  return run_dev(ctx, dev, stream, OP_AFFINE, xyzt, nullptr, n, xy, nullptr);
+  return run_dev(ctx, dev, stream, OP_AFFINE, 0, xyzt, nullptr, n, xy, nullptr);
 }
 
 int d377_batch_sqrt_ratio_zeta_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* num32, const uint8_t* den32,
                                    size_t n, uint8_t* root32, uint8_t* was_square) {
-  return run_dev(ctx, dev, stream, OP_SQRT, num32, den32, n, root32, was_square);
+  return run_dev(ctx, dev, stream, OP_SQRT, D377_SQRT_ROOT_ARK, num32, den32, n, root32, was_square);
+}
+int d377_batch_sqrt_ratio_zeta_ex_dev(d377_ctx* ctx, int dev, void* stream, int root, const uint8_t* num32,
+                                      const uint8_t* den32, size_t n, uint8_t* root32, uint8_t* was_square) {
+  int rc = sqrt_root_ok(root);
+  return rc ? rc : run_dev(ctx, dev, stream, OP_SQRT, root, num32, den32, n, root32, was_square);
 }
 int d377_batch_decompress_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, size_t n, uint64_t* xyzt,
                               uint8_t* status) {
-  return run_dev(ctx, dev, stream, OP_DECOMPRESS, enc32, nullptr, n, xyzt, status);
+  return run_dev(ctx, dev, stream, OP_DECOMPRESS, 0, enc32, nullptr, n, xyzt, status);
 }
 int d377_batch_compress_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t n, uint8_t* enc32) {
-  return run_dev(ctx, dev, stream, OP_COMPRESS, xyzt, nullptr, n, enc32, nullptr);
+  return run_dev(ctx, dev, stream, OP_COMPRESS, 0, xyzt, nullptr, n, enc32, nullptr);
 }
 int d377_batch_roundtrip_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, size_t n, uint8_t* enc32_out,
                              uint8_t* status) {
-  return run_dev(ctx, dev, stream, OP_ROUNDTRIP, enc32, nullptr, n, enc32_out, status);
+  return run_dev(ctx, dev, stream, OP_ROUNDTRIP, 0, enc32, nullptr, n, enc32_out, status);
 }
 int d377_batch_scalar_mul_base_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* scalar32, size_t n,
                                    uint8_t* enc32_out) {
-  return run_dev(ctx, dev, stream, OP_MUL_BASE, scalar32, nullptr, n, enc32_out, nullptr);
+  return run_dev(ctx, dev, stream, OP_MUL_BASE, 0, scalar32, nullptr, n, enc32_out, nullptr);
 }
 int d377_batch_scalar_mul_var_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, const uint8_t* scalar32,
                                   size_t n, uint8_t* enc32_out, uint8_t* status) {
-  return run_dev(ctx, dev, stream, OP_MUL_VAR, enc32, scalar32, n, enc32_out, status);
+  return run_dev(ctx, dev, stream, OP_MUL_VAR, 0, enc32, scalar32, n, enc32_out, status);
 }
 int d377_batch_encode_to_curve_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* fq32, size_t n,
                                    uint8_t* enc32_out) {
-  return run_dev(ctx, dev, stream, OP_ENCODE, fq32, nullptr, n, enc32_out, nullptr);
+  return run_dev(ctx, dev, stream, OP_ENCODE, 0, fq32, nullptr, n, enc32_out, nullptr);
 }
 int d377_batch_hash_to_curve_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* r1_32, const uint8_t* r2_32,
                                  size_t n, uint8_t* enc32_out) {
-  return run_dev(ctx, dev, stream, OP_HASH, r1_32, r2_32, n, enc32_out, nullptr);
+  return run_dev(ctx, dev, stream, OP_HASH, 0, r1_32, r2_32, n, enc32_out, nullptr);
+}
+
+int d377_batch_sharded_dev(d377_ctx* ctx, int root_dev, void* stream, int op, const void* in0, const void* in1, size_t n,
+                           void* out0, void* out1) {
+  Op o;
+  switch (op) {
+    case D377_OP_SQRT_RATIO_ZETA: o = OP_SQRT; break;
+    case D377_OP_DECOMPRESS: o = OP_DECOMPRESS; break;
+    case D377_OP_COMPRESS: o = OP_COMPRESS; break;
+    case D377_OP_ROUNDTRIP: o = OP_ROUNDTRIP; break;
+    case D377_OP_SCALAR_MUL_BASE: o = OP_MUL_BASE; break;
+    case D377_OP_SCALAR_MUL_VAR: o = OP_MUL_VAR; break;
+    case D377_OP_ENCODE_TO_CURVE: o = OP_ENCODE; break;
+    case D377_OP_HASH_TO_CURVE: o = OP_HASH; break;
+    default: return fail(D377_ERR_ARG, "%s", "unknown D377_OP_* code");
+  }
+  return run_sharded_dev(ctx, root_dev, stream, o, 0, in0, in1, n, out0, out1);
 }
 
 }  // extern "C"

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <mutex>
 #include <vector>
 
@@ -23,10 +24,26 @@ inline int fail(int code, const char* fmt, const char* detail) {
     if (e_ != hipSuccess) return ::d377::fail(D377_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
   } while (0)
 
+// A per-device scratch area that kernels launched on ANY stream may use (the variable-base window
+// tables, the MSM workspace).  Users are serialised on the device: a launch first makes its stream wait
+// for the previous user's completion event and records its own afterwards, so two `_dev` calls on
+// different streams (or a host-path call on the context's private stream while a `_dev` launch is in
+// flight) queue up instead of racing.  Host-side access to this struct is under d377_ctx::mu.
+struct ScratchGuard {
+  hipEvent_t ev = nullptr;
+  bool used = false;
+  int init() { HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); return D377_OK; }
+  void destroy() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; used = false; }
+  int acquire(hipStream_t s) { if (used) HIP_TRY(hipStreamWaitEvent(s, ev, 0)); return D377_OK; }
+  int release(hipStream_t s) { HIP_TRY(hipEventRecord(ev, s)); used = true; return D377_OK; }
+  int drain() { if (used) HIP_TRY(hipEventSynchronize(ev)); return D377_OK; }   // before freeing the area
+};
+
 // workspace of the multi-scalar multiplication (msm.hip), grow-only
 struct MsmWorkspace {
   uint8_t* mem = nullptr;
   size_t cap = 0;
+  ScratchGuard guard;
 };
 
 struct DeviceState {
@@ -37,6 +54,7 @@ struct DeviceState {
   uint32_t* fbase = nullptr;
   uint32_t* vb_scratch = nullptr;
   int vb_blocks = 0;
+  ScratchGuard vb_guard;
   hipStream_t stream = nullptr;          // compute stream of the host-pointer entry points
   hipStream_t copy_stream = nullptr;     // PCIe copies of the pipelined host path
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -46,30 +64,54 @@ struct DeviceState {
   size_t cap[4] = {0, 0, 0, 0};
   uint8_t* buf2[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t cap2[4] = {0, 0, 0, 0};
+  // staging of the sharded device-pointer path (slices of a batch that lives on another device)
+  uint8_t* shard[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t shard_cap[4] = {0, 0, 0, 0};
+  hipEvent_t ev_shard = nullptr;
   MsmWorkspace msm;
   SqrtTables tables() const { return SqrtTables{gtab, s_lookup}; }
 };
 
-inline int ensure(DeviceState& d, int slot, size_t bytes) {
-  if (bytes <= d.cap[slot]) return D377_OK;
-  if (d.buf[slot]) HIP_TRY(hipFree(d.buf[slot]));
-  d.buf[slot] = nullptr; d.cap[slot] = 0;
-  size_t want = bytes + bytes / 4 + 4096;
-  HIP_TRY(hipMalloc(&d.buf[slot], want));
-  d.cap[slot] = want;
+inline int grow(uint8_t*& p, size_t& cap, size_t bytes, size_t slack) {
+  if (bytes <= cap) return D377_OK;
+  if (p) HIP_TRY(hipFree(p));
+  p = nullptr; cap = 0;
+  HIP_TRY(hipMalloc(&p, bytes + slack));
+  cap = bytes + slack;
   return D377_OK;
 }
-
-inline int ensure2(DeviceState& d, int slot, size_t bytes) {
-  if (bytes <= d.cap2[slot]) return D377_OK;
-  if (d.buf2[slot]) HIP_TRY(hipFree(d.buf2[slot]));
-  d.buf2[slot] = nullptr; d.cap2[slot] = 0;
-  HIP_TRY(hipMalloc(&d.buf2[slot], bytes + 4096));
-  d.cap2[slot] = bytes + 4096;
-  return D377_OK;
-}
+inline int ensure(DeviceState& d, int slot, size_t bytes) { return grow(d.buf[slot], d.cap[slot], bytes, bytes / 4 + 4096); }
+inline int ensure2(DeviceState& d, int slot, size_t bytes) { return grow(d.buf2[slot], d.cap2[slot], bytes, 4096); }
+inline int ensure_shard(DeviceState& d, int slot, size_t bytes) { return grow(d.shard[slot], d.shard_cap[slot], bytes, bytes / 4 + 4096); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Synchronises a set of streams when the enclosing function returns with an error after work has been
+// enqueued: no copy into caller memory (or into a local vector) may still be in flight once we return.
+struct SyncOnError {
+  int* rc;
+  int device;
+  hipStream_t a, b;
+  ~SyncOnError() {
+    if (*rc == D377_OK) return;
+    char saved[sizeof d377_g_err];
+    memcpy(saved, d377_g_err, sizeof saved);            // keep the first error text
+    (void)hipSetDevice(device);
+    if (a) (void)hipStreamSynchronize(a);
+    if (b) (void)hipStreamSynchronize(b);
+    memcpy(d377_g_err, saved, sizeof saved);
+  }
+};
+
+// op codes of the generic launcher in d377.hip (shared with the sharded path)
+enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE,
+          OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE, OP_NEG, OP_IS_IDENTITY, OP_FQ_BIN,
+          OP_FQ_UN, OP_FQ_CHECKED, OP_FQ_TO_BYTES, OP_FR_MOD, OP_FR_CHECKED };
+
+// D377_DEBUG_DEVICE_DELAY_MS (tests only): every per-device worker of a multi-device host call sleeps this
+// long before it touches its device, which makes "the devices work concurrently" observable on a box
+// with a single GPU listed twice.
+int debug_device_delay_ms();
 
 }  // namespace d377
 

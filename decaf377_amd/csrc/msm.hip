@@ -22,6 +22,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/decaf377_amd.h"
@@ -70,15 +73,22 @@ __device__ __forceinline__ int msm_digit(const uint32_t k[8], int w, int c, int 
   return (int)d;
 }
 
+// the square-root power table lives in LDS only in the instantiation that decompresses: the Element
+// form needs none, and 72 KiB of LDS per block would cap it at 2 blocks per CU for nothing
+template <bool ENCODED> struct PrepareLds { uint32_t tab[POW_TAB * NL * BLOCK]; };
+template <> struct PrepareLds<false> { uint32_t tab[1]; };
+
 template <bool ENCODED>
-__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+__global__ void __launch_bounds__(BLOCK, ENCODED ? WAVES_PER_SIMD : 4)
 k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, int c, int W, int nb,
               uint32_t* pts, int16_t* digits, uint32_t* rank, uint32_t* count, uint8_t* status) {
-  D377_POW_LDS();
+  __shared__ PrepareLds<ENCODED> lds_;
+  LdsPowTab pt;
+  pt.col = lds_.tab + threadIdx.x;
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     ge g;
     uint32_t bad = 0;
-    if (ENCODED) {
+    if constexpr (ENCODED) {
       uint32_t w[8];
       load32(reinterpret_cast<const uint8_t*>(pts_in), i, w);
       bad = ge_decompress(T, pt, w, &g);
@@ -344,14 +354,20 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_rank = carve((size_t)W * n * 4);
   const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
   const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
-  const size_t o_f0 = carve((size_t)W * ((nchunks + FOLD - 1) / FOLD) * PT_WORDS * 4);
-  const size_t o_f1 = carve((size_t)W * PT_WORDS * 4 * 2);
+  // ping-pong buffers of the 32-to-1 folds, sized from the fold sequence itself: the first fold writes
+  // ceil(nchunks / FOLD) records per window into f0, the second ceil(that / FOLD) into f1, and so on
+  const size_t m1 = (size_t)(nchunks + FOLD - 1) / FOLD, m2 = (m1 + FOLD - 1) / FOLD;
+  const size_t o_f0 = carve((size_t)W * m1 * PT_WORDS * 4);
+  const size_t o_f1 = carve((size_t)W * m2 * PT_WORDS * 4);
+  int rc;
   if (off > d.msm.cap) {
+    if ((rc = d.msm.guard.drain())) return rc;          // a launch on another stream may still be using the old area
     if (d.msm.mem) HIP_TRY(hipFree(d.msm.mem));
     d.msm.mem = nullptr; d.msm.cap = 0;
     HIP_TRY(hipMalloc(&d.msm.mem, off + off / 8));
     d.msm.cap = off + off / 8;
   }
+  if ((rc = d.msm.guard.acquire(s))) return rc;         // one workspace per device: queue behind its last user
   uint8_t* m = d.msm.mem;
   uint32_t* pts = (uint32_t*)(m + o_pts);
   int16_t* dig = (int16_t*)(m + o_dig);
@@ -380,15 +396,45 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   int mcur = nchunks;
   uint32_t* bufs[2] = {f0, f1};
   int which = 0;
+  const size_t fold_cap[2] = {m1, m2};
   while (mcur > 1) {
     const int mout = (mcur + FOLD - 1) / FOLD;
+    if ((size_t)mout > fold_cap[which]) return fail(D377_ERR_ARG, "%s", "msm: fold buffer too small (internal)");
     uint32_t* o = bufs[which];
     hipLaunchKernelGGL(k_msm_fold, dim3(grid_of(d, (size_t)W * mout)), dim3(BLOCK), 0, s, cur_in, W, mcur, mout, o);
     cur_in = o; mcur = mout; which ^= 1;
   }
   hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, T, cur_in, W, c, enc_out, xyzt_out);
   HIP_TRY(hipGetLastError());
-  return D377_OK;
+  return d.msm.guard.release(s);
+}
+
+// one device's share of a host batch: copies in, MSM, partial sum (Element record) and statuses out, synchronised
+int msm_one(DeviceState& d, bool encoded, const uint8_t* pts_in, const uint8_t* scalars, size_t cnt, uint8_t* enc_out,
+            uint64_t* partial_out, uint8_t* status) {
+  HIP_TRY(hipSetDevice(d.id));
+  int rc = D377_OK;
+  SyncOnError guard{&rc, d.id, d.stream, nullptr};
+  auto body = [&]() -> int {
+    const size_t rec = encoded ? 32 : 128;
+    int r;
+    if ((r = ensure(d, 0, cnt * rec + 16))) return r;
+    if ((r = ensure(d, 1, cnt * 32 + 16))) return r;
+    if ((r = ensure(d, 2, 32 + 128))) return r;
+    if ((r = ensure(d, 3, cnt + 16))) return r;
+    if (cnt) {
+      HIP_TRY(hipMemcpyAsync(d.buf[0], pts_in, cnt * rec, hipMemcpyHostToDevice, d.stream));
+      HIP_TRY(hipMemcpyAsync(d.buf[1], scalars, cnt * 32, hipMemcpyHostToDevice, d.stream));
+    }
+    if ((r = msm_launch(d, d.stream, encoded, d.buf[0], d.buf[1], cnt, d.buf[2], (uint64_t*)(d.buf[2] + 32), d.buf[3]))) return r;
+    HIP_TRY(hipMemcpyAsync(partial_out, d.buf[2] + 32, 128, hipMemcpyDeviceToHost, d.stream));
+    if (encoded && cnt) HIP_TRY(hipMemcpyAsync(status, d.buf[3], cnt, hipMemcpyDeviceToHost, d.stream));
+    if (enc_out) HIP_TRY(hipMemcpyAsync(enc_out, d.buf[2], 32, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    return D377_OK;
+  };
+  rc = body();
+  return rc;
 }
 
 int msm_host(d377_ctx* ctx, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n, uint8_t* enc_out,
@@ -398,39 +444,43 @@ int msm_host(d377_ctx* ctx, bool encoded, const void* pts_in, const uint8_t* sca
   std::lock_guard<std::mutex> lock(ctx->mu);
   const size_t nd = ctx->devs.size();
   const size_t rec = encoded ? 32 : 128;
-  const size_t per = (n + nd - 1) / nd;
   std::vector<uint64_t> partial(nd * 16, 0);
-  size_t used = 0;
   int rc;
+  if (nd == 1) {
+    if ((rc = msm_one(ctx->devs[0], encoded, (const uint8_t*)pts_in, scalars, n, enc_out, partial.data(), status))) return rc;
+    if (xyzt_out) memcpy(xyzt_out, partial.data(), 128);
+    return D377_OK;
+  }
+  // several devices: one host thread each (pageable copies block their issuing thread), joined before
+  // anything else happens; then one small cross-device reduction of the partial sums on device 0
+  const size_t per = (n + nd - 1) / nd;
+  std::vector<int> rcs(nd, D377_OK);
+  std::vector<std::string> errs(nd);
+  std::vector<std::thread> workers;
+  const int delay = debug_device_delay_ms();
+  size_t used = 0;
   for (size_t k = 0; k < nd; ++k) {
-    DeviceState& d = ctx->devs[k];
     const size_t lo = per * k;
     if (k > 0 && lo >= n) break;
     const size_t cnt = (lo >= n) ? 0 : ((lo + per <= n) ? per : n - lo);
-    HIP_TRY(hipSetDevice(d.id));
-    if ((rc = ensure(d, 0, cnt * rec + 16))) return rc;
-    if ((rc = ensure(d, 1, cnt * 32 + 16))) return rc;
-    if ((rc = ensure(d, 2, 32 + 128))) return rc;
-    if ((rc = ensure(d, 3, cnt + 16))) return rc;
-    if (cnt) {
-      HIP_TRY(hipMemcpyAsync(d.buf[0], (const uint8_t*)pts_in + lo * rec, cnt * rec, hipMemcpyHostToDevice, d.stream));
-      HIP_TRY(hipMemcpyAsync(d.buf[1], scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, d.stream));
-    }
-    if ((rc = msm_launch(d, d.stream, encoded, d.buf[0], d.buf[1], cnt, d.buf[2], (uint64_t*)(d.buf[2] + 32), d.buf[3])))
-      return rc;
-    HIP_TRY(hipMemcpyAsync(partial.data() + 16 * k, d.buf[2] + 32, 128, hipMemcpyDeviceToHost, d.stream));
-    if (encoded && cnt) HIP_TRY(hipMemcpyAsync(status + lo, d.buf[3], cnt, hipMemcpyDeviceToHost, d.stream));
-    if (nd == 1) HIP_TRY(hipMemcpyAsync(enc_out, d.buf[2], 32, hipMemcpyDeviceToHost, d.stream));
     ++used;
+    workers.emplace_back([&, k, lo, cnt]() {
+      if (delay > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay));
+      rcs[k] = msm_one(ctx->devs[k], encoded, (const uint8_t*)pts_in + lo * rec, scalars + lo * 32, cnt, nullptr,
+                       partial.data() + 16 * k, (encoded && cnt) ? status + lo : nullptr);
+      if (rcs[k] != D377_OK) errs[k] = d377_g_err;
+    });
   }
-  for (size_t k = 0; k < used; ++k) {
-    HIP_TRY(hipSetDevice(ctx->devs[k].id));
-    HIP_TRY(hipStreamSynchronize(ctx->devs[k].stream));
-  }
-  if (nd > 1) {   // one small cross-device reduction: add the per-GPU partial sums on device 0
-    DeviceState& d = ctx->devs[0];
-    HIP_TRY(hipSetDevice(d.id));
-    if ((rc = ensure(d, 0, used * 128))) return rc;
+  for (auto& w : workers) w.join();
+  for (size_t k = 0; k < used; ++k)
+    if (rcs[k] != D377_OK) return fail(rcs[k], "%s", errs[k].c_str());
+  DeviceState& d = ctx->devs[0];
+  HIP_TRY(hipSetDevice(d.id));
+  rc = D377_OK;
+  SyncOnError guard{&rc, d.id, d.stream, nullptr};
+  auto combine = [&]() -> int {
+    int r;
+    if ((r = ensure(d, 0, used * 128))) return r;
     HIP_TRY(hipMemcpyAsync(d.buf[0], partial.data(), used * 128, hipMemcpyHostToDevice, d.stream));
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, d.stream, d.tables(), (const uint64_t*)d.buf[0], used, d.buf[2],
                        (uint64_t*)(d.buf[2] + 32));
@@ -438,7 +488,10 @@ int msm_host(d377_ctx* ctx, bool encoded, const void* pts_in, const uint8_t* sca
     HIP_TRY(hipMemcpyAsync(enc_out, d.buf[2], 32, hipMemcpyDeviceToHost, d.stream));
     HIP_TRY(hipMemcpyAsync(partial.data(), d.buf[2] + 32, 128, hipMemcpyDeviceToHost, d.stream));
     HIP_TRY(hipStreamSynchronize(d.stream));
-  }
+    return D377_OK;
+  };
+  rc = combine();
+  if (rc) return rc;
   if (xyzt_out) memcpy(xyzt_out, partial.data(), 128);
   return D377_OK;
 }
@@ -450,6 +503,7 @@ int msm_dev(d377_ctx* ctx, int dev, void* stream, bool encoded, const void* pts_
   if (!enc_out || (n && (!pts_in || !scalars)) || (encoded && n && !status)) return fail(D377_ERR_ARG, "%s", "null buffer");
   if (!aligned16(pts_in) || !aligned16(scalars) || !aligned16(enc_out) || !aligned16(xyzt_out))
     return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
+  std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceState& d = ctx->devs[(size_t)dev];
   HIP_TRY(hipSetDevice(d.id));
   return msm_launch(d, (hipStream_t)stream, encoded, pts_in, scalars, n, enc_out, xyzt_out, status);
@@ -480,6 +534,9 @@ int d377_sum_elements_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* 
   if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
   if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
   if (!enc32_out || (m && !xyzt)) return fail(D377_ERR_ARG, "%s", "null buffer");
+  if (!aligned16(xyzt) || !aligned16(enc32_out) || !aligned16(xyzt_out))
+    return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
+  std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceState& d = ctx->devs[(size_t)dev];
   HIP_TRY(hipSetDevice(d.id));
   hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, (hipStream_t)stream, d.tables(), xyzt, m, enc32_out, xyzt_out);

@@ -30,9 +30,39 @@ def _is_torch(x):
 
 
 def _rows(a):
-    if a.ndim < 2:
+    if a.ndim < 1:
         raise ValueError("expected a [n, k] array of packed records")
     return int(a.shape[0])
+
+
+# row layouts of the packed records (trailing shape, element kind): the native code reads and writes
+# n * (that many bytes) unconditionally, so every array is checked against these before a call
+ENC = ((32,), "u8")          # Encoding / Fq / Fr byte strings
+ELEM = ((16,), "u64")        # Element: X, Y, Z, T as 4 Montgomery limbs each
+FQM = ((4,), "u64")          # Fq as 4 Montgomery limbs
+AFF = ((8,), "u64")          # affine x, y
+FLAG = ((), "u8")            # one status / flag byte per element
+SQRT_ROOT = {"ark": 0, "arkworks": 0, "min_curve": 1}
+SHARD_OPS = {"sqrt_ratio_zeta": 0, "decompress": 1, "compress": 2, "roundtrip": 3, "scalar_mul_base": 4,
+             "scalar_mul_var": 5, "encode_to_curve": 6, "hash_to_curve": 7}
+
+
+def _check(a, spec, n, what, device=None):
+    """Raises ValueError unless `a` is a contiguous-able [n, *tail] array of the right element type
+    (and, for torch tensors, lives on `device`)."""
+    tail, kind = spec
+    shape = tuple(int(x) for x in a.shape)
+    if shape != (n,) + tail:
+        raise ValueError("%s: expected shape %s, got %s" % (what, (n,) + tail, shape))
+    if _is_torch(a):
+        import torch
+        ok = a.dtype == torch.uint8 if kind == "u8" else a.dtype in (torch.int64, torch.uint64)
+        if device is not None and a.device != device:
+            raise ValueError("%s: tensor on %s, expected %s" % (what, a.device, device))
+    else:
+        ok = a.dtype == np.uint8 if kind == "u8" else a.dtype in (np.uint64, np.int64)
+    if not ok:
+        raise ValueError("%s: expected %s elements, got %s" % (what, "uint8" if kind == "u8" else "uint64/int64", a.dtype))
 
 
 class Context:
@@ -61,76 +91,123 @@ class Context:
             pass
 
     # -- plumbing ---------------------------------------------------------------------------
-    def _run(self, name, ins, outs_spec, n, outs=None):
-        """ins: list of arrays; outs_spec: list of (shape_tail, numpy dtype).  Host or device
-        path by the type of the first input.  `outs` lets a caller reuse output tensors."""
+    def _dev_index(self, dev):
+        if dev.type != "cuda":
+            raise _native.NativeError("torch tensors must live on the GPU (there is no CPU path)")
+        if dev.index not in self.device_ids:
+            raise _native.NativeError("tensor on cuda:%s but context owns %s" % (dev.index, self.device_ids))
+        return self.device_ids.index(dev.index)
+
+    def _run(self, name, ins, in_specs, out_specs, outs=None, pre=(), sharded_op=None):
+        """ins: input arrays (specs in `in_specs`); out_specs: row layouts of the outputs.  Host or
+        device path by the type of the first input; `pre` = extra integer arguments that precede the
+        buffers in the C signature; `outs` lets a caller reuse output arrays (checked like inputs).
+        sharded_op: run through d377_batch_sharded_dev (HBM-resident batch split over the context's GPUs)."""
+        n = _rows(ins[0])
+        np_dt = {"u8": np.uint8, "u64": np.uint64}
         if _is_torch(ins[0]):
             import torch
             dev = ins[0].device
-            if dev.type != "cuda":
-                raise _native.NativeError("torch tensors must live on the GPU (there is no CPU path)")
-            if dev.index not in self.device_ids:
-                raise _native.NativeError("tensor on cuda:%s but context owns %s" % (dev.index, self.device_ids))
-            tdt = {np.uint8: torch.uint8, np.uint64: torch.int64}
+            di = self._dev_index(dev)
+            for a, spec in zip(ins, in_specs):
+                _check(a, spec, n, name + " input", dev)
+            tdt = {"u8": torch.uint8, "u64": torch.int64}
             ins = [t.contiguous() for t in ins]
             if outs is None:
-                outs = [torch.empty((n,) + tail, dtype=tdt[dt], device=dev) for tail, dt in outs_spec]
+                outs = [torch.empty((n,) + tail, dtype=tdt[k], device=dev) for tail, k in out_specs]
+            else:
+                if len(outs) != len(out_specs):
+                    raise ValueError("%s: expected %d output arrays" % (name, len(out_specs)))
+                for a, spec in zip(outs, out_specs):
+                    _check(a, spec, n, name + " output", dev)
+                    if not a.is_contiguous():
+                        raise ValueError("%s output must be contiguous" % name)
             stream = torch.cuda.current_stream(dev).cuda_stream
-            args = [self._h, self.device_ids.index(dev.index), ctypes.c_void_p(stream)]
-            args += [ctypes.c_void_p(t.data_ptr()) for t in ins] + [ctypes.c_size_t(n)]
-            args += [ctypes.c_void_p(t.data_ptr()) for t in outs]
+            bufs = [ctypes.c_void_p(t.data_ptr()) for t in ins]
+            obufs = [ctypes.c_void_p(t.data_ptr()) for t in outs]
+            if sharded_op is not None:
+                bufs += [None] * (2 - len(bufs))
+                obufs += [None] * (2 - len(obufs))
+                _native.check(self._lib.d377_batch_sharded_dev(self._h, di, ctypes.c_void_p(stream), sharded_op,
+                                                               bufs[0], bufs[1], ctypes.c_size_t(n), obufs[0], obufs[1]))
+                return outs
+            args = [self._h, di, ctypes.c_void_p(stream)] + list(pre) + bufs + [ctypes.c_size_t(n)] + obufs
             _native.check(getattr(self._lib, name + "_dev")(*args))
             return outs
+        if sharded_op is not None:
+            raise ValueError("the sharded path takes torch CUDA tensors (host arrays are sharded by the host path)")
         ins = [np.ascontiguousarray(a) for a in ins]
+        for a, spec in zip(ins, in_specs):
+            _check(a, spec, n, name + " input")
         if outs is None:
-            outs = [np.empty((n,) + tail, dtype=dt) for tail, dt in outs_spec]   # np.zeros would page-fault inside the D2H copy
-        args = [self._h] + [a.ctypes.data_as(ctypes.c_void_p) for a in ins] + [ctypes.c_size_t(n)]
+            outs = [np.empty((n,) + tail, dtype=np_dt[k]) for tail, k in out_specs]   # np.zeros would page-fault inside the D2H copy
+        else:
+            if len(outs) != len(out_specs):
+                raise ValueError("%s: expected %d output arrays" % (name, len(out_specs)))
+            for a, spec in zip(outs, out_specs):
+                _check(a, spec, n, name + " output")
+                if not a.flags["C_CONTIGUOUS"]:
+                    raise ValueError("%s output must be contiguous" % name)
+        args = [self._h] + list(pre) + [a.ctypes.data_as(ctypes.c_void_p) for a in ins] + [ctypes.c_size_t(n)]
         args += [a.ctypes.data_as(ctypes.c_void_p) for a in outs]
         _native.check(getattr(self._lib, name)(*args))
         return outs
 
     # -- the batch operations (C ABI names) ---------------------------------------------------
-    def sqrt_ratio_zeta(self, num32, den32, outs=None):
-        return self._run("d377_batch_sqrt_ratio_zeta", [num32, den32],
-                         [((32,), np.uint8), ((), np.uint8)], _rows(num32), outs)
+    def sqrt_ratio_zeta(self, num32, den32, outs=None, root="ark"):
+        """root: "ark" (Sarkar tables, src/ark_curve/invsqrt.rs:75-166) or "min_curve" (Tonelli-Shanks
+        seeded with 11^m, src/min_curve/invsqrt.rs:11-95): same flags, root negated about half the time."""
+        return self._run("d377_batch_sqrt_ratio_zeta_ex", [num32, den32], [ENC, ENC], [ENC, FLAG], outs,
+                         pre=(ctypes.c_int(SQRT_ROOT[root]),))
 
     def decompress(self, enc32, outs=None):
-        return self._run("d377_batch_decompress", [enc32], [((16,), np.uint64), ((), np.uint8)], _rows(enc32), outs)
+        return self._run("d377_batch_decompress", [enc32], [ENC], [ELEM, FLAG], outs)
 
     def compress(self, xyzt, outs=None):
-        return self._run("d377_batch_compress", [xyzt], [((32,), np.uint8)], _rows(xyzt), outs)[0]
+        return self._run("d377_batch_compress", [xyzt], [ELEM], [ENC], outs)[0]
 
     def roundtrip(self, enc32, outs=None):
-        return self._run("d377_batch_roundtrip", [enc32], [((32,), np.uint8), ((), np.uint8)], _rows(enc32), outs)
+        return self._run("d377_batch_roundtrip", [enc32], [ENC], [ENC, FLAG], outs)
 
     def scalar_mul_base(self, scalar32, outs=None):
-        return self._run("d377_batch_scalar_mul_base", [scalar32], [((32,), np.uint8)], _rows(scalar32), outs)[0]
+        return self._run("d377_batch_scalar_mul_base", [scalar32], [ENC], [ENC], outs)[0]
 
     def scalar_mul_var(self, enc32, scalar32, outs=None):
-        return self._run("d377_batch_scalar_mul_var", [enc32, scalar32],
-                         [((32,), np.uint8), ((), np.uint8)], _rows(enc32), outs)
+        return self._run("d377_batch_scalar_mul_var", [enc32, scalar32], [ENC, ENC], [ENC, FLAG], outs)
 
     def encode_to_curve(self, fq32, outs=None):
-        return self._run("d377_batch_encode_to_curve", [fq32], [((32,), np.uint8)], _rows(fq32), outs)[0]
+        return self._run("d377_batch_encode_to_curve", [fq32], [ENC], [ENC], outs)[0]
 
     def hash_to_curve(self, r1_32, r2_32, outs=None):
-        return self._run("d377_batch_hash_to_curve", [r1_32, r2_32], [((32,), np.uint8)], _rows(r1_32), outs)[0]
-
+        return self._run("d377_batch_hash_to_curve", [r1_32, r2_32], [ENC, ENC], [ENC], outs)[0]
 
     def add(self, p_xyzt, q_xyzt, outs=None):
-        return self._run("d377_batch_add", [p_xyzt, q_xyzt], [((16,), np.uint64)], _rows(p_xyzt), outs)[0]
+        return self._run("d377_batch_add", [p_xyzt, q_xyzt], [ELEM, ELEM], [ELEM], outs)[0]
 
     def double(self, p_xyzt, outs=None):
-        return self._run("d377_batch_double", [p_xyzt], [((16,), np.uint64)], _rows(p_xyzt), outs)[0]
+        return self._run("d377_batch_double", [p_xyzt], [ELEM], [ELEM], outs)[0]
 
     def eq(self, p_xyzt, q_xyzt, outs=None):
-        return self._run("d377_batch_eq", [p_xyzt, q_xyzt], [((), np.uint8)], _rows(p_xyzt), outs)[0]
+        return self._run("d377_batch_eq", [p_xyzt, q_xyzt], [ELEM, ELEM], [FLAG], outs)[0]
 
     def neg(self, p_xyzt, outs=None):
-        return self._run("d377_batch_neg", [p_xyzt], [((16,), np.uint64)], _rows(p_xyzt), outs)[0]
+        return self._run("d377_batch_neg", [p_xyzt], [ELEM], [ELEM], outs)[0]
 
     def is_identity(self, p_xyzt, outs=None):
-        return self._run("d377_batch_is_identity", [p_xyzt], [((), np.uint8)], _rows(p_xyzt), outs)[0]
+        return self._run("d377_batch_is_identity", [p_xyzt], [ELEM], [FLAG], outs)[0]
+
+    def sharded(self, op, in0, in1=None, outs=None):
+        """d377_batch_sharded_dev: an HBM-resident batch (torch CUDA tensors on one device of this context)
+        split into contiguous slices over all the context's GPUs by peer copies over xGMI.  op is one of
+        SHARD_OPS; inputs and outputs are those of the method of the same name."""
+        specs = {"sqrt_ratio_zeta": ([ENC, ENC], [ENC, FLAG]), "decompress": ([ENC], [ELEM, FLAG]),
+                 "compress": ([ELEM], [ENC]), "roundtrip": ([ENC], [ENC, FLAG]), "scalar_mul_base": ([ENC], [ENC]),
+                 "scalar_mul_var": ([ENC, ENC], [ENC, FLAG]), "encode_to_curve": ([ENC], [ENC]),
+                 "hash_to_curve": ([ENC, ENC], [ENC])}[op]
+        ins = [in0] if in1 is None else [in0, in1]
+        if len(ins) != len(specs[0]):
+            raise ValueError("%s takes %d input arrays" % (op, len(specs[0])))
+        return self._run("d377_batch_sharded_dev:" + op, ins, specs[0], specs[1], outs, sharded_op=SHARD_OPS[op])
 
     def identity(self):
         """Element::IDENTITY as one [16] u64 record (src/min_curve/element.rs:53-58)."""
@@ -149,6 +226,7 @@ class Context:
     def fr_from_le_bytes_mod_order(self, bytes32):
         """Fr::from_le_bytes_mod_order on [n, 32] byte strings -> canonical [n, 32] (src/fields/fr.rs:82-94)."""
         b = np.ascontiguousarray(bytes32, dtype=np.uint8)
+        _check(b, ENC, _rows(b), "fr_from_le_bytes_mod_order input")
         out = np.empty_like(b)
         _native.check(self._lib.d377_batch_fr_from_le_bytes_mod_order(
             self._h, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b.shape[0]), out.ctypes.data_as(ctypes.c_void_p)))
@@ -157,6 +235,7 @@ class Context:
     def fr_from_bytes_checked(self, bytes32):
         """Fr::from_bytes_checked (src/fields/fr.rs:100-107) -> ([n, 32], status[n])."""
         b = np.ascontiguousarray(bytes32, dtype=np.uint8)
+        _check(b, ENC, _rows(b), "fr_from_bytes_checked input")
         out = np.empty_like(b)
         st = np.zeros(max(b.shape[0], 1), np.uint8)
         _native.check(self._lib.d377_batch_fr_from_bytes_checked(
@@ -169,34 +248,62 @@ class Context:
 
     def fq_op(self, op, a, b=None):
         """Fq add/sub/mul (binary) and square/neg/inverse (unary) on [n, 4] u64 Montgomery records
-        (src/fields/fq/u64/wrapper.rs:99-132) -> (out [n, 4], status [n]); status 1 only for inverse(0)."""
+        (src/fields/fq/u64/wrapper.rs:99-132) -> (out [n, 4], status [n]); status 1 only for inverse(0).
+        numpy arrays (host path) or torch CUDA tensors (device path)."""
         code = self.FQ_OPS[op]
+        binary = code <= 2
+        if binary and b is None:
+            raise ValueError("fq_op %s takes two operands" % op)
+        if _is_torch(a):
+            import torch
+            n = _rows(a)
+            dev = a.device
+            di = self._dev_index(dev)
+            _check(a, FQM, n, "fq_op input", dev)
+            if binary:
+                _check(b, FQM, n, "fq_op input", dev)
+            a = a.contiguous()
+            bb = b.contiguous() if binary else None
+            out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+            st = torch.zeros((max(n, 1),), dtype=torch.uint8, device=dev)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _native.check(self._lib.d377_batch_fq_op_dev(self._h, di, stream, code, ctypes.c_void_p(a.data_ptr()),
+                                                         ctypes.c_void_p(bb.data_ptr()) if binary else None,
+                                                         ctypes.c_size_t(n), ctypes.c_void_p(out.data_ptr()),
+                                                         ctypes.c_void_p(st.data_ptr())))
+            return out, st[:n]
         a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
         n = a.shape[0]
         out = np.empty((n, 4), np.uint64)
         st = np.zeros(max(n, 1), np.uint8)
         p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
         bb = None
-        if code <= 2:
+        if binary:
             bb = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+            if bb.shape[0] != n:
+                raise ValueError("fq_op: operands have %d and %d rows" % (n, bb.shape[0]))
         _native.check(self._lib.d377_batch_fq_op(self._h, code, p(a), p(bb) if bb is not None else None,
                                                  ctypes.c_size_t(n), p(out), p(st)))
         return out, st[:n]
 
     def fq_from_bytes_checked(self, bytes32):
         """Fq::from_bytes_checked (src/fields/fq.rs:108-115) -> ([n, 4] u64, status[n])."""
-        return self._run("d377_batch_fq_from_bytes_checked", [bytes32], [((4,), np.uint64), ((), np.uint8)], _rows(bytes32))
+        return self._run("d377_batch_fq_from_bytes_checked", [bytes32], [ENC], [FQM, FLAG])
 
     def fq_to_bytes(self, a):
         """Fq::to_bytes_le on [n, 4] u64 Montgomery records -> [n, 32] u8."""
-        return self._run("d377_batch_fq_to_bytes", [a], [((32,), np.uint8)], _rows(a))[0]
+        return self._run("d377_batch_fq_to_bytes", [a], [FQM], [ENC])[0]
 
     # -- wide byte strings and affine normalisation -----------------------------------------------
     def _wide(self, name, data):
+        if data.ndim != 2 or int(data.shape[1]) not in (48, 64):
+            raise ValueError("%s: expected [n, 48] or [n, 64] byte strings, got shape %s" % (name, tuple(data.shape)))
         n, length = int(data.shape[0]), int(data.shape[1])
+        _check(data, ((length,), "u8"), n, name + " input")
         if _is_torch(data):
             import torch
             dev = data.device
+            self._dev_index(dev)
             out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _native.check(getattr(self._lib, name + "_dev")(self._h, self.device_ids.index(dev.index), stream,
@@ -220,7 +327,7 @@ class Context:
 
     def to_affine(self, xyzt, outs=None):
         """CurveGroup::normalize_batch: [n, 16] Elements -> [n, 8] (x, y Montgomery limbs)."""
-        return self._run("d377_batch_to_affine", [xyzt], [((8,), np.uint64)], _rows(xyzt), outs)[0]
+        return self._run("d377_batch_to_affine", [xyzt], [ELEM], [AFF], outs)[0]
 
     # -- multi-scalar multiplication -------------------------------------------------------------
     def msm(self, points, scalar32, encoded=None):
@@ -228,11 +335,17 @@ class Context:
         points: [n, 16] u64 Elements or [n, 32] u8 Encodings (detected by the row width).
         Returns (enc[32] u8, xyzt[16] u64, status[n] or None)."""
         n = _rows(points)
+        if points.ndim != 2 or int(points.shape[1]) not in (16, 32):
+            raise ValueError("msm: points must be [n, 16] Elements or [n, 32] Encodings")
         if encoded is None:
             encoded = int(points.shape[1]) == 32
+        # the reference zips scalars with points (projective.rs:99-117); a length mismatch is a caller bug here
+        _check(points, ENC if encoded else ELEM, n, "msm points")
+        _check(scalar32, ENC, n, "msm scalars", points.device if _is_torch(points) else None)
         if _is_torch(points):
             import torch
             dev = points.device
+            self._dev_index(dev)
             pts, sc = points.contiguous(), scalar32.contiguous()
             enc = torch.empty((32,), dtype=torch.uint8, device=dev)
             xyzt = torch.empty((16,), dtype=torch.int64, device=dev)
@@ -263,7 +376,9 @@ class Context:
         per-rank partial sums of a sharded MSM."""
         import torch
         m = _rows(xyzt)
+        _check(xyzt, ELEM, m, "sum_elements input")
         dev = xyzt.device
+        self._dev_index(dev)
         enc = torch.empty((32,), dtype=torch.uint8, device=dev)
         out = torch.empty((16,), dtype=torch.int64, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -308,10 +423,11 @@ class Fq(_Bytes32):
     Fq::from_le_bytes_mod_order (src/fields/fq.rs:90-102)."""
 
     @staticmethod
-    def sqrt_ratio_zeta(num, den):
-        """Fq::sqrt_ratio_zeta (src/ark_curve/invsqrt.rs:75-166) -> (was_square[n], Fq roots)."""
-        root, ws = num._ctx().sqrt_ratio_zeta(num.data, den.data)
-        return ws, Fq(root, num.ctx)
+    def sqrt_ratio_zeta(num, den, root="ark"):
+        """Fq::sqrt_ratio_zeta (src/ark_curve/invsqrt.rs:75-166; root="min_curve": the min_curve backend's
+        non_arkworks_sqrt_ratio_zeta, src/min_curve/invsqrt.rs:73-95) -> (was_square[n], Fq roots)."""
+        r, ws = num._ctx().sqrt_ratio_zeta(num.data, den.data, root=root)
+        return ws, Fq(r, num.ctx)
 
 
 class Fr(_Bytes32):

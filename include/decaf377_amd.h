@@ -16,16 +16,26 @@
  *              (failed elements get all-zero output records)
  *
  * Return value: 0 on success, negative D377_ERR_* otherwise; per-element failures are only
- * reported through `status`.  A context is used by one thread at a time (one call in flight
- * per context: the variable-base kernel owns a per-context scratch table); distinct contexts
- * are independent.  Buffers belong to the caller and are never retained.
+ * reported through `status`.  Buffers belong to the caller and are never retained.
  *
- * Two families:
- *   d377_batch_*      host pointers; the library copies to the context's GPU(s), shards
- *                     contiguous slices over them when the context owns several, and copies back.
- *   d377_batch_*_dev  device pointers (16-byte aligned, resident on the context's device
- *                     `dev`), enqueued on `stream` (a hipStream_t, NULL = default stream) with
- *                     no host synchronisation: for callers that keep batches in HBM.
+ * Threads and streams.  Calls on one context are serialised by a mutex inside the context, so
+ * several host threads may share it; distinct contexts are independent.  The `_dev` entry points
+ * return as soon as the work is enqueued, and calls on DIFFERENT streams may be in flight at the
+ * same time: the per-device scratch areas some kernels use (the variable-base window tables, the MSM
+ * workspace) are handed from one launch to the next by events on the device, so such launches queue
+ * up behind each other instead of racing -- results are the same as if the calls had been made one
+ * after another; only their overlap is lost.  Kernels that use no scratch overlap freely.
+ *
+ * Three families:
+ *   d377_batch_*          host pointers; the library copies to the context's GPU(s), shards
+ *                         contiguous slices over them when the context owns several (one host
+ *                         thread per device, so the devices run concurrently), and copies back.
+ *   d377_batch_*_dev      device pointers (16-byte aligned, resident on the context's device
+ *                         `dev`), enqueued on `stream` (a hipStream_t, NULL = default stream) with
+ *                         no host synchronisation: for callers that keep batches in HBM.
+ *   d377_batch_sharded_dev  a batch resident in the HBM of ONE device of a multi-GPU context:
+ *                         contiguous slices go to the other devices by peer copies over xGMI, every
+ *                         device runs the kernel, the outputs come back; ordered on `stream`.
  */
 #ifndef DECAF377_AMD_H
 #define DECAF377_AMD_H
@@ -60,9 +70,19 @@ int d377_ctx_num_devices(const d377_ctx* ctx);
 int d377_ctx_device_id(const d377_ctx* ctx, int dev);
 
 /* Fq::sqrt_ratio_zeta(num, den) -> (was_square, root)        src/ark_curve/invsqrt.rs:75-166
- * num32/den32: 32-byte strings reduced mod q like Fq::from_le_bytes_mod_order. */
+ * num32/den32: 32-byte strings reduced mod q like Fq::from_le_bytes_mod_order.
+ * The crate's two backends return different roots (same flag, root negated about half the time):
+ *   D377_SQRT_ROOT_ARK        the default `arkworks` backend, Sarkar's table method   src/ark_curve/invsqrt.rs:75-166
+ *   D377_SQRT_ROOT_MIN_CURVE  `Fq::non_arkworks_sqrt_ratio_zeta`, constant-time Tonelli-Shanks seeded
+ *                             with 11^m                       src/min_curve/invsqrt.rs:11-95, src/fields/fq.rs:62-67
+ * d377_batch_sqrt_ratio_zeta returns the ARK root; the _ex forms take the convention.  Every group-level
+ * output (encodings) is the same under either: decompress / compress / Elligator fix the sign themselves. */
+#define D377_SQRT_ROOT_ARK 0
+#define D377_SQRT_ROOT_MIN_CURVE 1
 int d377_batch_sqrt_ratio_zeta(d377_ctx* ctx, const uint8_t* num32, const uint8_t* den32, size_t n,
                                uint8_t* root32, uint8_t* was_square);
+int d377_batch_sqrt_ratio_zeta_ex(d377_ctx* ctx, int root, const uint8_t* num32, const uint8_t* den32, size_t n,
+                                  uint8_t* root32, uint8_t* was_square);
 /* Encoding::vartime_decompress                                src/ark_curve/encoding.rs:32-83 */
 int d377_batch_decompress(d377_ctx* ctx, const uint8_t* enc32, size_t n, uint64_t* xyzt, uint8_t* status);
 /* Element::vartime_compress                                   src/ark_curve/encoding.rs:91-128 */
@@ -143,6 +163,8 @@ void d377_generator(uint64_t xyzt[16]);
 /* Device-pointer forms (same semantics). */
 int d377_batch_sqrt_ratio_zeta_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* num32,
                                    const uint8_t* den32, size_t n, uint8_t* root32, uint8_t* was_square);
+int d377_batch_sqrt_ratio_zeta_ex_dev(d377_ctx* ctx, int dev, void* stream, int root, const uint8_t* num32,
+                                      const uint8_t* den32, size_t n, uint8_t* root32, uint8_t* was_square);
 int d377_batch_decompress_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, size_t n,
                               uint64_t* xyzt, uint8_t* status);
 int d377_batch_compress_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t n,
@@ -183,6 +205,23 @@ int d377_msm_encoded_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* en
 /* Sum of m Element records (e.g. the per-rank partial sums of a sharded MSM after an all-gather). */
 int d377_sum_elements_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t m,
                           uint8_t* enc32_out, uint64_t* xyzt_out);
+
+
+/* Multi-GPU for a batch that already lives in HBM (contiguous slices, scatter of inputs and
+ * gather of outputs only, no other exchange).  in0/in1/out0/out1 are the buffers the matching
+ * d377_batch_*_dev entry point takes, in its order (unused ones NULL), resident on device `root_dev` of
+ * the context; slice k of the batch runs on device k (peer copies over xGMI for k != root_dev, in place
+ * for the root), and `stream` (a stream of the root device) continues once every slice is back. */
+#define D377_OP_SQRT_RATIO_ZETA 0
+#define D377_OP_DECOMPRESS 1
+#define D377_OP_COMPRESS 2
+#define D377_OP_ROUNDTRIP 3
+#define D377_OP_SCALAR_MUL_BASE 4
+#define D377_OP_SCALAR_MUL_VAR 5
+#define D377_OP_ENCODE_TO_CURVE 6
+#define D377_OP_HASH_TO_CURVE 7
+int d377_batch_sharded_dev(d377_ctx* ctx, int root_dev, void* stream, int op, const void* in0, const void* in1, size_t n,
+                           void* out0, void* out1);
 
 #ifdef __cplusplus
 }

@@ -58,3 +58,14 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".inc", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "d377o_" not in text and "libd377_oracle" not in text and "d377_model" not in text, f
+
+
+def test_every_dev_export_is_named_in_a_gpu_test():
+    """No `_dev` entry point without a `-m gpu` test that touches it: tests/test_gpu_parity.py's
+    test_every_dev_export keys its table by export name (and asserts the table equals the export list
+    on the GPU box); this is the same check without a GPU."""
+    from decaf377_amd import _native
+    text = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
+    for name in _native.EXPORTS:
+        if name.endswith("_dev"):
+            assert '"%s"' % name in text, name

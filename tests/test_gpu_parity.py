@@ -378,8 +378,13 @@ def test_wide_bytes_and_affine(ctx, oracle):
         enc = ctx.encode_to_curve_wide(raw)
         assert (enc == oracle.encode_to_curve_wide(raw, length)).all()
         assert (enc == ctx.encode_to_curve(fq)).all()
-    with pytest.raises(d.NativeError):
+    with pytest.raises(ValueError):                   # the host mirror refuses other widths before the call ...
         ctx.fq_from_wide_bytes(rng.integers(0, 256, (4, 40), dtype=np.uint8))
+    import ctypes                                     # ... and so does the C ABI itself
+    bad = np.zeros((4, 40), np.uint8)
+    out = np.zeros((4, 32), np.uint8)
+    assert ctx._lib.d377_batch_fq_from_wide_bytes(ctx._h, bad.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(40),
+                                                  ctypes.c_size_t(4), out.ctypes.data_as(ctypes.c_void_p)) == -2
     P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
     xy = ctx.to_affine(P)
     assert (xy == oracle.to_affine(P)).all()
@@ -569,3 +574,300 @@ def test_fr_bytes(ctx, oracle, kats):
     assert (out[ok] == raw[ok]).all() and not out[~ok].any()
     p1 = np.array(kats["fr_examples"]["p_plus_1_bytes"], dtype=np.uint8).reshape(1, 32)
     assert bytes(ctx.fr_from_le_bytes_mod_order(p1)[0]) == (1).to_bytes(32, "little")
+
+
+# --- round 2: oracle parity for a9 / a3, the min_curve root (a4'), every _dev export, streams, devices ---
+def test_neg_is_identity_eq_inverse_vs_oracle(ctx, oracle):
+    """SURVEY 8a rows a9 and a3 against the oracle's restatements, bit for bit: Element neg
+    (src/min_curve/element.rs:324-332), is_identity (:113-117), PartialEq (:334-340), Fq::inverse
+    (src/fields/fq/u64/wrapper.rs:104-112)."""
+    rng = np.random.default_rng(701)
+    n = 3000
+    P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    Qp = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    P[0] = oracle.identity_xyzt()
+    P[1] = oracle.generator_xyzt()
+    assert (ctx.neg(P) == oracle.neg_xyzt(P)).all()
+    mixed = P.copy()
+    mixed[::5] = oracle.add_xyzt(P[::5], oracle.neg_xyzt(P[::5]))       # some identities in non-canonical coordinates
+    assert (ctx.is_identity(mixed) == oracle.is_identity(mixed)).all() and ctx.is_identity(mixed)[::5].all()
+    # equality: same representative, another representative of the same element, negation, unrelated
+    other = oracle.add_xyzt(P, np.tile(oracle.identity_xyzt(), (n, 1)))
+    assert (other != P).any()
+    pairs_l = np.concatenate([P, P, P, P])
+    pairs_r = np.concatenate([P, other, oracle.neg_xyzt(P), Qp])
+    got = ctx.eq(pairs_l, pairs_r)
+    want = oracle.eq_xyzt(pairs_l, pairs_r)
+    assert (got == want).all()
+    assert got[:2 * n].all() and not got[3 * n:].any()
+    a = oracle.fq_from_bytes_mod_order(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    a[0] = 0
+    for name, code in (("add", 0), ("sub", 1), ("mul", 2), ("square", 3), ("neg", 4), ("inverse", 5)):
+        b = a[::-1].copy()
+        out, st = ctx.fq_op(name, a, b if code <= 2 else None)
+        o_out, o_st = oracle.fq_op(code, a, b if code <= 2 else None)
+        assert (out == o_out).all() and (st == o_st).all(), name
+
+
+def test_min_curve_root_2_16(ctx, oracle):
+    """SURVEY 8a row a4': `Fq::non_arkworks_sqrt_ratio_zeta` (src/min_curve/invsqrt.rs:11-95, the root the
+    min_curve backend returns) on 2^16 random pairs plus the edge pairs, bit-exact against the oracle's
+    constant-time Tonelli-Shanks restatement; flags equal the arkworks root's.  The convention only exists
+    on the raw square-root entry point: the group-level kernels take no such argument, so their outputs
+    cannot depend on it (and both roots give the same encodings: test_oracle.py)."""
+    rng = np.random.default_rng(702)
+    n = 1 << 16
+    num = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    den = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    edges = [(0, 1), (1, 0), (0, 0), (1, 1), (1 << 248, 1 << 248), (Q, 5), (1, Q), (Q - 1, 1), (1, Q - 1)]
+    for j, (u, v) in enumerate(edges):
+        num[j], den[j] = ibytes(u), ibytes(v)
+    root, ws = ctx.sqrt_ratio_zeta(num, den, root="min_curve")
+    o_root, o_ws, _ = oracle.run_threads("sqrt_ratio_zeta_min_curve", num, den, os.cpu_count() or 4)
+    assert (ws == o_ws).all()
+    assert (root == o_root).all()
+    root_a, ws_a = ctx.sqrt_ratio_zeta(num, den)
+    assert (ws_a == ws).all()
+    differs = (root_a != root).any(axis=1)
+    assert 0.4 < differs.mean() < 0.6
+    ra = [int.from_bytes(bytes(x), "little") for x in root_a[:512]]
+    rm = [int.from_bytes(bytes(x), "little") for x in root[:512]]
+    assert all(y in (x, (Q - x) % Q) for x, y in zip(ra, rm))
+    import decaf377_amd as d
+    with pytest.raises(KeyError):
+        ctx.sqrt_ratio_zeta(num[:4], den[:4], root="other")
+
+
+def _dev_cases(ctx, oracle, torch, n):
+    """name of the _dev export -> (callable on device tensors, callable on host arrays)."""
+    rng = np.random.default_rng(703)
+    dev = torch.device("cuda:0")
+    u8 = lambda m, w=32: rng.integers(0, 256, (m, w), dtype=np.uint8)
+    r0, r1, k = u8(n), u8(n), u8(n)
+    enc = oracle.encode_to_curve(r0)
+    raw = enc.copy()
+    raw[::9, 31] |= 0x40
+    P = oracle.elligator_map_xyzt(r0)
+    Qp = oracle.double_xyzt(oracle.elligator_map_xyzt(r1))
+    a = oracle.fq_from_bytes_mod_order(r0)
+    b = oracle.fq_from_bytes_mod_order(r1)
+    a[0] = 0
+    w48, w64 = u8(n, 48), u8(n, 64)
+    t = lambda x: torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else x).to(dev)
+    cases = {
+        "d377_batch_sqrt_ratio_zeta_dev": lambda f: f.sqrt_ratio_zeta,
+        "d377_batch_sqrt_ratio_zeta_ex_dev": lambda f: (lambda x, y: f.sqrt_ratio_zeta(x, y, root="min_curve")),
+        "d377_batch_decompress_dev": lambda f: f.decompress,
+        "d377_batch_compress_dev": lambda f: f.compress,
+        "d377_batch_roundtrip_dev": lambda f: f.roundtrip,
+        "d377_batch_scalar_mul_base_dev": lambda f: f.scalar_mul_base,
+        "d377_batch_scalar_mul_var_dev": lambda f: f.scalar_mul_var,
+        "d377_batch_encode_to_curve_dev": lambda f: f.encode_to_curve,
+        "d377_batch_hash_to_curve_dev": lambda f: f.hash_to_curve,
+        "d377_batch_add_dev": lambda f: f.add,
+        "d377_batch_double_dev": lambda f: f.double,
+        "d377_batch_eq_dev": lambda f: f.eq,
+        "d377_batch_neg_dev": lambda f: f.neg,
+        "d377_batch_is_identity_dev": lambda f: f.is_identity,
+        "d377_batch_to_affine_dev": lambda f: f.to_affine,
+        "d377_batch_fq_from_wide_bytes_dev": lambda f: f.fq_from_wide_bytes,
+        "d377_batch_encode_to_curve_wide_dev": lambda f: f.encode_to_curve_wide,
+        "d377_batch_fq_op_dev": lambda f: f.fq_op,
+        "d377_msm_dev": lambda f: f.msm,
+        "d377_msm_encoded_dev": lambda f: f.msm,
+        "d377_sum_elements_dev": None,
+        "d377_batch_sharded_dev": None,
+    }
+    args = {
+        "d377_batch_sqrt_ratio_zeta_dev": [(r0, k)], "d377_batch_sqrt_ratio_zeta_ex_dev": [(r0, k)],
+        "d377_batch_decompress_dev": [(raw,)], "d377_batch_compress_dev": [(Qp,)], "d377_batch_roundtrip_dev": [(raw,)],
+        "d377_batch_scalar_mul_base_dev": [(k,)], "d377_batch_scalar_mul_var_dev": [(raw, k)],
+        "d377_batch_encode_to_curve_dev": [(r0,)], "d377_batch_hash_to_curve_dev": [(r0, r1)],
+        "d377_batch_add_dev": [(P, Qp)], "d377_batch_double_dev": [(Qp,)], "d377_batch_eq_dev": [(P, Qp), (Qp, Qp)],
+        "d377_batch_neg_dev": [(Qp,)], "d377_batch_is_identity_dev": [(oracle.add_xyzt(P, oracle.neg_xyzt(P)),), (P,)],
+        "d377_batch_to_affine_dev": [(Qp,)], "d377_batch_fq_from_wide_bytes_dev": [(w48,), (w64,)],
+        "d377_batch_encode_to_curve_wide_dev": [(w48,), (w64,)],
+        "d377_batch_fq_op_dev": [("add", a, b), ("sub", a, b), ("mul", a, b), ("square", a), ("neg", a), ("inverse", a)],
+        "d377_msm_dev": [(Qp, k)], "d377_msm_encoded_dev": [(raw, k)],
+    }
+    return cases, args, t, (P, Qp, raw, k, r0)
+
+
+def _same(x, y):
+    import torch
+    if x is None or y is None:
+        return x is None and y is None
+    xs = x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    ys = y.cpu().numpy() if isinstance(y, torch.Tensor) else np.asarray(y)
+    return xs.shape == ys.shape and (xs.view(np.uint8) == ys.view(np.uint8)).all()
+
+
+def test_every_dev_export(ctx, oracle, torch_mod):
+    """Drives EVERY `_dev` export of include/decaf377_amd.h on device tensors and compares it, byte for
+    byte, with the host-pointer form of the same entry point (which the other tests pin to the oracle);
+    MSM results (not unique as coordinates) are compared as encodings."""
+    import decaf377_amd._native as nat
+    torch = torch_mod
+    n = 2500
+    cases, args, t, (P, Qp, raw, k, r0) = _dev_cases(ctx, oracle, torch, n)
+    dev_exports = {e for e in nat.EXPORTS if e.endswith("_dev")}
+    assert dev_exports == set(cases), dev_exports ^ set(cases)
+    for name, getter in cases.items():
+        if getter is None:
+            continue
+        f = getter(ctx)
+        for a in args[name]:
+            host = f(*a)
+            devr = f(*[t(x) if isinstance(x, np.ndarray) else x for x in a])
+            torch.cuda.synchronize()
+            host = host if isinstance(host, (tuple, list)) else (host,)
+            devr = devr if isinstance(devr, (tuple, list)) else (devr,)
+            if name.startswith("d377_msm"):
+                assert _same(host[0], devr[0]) and _same(host[2], devr[2]), name      # encoding and statuses
+                assert oracle.eq_xyzt(host[1].reshape(1, 16), devr[1].cpu().numpy().view(np.uint64).reshape(1, 16)).all()
+            else:
+                assert len(host) == len(devr) and all(_same(h, g) for h, g in zip(host, devr)), name
+    # sum of Element records held in HBM
+    enc, xyzt = ctx.sum_elements(t(Qp[:37]))
+    acc = Qp[0:1]
+    for i in range(1, 37):
+        acc = oracle.add_xyzt(acc, Qp[i:i + 1])
+    assert bytes(enc.cpu().numpy()) == bytes(oracle.compress(acc)[0])
+    assert oracle.eq_xyzt(xyzt.cpu().numpy().view(np.uint64).reshape(1, 16), acc).all()
+
+
+def test_sharded_device_path(oracle, torch_mod):
+    """d377_batch_sharded_dev: an HBM-resident batch split over the context's devices by peer copies (SURVEY
+    8e at the C ABI).  One physical GPU listed two and three times exercises slicing, staging, the event
+    ordering and the gather; results equal the single-device entry points, ragged sizes included."""
+    import decaf377_amd as d
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(704)
+    t = lambda x: torch.from_numpy(x).to(dev)
+    for ids in ([0, 0], [0, 0, 0]):
+        c = d.Context(ids)
+        for n in (1, 17, 1000, 40001):
+            r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            r1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            enc = c.sharded("encode_to_curve", t(r0))[0]
+            assert _same(enc, c.encode_to_curve(r0))
+            raw = enc.clone()
+            raw[::7, 31] |= 0x80
+            out, st = c.sharded("scalar_mul_var", raw, t(k))
+            h_out, h_st = c.scalar_mul_var(raw.cpu().numpy(), k)
+            assert _same(out, h_out) and _same(st, h_st)
+            rt, st = c.sharded("roundtrip", raw)
+            h_rt, h_st = c.roundtrip(raw.cpu().numpy())
+            assert _same(rt, h_rt) and _same(st, h_st)
+            xyzt, st = c.sharded("decompress", enc)
+            assert _same(c.sharded("compress", xyzt)[0], enc)
+            assert _same(c.sharded("scalar_mul_base", t(k))[0], c.scalar_mul_base(k))
+            assert _same(c.sharded("hash_to_curve", t(r0), t(r1))[0], c.hash_to_curve(r0, r1))
+            root, ws = c.sharded("sqrt_ratio_zeta", t(r0), t(r1))
+            h_root, h_ws = c.sqrt_ratio_zeta(r0, r1)
+            assert _same(root, h_root) and _same(ws, h_ws)
+        c.close()
+
+
+def test_concurrent_streams_share_scratch(ctx, oracle, torch_mod):
+    """Two torch streams issue variable-base batches and MSMs at the same time.  The per-device window tables
+    and the MSM workspace are handed from launch to launch by events (include/decaf377_amd.h, "Threads and
+    streams"), so the results must equal the one-at-a-time results; before that hand-over existed the two
+    launches overwrote each other's tables."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(705)
+    n = 1 << 15
+    sets = []
+    for _ in range(2):
+        enc = torch.from_numpy(oracle.encode_to_curve(rng.integers(0, 256, (4096, 32), dtype=np.uint8))).to(dev)
+        enc = enc.repeat(n // 4096, 1).contiguous()
+        k = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(dev)
+        sets.append((enc, k))
+    want = [ctx.scalar_mul_var(e, k) for e, k in sets]
+    want_msm = [ctx.msm(e, k) for e, k in sets]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for rep in range(3):
+        got, got_msm = [None, None], [None, None]
+        for j in (0, 1):
+            with torch.cuda.stream(streams[j]):
+                got[j] = ctx.scalar_mul_var(*sets[j])
+                got_msm[j] = ctx.msm(*sets[j])
+        # and the host-pointer path (the context's private stream) while those are in flight
+        h_out, h_st = ctx.scalar_mul_var(sets[0][0][:2048].cpu().numpy(), sets[0][1][:2048].cpu().numpy())
+        torch.cuda.synchronize()
+        for j in (0, 1):
+            assert torch.equal(got[j][0], want[j][0]) and torch.equal(got[j][1], want[j][1])
+            assert torch.equal(got_msm[j][0], want_msm[j][0])
+        assert _same(h_out, want[0][0][:2048]) and _same(h_st, want[0][1][:2048])
+    assert (want[0][0][:256].cpu().numpy() == oracle.scalar_mul_var(sets[0][0][:256].cpu().numpy(),
+                                                                    sets[0][1][:256].cpu().numpy())[0]).all()
+
+
+def test_multi_device_host_path_is_concurrent(oracle):
+    """The host-pointer path drives each device of a multi-device context from its own host thread.  With
+    D377_DEBUG_DEVICE_DELAY_MS every per-device worker first sleeps: three devices (one GPU listed three
+    times) must take about one delay, not three -- the serial loop this replaced took the sum."""
+    import time
+    import decaf377_amd as d
+    rng = np.random.default_rng(706)
+    n = 3000
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    c = d.Context([0, 0, 0])
+    enc = c.encode_to_curve(r0)                      # warm-up: buffers, code objects
+    c.scalar_mul_var(enc, k)
+    xyzt, _ = c.decompress(enc)
+    c.msm(xyzt, k)
+    delay = 0.4
+    os.environ["D377_DEBUG_DEVICE_DELAY_MS"] = str(int(delay * 1000))
+    try:
+        t0 = time.perf_counter()
+        out, st = c.scalar_mul_var(enc, k)
+        t1 = time.perf_counter()
+        e, _, _ = c.msm(xyzt, k)
+        t2 = time.perf_counter()
+    finally:
+        del os.environ["D377_DEBUG_DEVICE_DELAY_MS"]
+    assert delay <= t1 - t0 < 2 * delay, t1 - t0
+    assert delay <= t2 - t1 < 2 * delay, t2 - t1
+    o_out, o_st = oracle.scalar_mul_var(enc, k)
+    assert (out == o_out).all() and (st == o_st).all()
+    assert bytes(e) == bytes(oracle.msm(xyzt, k)[0])
+    c.close()
+
+
+def test_engine_rejects_malformed_arrays(ctx, torch_mod):
+    """The native code reads n * record_size bytes unconditionally; the host mirror must refuse anything
+    else before the call: short second operands, wrong row widths, wrong dtypes, short outputs."""
+    torch = torch_mod
+    rng = np.random.default_rng(707)
+    enc = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    xyzt = np.zeros((64, 16), np.uint64)
+    with pytest.raises(ValueError):
+        ctx.scalar_mul_var(enc, k[:10])
+    with pytest.raises(ValueError):
+        ctx.roundtrip(enc[:, :16])
+    with pytest.raises(ValueError):
+        ctx.roundtrip(enc.astype(np.int32))
+    with pytest.raises(ValueError):
+        ctx.compress(enc)
+    with pytest.raises(ValueError):
+        ctx.msm(xyzt, k[:5])
+    with pytest.raises(ValueError):
+        ctx.msm(enc[:, :20], k)
+    with pytest.raises(ValueError):
+        ctx.roundtrip(enc, outs=[np.zeros((10, 32), np.uint8), np.zeros(64, np.uint8)])
+    with pytest.raises(ValueError):
+        ctx.fq_op("mul", xyzt[:, :4], xyzt[:5, :4])
+    with pytest.raises(ValueError):
+        ctx.fq_from_wide_bytes(np.zeros((4, 40), np.uint8))
+    dev = torch.device("cuda:0")
+    with pytest.raises(ValueError):
+        ctx.scalar_mul_var(torch.from_numpy(enc).to(dev), torch.from_numpy(k))       # second operand on the CPU
+    with pytest.raises(ValueError):
+        ctx.add(torch.zeros((8, 16), dtype=torch.int64, device=dev), torch.zeros((8, 15), dtype=torch.int64, device=dev))

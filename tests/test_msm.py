@@ -81,12 +81,13 @@ def test_msm_every_window_width(oracle, window):
 
 
 @pytest.mark.gpu
-def test_msm_full_size_properties(ctx, oracle):
-    """2^20 points on the device path: (1) all points equal P -> [sum k_i] P; (2) linearity:
-    MSM(A u B) == MSM(A) + MSM(B); (3) a 2^14 prefix against the oracle fold."""
+@pytest.mark.parametrize("log_n", [20, 22])
+def test_msm_full_size_properties(ctx, oracle, log_n):
+    """2^20 and 2^22 (the advertised size) points on the device path: (1) all points equal P ->
+    [sum k_i] P; (2) linearity: MSM(A u B) == MSM(A) + MSM(B); (3) a 2^14 prefix against the oracle fold."""
     import torch
     dev = torch.device("cuda:0")
-    n = 1 << 20
+    n = 1 << log_n
     g = torch.Generator(device=dev).manual_seed(703)
     r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
     k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
