@@ -5,14 +5,18 @@
 
 A "step" is one pass of the headline workload over one batch of synthetic input that is
 already resident in HBM: BASELINE.json configs[3], 2^22 variable-base scalar multiplications
-(random Element x random Fr: decompress, [k]P, compress) PER GPU (weak scaling: every rank owns
-its own 2^22-element shard, no data-path collective).  Rank 0 prints ONE JSON line.
+(random Element x random Fr: decompress, [k]P, compress).  Rank 0 prints ONE JSON line.
+
+  --scaling weak      (default) 2^22 elements PER GPU: every rank owns its own shard, no data-path collective
+  --scaling strong    configs[3] as written: 2^22 elements IN TOTAL, rank g owns n/G of them
+  --from-root         (with either total) the batch lives on rank 0: every step scatters the inputs over
+                      RCCL, runs the shards, gathers the outputs back; `collective_ms` reports their share
 
 Besides the contract keys the line carries
   roofline       HBM view of the dominant kernel (k_scalar_mul_var): algorithmic bytes / launch
                  duration (HIP events on the launch stream) against the 8 TB/s peak;
   roofline_valu  the view that actually binds: integer MACs/s against the v_mad_u64_u32 issue
-                 rate measured on this chip (tools/valu_rates.hip, profiles/r01_valu_rates_*);
+                 ceiling (one wave-instruction per 4 cycles per SIMD; tools/valu_mix.hip, profiles/r02_valu_mix*.txt);
   cpu_baseline   the C restatement of the reference algorithm (oracle/, kind "port") timed on the
                  host cores of this box on the same workload (rank 0, N = 1 only);
   extra          encodes/s of the other batch operations (round trip, Elligator, fixed base, sqrt).
@@ -29,10 +33,21 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes and reference-algorithm work per unit
 ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "scalar_mul_base": 64,
               "sqrt_ratio_zeta": 97}
-# 32-bit MACs our kernels execute per unit (counted from the schedule)
-KERNEL_MACS = {"scalar_mul_var": 4.152e5}   # 2 sqrt (288 S + 78 M each) + 63 windows x (16 S + 20 M) + table build, S = 117, M = 153 MACs
+# Field products (M, 153 v_mad_u64_u32 each) and squarings (S, 117) one element executes, counted by the
+# instrumented host build of the same headers (tests/test_host_sim.py::test_bench_mac_counts):
+# variable base = 2 square roots (288 S + 83 M with the Elligator-free callers' extras) + 63 windows x
+# (4 doublings of 3 S + 4 M, + 1 M for T, + a 7 M cached addition) + the 9-entry table.
+KERNEL_OPS = {"scalar_mul_var": (1750, 1340), "roundtrip": (177, 580), "scalar_mul_base": (312, 289),
+              "sqrt_ratio_zeta": (83, 288)}
+MACS_PER_MUL, MACS_PER_SQR = 153, 117
+KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR for k, (m, s) in KERNEL_OPS.items()}   # scalar_mul_var: 424530
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
-VALU_MAC_PEAK = 3.28e13               # measured: v_mad_u64_u32 lane-ops/s, 8 waves/SIMD (profiles/r01_valu_rates_microbench.txt)
+# v_mad_u64_u32 issues one wave-instruction per 4 cycles per SIMD (16 lanes / cycle): 256 CUs x 4 SIMDs x 16
+# lanes x 2.4 GHz.  Measured on this chip: 3.74-3.80e13/s = 95-97 % of it, because the sustained clock under this
+# load is ~2.3 GHz (tools/valu_mix.hip, tools/valu_mix2.hip -> profiles/r02_valu_mix.txt, r02_valu_mix2.txt).
+# Round 1 quoted 3.28e13 from a loop with 8 instructions per branch; that figure was the benchmark's, not the chip's.
+VALU_MAC_PEAK = 256 * 4 * 16 * 2.4e9  # 3.93e13 MAC/s
+VALU_MAC_PEAK_MEASURED = 3.80e13
 
 
 def parse():
@@ -40,7 +55,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log2n", type=int, default=22, help="elements per GPU per step (2^log2n)")
+    ap.add_argument("--log2n", type=int, default=22, help="2^log2n elements per step: per GPU (weak) or in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--from-root", action="store_true",
+                    help="the batch starts and ends on rank 0: scatter -> shards -> gather inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -112,45 +130,51 @@ def main():
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     ctx = d.Context([local])
+    from decaf377_amd import sharding
     n = 1 << args.log2n
+    mode = "from-root" if args.from_root else args.scaling
+    if args.from_root and args.scaling == "weak":
+        n_job = n * world                # the root holds world x 2^log2n records
+    else:
+        n_job = n
 
-    # synthetic shard of this rank, generated on the device and resident before timing
+    # synthetic records, generated on the device and resident before timing
+    def make_inputs(count, rk):
+        g = torch.Generator(device=dev).manual_seed(666 + rk)
+        r0_ = torch.randint(0, 256, (count, 32), dtype=torch.uint8, device=dev, generator=g)
+        k_ = torch.randint(0, 256, (count, 32), dtype=torch.uint8, device=dev, generator=g)
+        return ctx.encode_to_curve(r0_), k_      # valid encodings, strategy of tests/operations.rs:6-11
+
+    kernel_events = []
+
+    def compute(points_, scalars_):
+        cnt = int(points_.shape[0])
+        o = torch.empty((cnt, 32), dtype=torch.uint8, device=dev)
+        st = torch.empty((cnt,), dtype=torch.uint8, device=dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()                               # torch's current stream is the launch stream of the _dev call
+        if cnt:
+            ctx.scalar_mul_var(points_, scalars_, outs=[o, st])
+        b.record()
+        kernel_events.append((a, b))
+        return o, st
+
+    res = sharding.run_job(mode, n_job, args.steps, args.warmup, make_inputs, compute, dev,
+                           sync=torch.cuda.synchronize, red_device=red_dev, coll_device=red_dev)
+    elapsed = res["elapsed_s"]
+    timed = kernel_events[-args.steps:]
+    kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / max(1, len(timed))
+    n_launch = res["per_rank"]                   # records one launch of this rank processed
+    out, status = res["outputs"] if rank == 0 else (None, None)
+    if rank == 0 and out is not None:
+        assert int(status.sum().item()) == 0, "valid inputs must all decode"
+    # the extra ops and the CPU baseline below reuse rank 0's records
     g = torch.Generator(device=dev).manual_seed(666 + rank)
     r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
     scalars = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
-    points = ctx.encode_to_curve(r0)          # valid encodings, strategy of tests/operations.rs:6-11
-    out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
-    status = torch.empty((n,), dtype=torch.uint8, device=dev)
+    points = ctx.encode_to_curve(r0)
 
-    def step():
-        ctx.scalar_mul_var(points, scalars, outs=[out, status])
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        step()
-        b.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert int(status.sum().item()) == 0, "valid inputs must all decode"
-
-    total_units = n * world * args.steps
-    value = total_units / elapsed
+    value = res["units"] / elapsed
     line = {
         "metric": "decaf377 var-base scalar-mults/sec + encodes/sec at 1/2/4/8 MI355X",
         "value": value,
@@ -160,30 +184,37 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
         "config": {
-            "workload": "2^%d variable-base scalar mult (random Element x random Fr -> Encoding) per GPU, "
-                        "BASELINE.json configs[3]" % args.log2n,
-            "elements_per_gpu": n,
-            "elements_total": n * world,
-            "sharding": "independent contiguous shards, one process per GPU, no data-path collective",
+            "workload": "2^%d variable-base scalar mult (random Element x random Fr -> Encoding) %s, "
+                        "BASELINE.json configs[3]" % (args.log2n, "per GPU" if args.scaling == "weak" else "in total"),
+            "mode": mode,
+            "elements_per_gpu": n_launch if mode != "weak" else n,
+            "elements_total": res["units"] // args.steps,
+            "sharding": ("the batch lives on rank 0: scatter of inputs, independent shards, gather of outputs (RCCL)"
+                         if args.from_root else
+                         "independent contiguous shards, one process per GPU, no data-path collective"),
             "inputs": "points = encode_to_curve(rand32), scalars = rand32 (reduced mod r on the GPU), seed 666+rank",
         },
     }
+    if args.from_root:
+        line["collective_ms"] = res["collective_s"] * 1e3 / args.steps
+    n = max(n_launch, 1) if mode != "weak" else n
     algo_bytes = ALGO_BYTES["scalar_mul_var"] * n
     ach = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source, pmc = None, None, {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            rec = json.load(open(tpath)).get("k_scalar_mul_var")
-            if rec and rec.get("elements") == n:
-                traffic = rec["hbm_bytes_per_launch"]     # PMC, separate rocprofv3 passes (profiles/r01_final_pmc.csv)
+            pmc = json.load(open(tpath)).get("k_scalar_mul_var") or {}
+            if pmc.get("elements") == n:
+                traffic = pmc["hbm_bytes_per_launch"]     # PMC counters of separate rocprofv3 passes, not of this run
+                traffic_source = "profiles/pmc_traffic.json (" + pmc.get("source", "rocprofv3 --pmc passes") + ")"
         except Exception:
-            traffic = None
+            traffic, pmc = None, {}
     line["roofline"] = {
         "kernel": "k_scalar_mul_var",
         "bound": "hbm",
@@ -192,8 +223,9 @@ def main():
         "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS,
         "traffic": traffic,
+        "traffic_source": traffic_source,
         "kernel_ms": kernel_ms,
-        "note": "integer-ALU-bound kernel: ~4.6e5 32-bit MACs per 97 algorithmic bytes; see roofline_valu",
+        "note": "integer-ALU-bound kernel: 4.2e5 32-bit MACs per 97 algorithmic bytes; see roofline_valu",
     }
     macs = KERNEL_MACS["scalar_mul_var"] * n / (kernel_ms * 1e-3)
     line["roofline_valu"] = {
@@ -202,7 +234,17 @@ def main():
         "peak": VALU_MAC_PEAK / 1e12,
         "unit": "TMAC/s",
         "frac": macs / VALU_MAC_PEAK,
+        "peak_measured": VALU_MAC_PEAK_MEASURED / 1e12,
+        "frac_of_measured": macs / VALU_MAC_PEAK_MEASURED,
+        "macs_per_element": KERNEL_MACS["scalar_mul_var"],
     }
+    if pmc.get("valu_insts_per_element"):
+        # every VALU instruction of this stream costs one issue slot: MACs / all VALU instructions is the ceiling
+        # of `frac` for this instruction stream, and instructions/s against the issue rate says how full the pipe is
+        vi = pmc["valu_insts_per_element"]
+        line["roofline_valu"]["valu_insts_per_mac"] = vi / KERNEL_MACS["scalar_mul_var"]
+        line["roofline_valu"]["valu_issue_frac"] = vi * n / (kernel_ms * 1e-3) / VALU_MAC_PEAK
+        line["roofline_valu"]["pmc_source"] = pmc.get("source")
 
     if not args.no_extra:
         extra = {}

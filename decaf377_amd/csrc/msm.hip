@@ -271,22 +271,78 @@ k_msm_fold(const uint32_t* in, int W, int m, int mout, uint32_t* out) {
   }
 }
 
-// Horner over the window sums S_w (one lane), result as Element record and as encoding
-__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+// ---- Horner tail, four lanes per group element -------------------------------------------------
+// The tail is one dependency chain (252 doublings + W additions) whatever the batch size.  A doubling
+// is two rounds of four independent field products (X^2, Y^2, 2Z^2, 2XY, then EF, GH, FG, EH), and so
+// is an addition after one preparatory product; so four lanes each take one product per round (the
+// same instruction stream on different operands: no divergence), exchange the four results with
+// ds_bpermute, and every lane rebuilds the linear combinations.  Depth per doubling: 2 products instead
+// of 8.  Every lane holds the whole point; lane j & 3 decides which product it computes.
+__device__ __forceinline__ fe fe_from_lane(const fe& v, int lane) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)__shfl((int)v.l[i], lane);
+  return r;
+}
+__device__ __forceinline__ fe fe_pick(int role, const fe& a, const fe& b, const fe& c, const fe& d) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const uint32_t lo = (role & 1) ? b.l[i] : a.l[i], hi = (role & 1) ? d.l[i] : c.l[i];
+    r.l[i] = (role & 2) ? hi : lo;
+  }
+  return r;
+}
+// -[2]P (same formulas as ge_double_neg)
+__device__ __forceinline__ ge ge_double_neg_coop(const ge& p, int role, int base) {
+  const fe y2 = fe_dbl(p.y), z2 = fe_dbl(p.z);
+  const fe m1 = fe_mul(fe_pick(role, p.x, p.y, p.z, p.x), fe_pick(role, p.x, p.y, z2, y2));
+  const fe a = fe_from_lane(m1, base), b = fe_from_lane(m1, base + 1), c = fe_from_lane(m1, base + 2), e = fe_from_lane(m1, base + 3);
+  const fe h = fe_add(a, b), g = fe_sub(a, b), f = fe_add(g, c);
+  const fe m2 = fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));
+  ge r;
+  r.x = fe_from_lane(m2, base); r.y = fe_from_lane(m2, base + 1); r.z = fe_from_lane(m2, base + 2); r.t = fe_from_lane(m2, base + 3);
+  return r;
+}
+// P + Q (src/min_curve/element.rs:291-322), Q's coordinates products as loaded from a pt_store_ext record
+__device__ __forceinline__ ge ge_add_coop(const ge& p, const ge& q, int role, int base) {
+  const fe kt = fe_mul(fe_const(FE_K), q.t);                   // every lane: one product
+  const fe m1 = fe_mul(fe_pick(role, fe_sub(p.y, p.x), fe_add(p.y, p.x), p.t, fe_dbl(p.z)),
+                       fe_pick(role, fe_sub(q.y, q.x), fe_carry(fe_add(q.y, q.x)), kt, q.z));
+  const fe a = fe_from_lane(m1, base), b = fe_from_lane(m1, base + 1), c = fe_from_lane(m1, base + 2), d = fe_from_lane(m1, base + 3);
+  const fe e = fe_sub(b, a), f = fe_sub(d, c), g = fe_carry(fe_add(d, c)), h = fe_add(b, a);
+  const fe m2 = fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));
+  ge r;
+  r.x = fe_from_lane(m2, base); r.y = fe_from_lane(m2, base + 1); r.z = fe_from_lane(m2, base + 2); r.t = fe_from_lane(m2, base + 3);
+  return r;
+}
+
+// Horner over the window sums S_w (lanes 0-3 of one wave), result as Element record and as encoding
+__global__ void __launch_bounds__(64, 1)
 k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, uint64_t* xyzt_out) {
-  D377_POW_LDS();
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
+  struct Pow64 {                                   // the square-root power table, 64 columns
+    uint32_t* col;
+    __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
+    __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
+  } pt;
+  pt.col = lds_pow_ + threadIdx.x;
+  if (blockIdx.x != 0) return;
+  const int role = threadIdx.x & 3, base = threadIdx.x & ~3;     // every group of four lanes computes the same thing
   ge r = pt_load_ext(sums + (size_t)(W - 1) * PT_WORDS);
 #pragma unroll 1
   for (int w = W - 2; w >= 0; --w) {
 #pragma unroll 1
-    for (int j = 0; j < c; ++j) r = ge_double_latency(r);
-    r = ge_add(r, pt_load_ext(sums + (size_t)w * PT_WORDS));
+    for (int j = 0; j < c; ++j) r = ge_double_neg_coop(r, role, base);
+    if (c & 1) r = ge_neg(r);                                    // an odd number of sign-flipping doublings
+    r = ge_add_coop(r, pt_load_ext(sums + (size_t)w * PT_WORDS), role, base);
   }
-  if (xyzt_out) store_ge_mont256(xyzt_out, 0, r);
   uint32_t w8[8];
   ge_compress(T, pt, r, w8);
-  store32(enc_out, 0, w8);
+  if (threadIdx.x == 0) {
+    if (xyzt_out) store_ge_mont256(xyzt_out, 0, r);
+    store32(enc_out, 0, w8);
+  }
 }
 
 // sum of m Element records (partial results of several GPUs / ranks), one lane

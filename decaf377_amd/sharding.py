@@ -109,3 +109,83 @@ def msm_sharded(ctx, points, scalars, group=None):
     allp = allgather_partials(partial, group)
     enc, _ = ctx.sum_elements(allp)
     return enc
+
+
+def run_job(mode, n, steps, warmup, make_inputs, compute, device, sync=lambda: None, red_device=None, group=None,
+            coll_device=None):
+    """The timed region of bench.py, for any backend (RCCL on GPUs; gloo + a CPU stand-in in the tests).
+
+    mode  "weak":      every rank owns n records of its own (per-GPU work fixed as ranks are added);
+          "strong":    n records in total, rank g owns shard_bounds(n, world, g) of them;
+          "from-root": n records in total that live on rank 0: every step scatters the inputs, runs the
+                       shard on every rank and gathers the outputs back (the only collectives the path
+                       has); their share of the step is returned as collective_s.
+    make_inputs(count, rank) -> tuple of [count, ...] tensors on `device` (the rank's synthetic records);
+    compute(*inputs) -> tuple of output tensors; sync() drains the device; coll_device: where the collectives'
+    tensors must live (the compute device for RCCL; the CPU when HBM tensors are moved by gloo in plumbing tests).
+    Returns dict(elapsed_s (max over ranks, `steps` timed steps), units (records all ranks processed in
+    them), per_rank (records of this rank per step), collective_s, outputs (last step: this rank's, or
+    rank 0's gathered ones in from-root mode))."""
+    import time
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if mode not in ("weak", "strong", "from-root"):
+        raise ValueError("mode must be weak, strong or from-root")
+    if mode == "weak":
+        lo, hi = 0, n
+        total = n * world
+    else:
+        lo, hi = shard_bounds(n, world, rank)
+        total = n
+    from_root = mode == "from-root"
+    cdev = coll_device if coll_device is not None else device
+    if from_root:
+        full = make_inputs(n, 0) if rank == 0 else None
+        specs = [(tuple(t.shape[1:]), t.dtype) for t in make_inputs(1, 0)]
+    else:
+        local = make_inputs(hi - lo, rank)
+    coll = 0.0
+    outs = None
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier(group)
+        sync()
+
+    def one_step(timed):
+        nonlocal coll, outs
+        if from_root and world > 1:
+            t0 = time.perf_counter()
+            ins = [scatter_records(full[i].to(cdev) if rank == 0 else None, n, specs[i][0], specs[i][1], cdev, 0,
+                                   group).to(device) for i in range(len(specs))]
+            sync()
+            t1 = time.perf_counter()
+            res = compute(*ins)
+            sync()
+            t2 = time.perf_counter()
+            outs = [gather_records(o.to(cdev), n, 0, group) for o in res]
+            if rank == 0:
+                outs = [o.to(device) for o in outs]
+            sync()
+            if timed:
+                coll += (t1 - t0) + (time.perf_counter() - t2)
+        elif from_root:
+            outs = list(compute(*full))
+        else:
+            outs = list(compute(*local))
+
+    for _ in range(warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rd = red_device if red_device is not None else device
+    if world > 1:
+        elapsed = max_over_ranks(elapsed, rd, group)
+        coll = max_over_ranks(coll, rd, group)
+    return {"elapsed_s": elapsed, "units": total * steps, "per_rank": hi - lo, "collective_s": coll, "outputs": outs,
+            "world": world, "rank": rank}

@@ -63,6 +63,36 @@ def main():
     for r in range(1, world):
         acc = orc.add_xyzt(acc, allp[r:r + 1].numpy().view(np.uint64))
     assert bytes(orc.compress(acc)[0]) == bytes(orc.msm(P, k, threads=1)[0])
+    # bench.py's timed region in its three modes, with the oracle standing in for the kernels
+    def make_inputs(count, rk):
+        rng = np.random.default_rng(500 + rk)
+        r0 = rng.integers(0, 256, (count, 32), dtype=np.uint8)
+        pts = orc.encode_to_curve(r0) if count else np.zeros((0, 32), np.uint8)
+        return torch.from_numpy(pts), torch.from_numpy(rng.integers(0, 256, (count, 32), dtype=np.uint8))
+
+    def compute(p, s):
+        if p.shape[0] == 0:
+            return torch.zeros((0, 32), dtype=torch.uint8), torch.zeros((0,), dtype=torch.uint8)
+        o, st = orc.scalar_mul_var(p.numpy(), s.numpy())
+        return torch.from_numpy(o), torch.from_numpy(st)
+
+    n = 41
+    for mode in ("weak", "strong", "from-root"):
+        res = sharding.run_job(mode, n, 2, 1, make_inputs, compute, dev)
+        assert res["world"] == world and res["elapsed_s"] > 0
+        if mode == "weak":
+            assert res["units"] == n * world * 2 and res["per_rank"] == n and res["collective_s"] == 0
+        else:
+            lo, hi = sharding.shard_bounds(n, world, rank)
+            assert res["units"] == n * 2 and res["per_rank"] == hi - lo
+        if mode == "from-root":
+            assert res["collective_s"] > 0
+            if rank == 0:
+                fp, fk = make_inputs(n, 0)
+                e_out, e_st = orc.scalar_mul_var(fp.numpy(), fk.numpy())
+                assert (res["outputs"][0].numpy() == e_out).all() and (res["outputs"][1].numpy() == e_st).all()
+            else:
+                assert res["outputs"] == [None, None]
     t = sharding.max_over_ranks(0.5 + rank, dev)
     assert abs(t - (0.5 + world - 1)) < 1e-9
     dist.barrier()

@@ -210,6 +210,13 @@ void sim_scalar_mul_base(const uint32_t* k, size_t n, uint32_t* out) {
     ge_compress(g_T, pt, ge_scalar_mul_base_w8(kk, ft), out + 8 * i);
   }
 }
+#if defined(D377_BOUNDS)
+// products / squarings executed since the last call (bounds build only): bench.py's per-element MAC counts
+void sim_op_counts(unsigned long* mul, unsigned long* sqr) {
+  *mul = op_counts().mul; *sqr = op_counts().sqr;
+  op_counts().mul = 0; op_counts().sqr = 0;
+}
+#endif
 void sim_fr_reduce(const uint32_t* k, size_t n, uint32_t* out) {
   for (size_t i = 0; i < n; ++i) { uint32_t kk[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); memcpy(out + 8 * i, kk, 32); }
 }
