@@ -271,6 +271,9 @@ def main():
         pm, _ = ctx.decompress(enc1)
         ker, _ = time_op(torch, lambda: ctx.msm(pm, scalars[:ne]), 3, 1)
         extra["msm_2^20"] = {"n": ne, "ms": ker, "per_sec": ne / (ker * 1e-3)}
+        aff = torch.empty((ne, 8), dtype=torch.int64, device=dev)
+        ker, _ = time_op(torch, lambda: ctx.to_affine(pm, outs=[aff]), 3, 1)
+        extra["to_affine"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}
         extra["encodes_per_sec"] = extra["roundtrip"]["per_sec_all_gpus"]          # whole job, all GPUs
         extra["elligator_encodes_per_sec"] = extra["encode_to_curve"]["per_sec_all_gpus"]
         line["extra"] = extra

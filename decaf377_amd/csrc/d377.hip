@@ -300,15 +300,52 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(
     store32(out32, i, w);
   }
 }
-// (x/z, y/z) as Montgomery-256 limbs: CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81)
+// (x/z, y/z) as Montgomery-256 limbs: CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81), with
+// the batched inversion that name implies (Montgomery's trick).  A lane walks its grid-stride elements
+// twice: forward it multiplies the z's up, parking each exclusive prefix product in the element's own
+// 64-byte output slot; then ONE inversion (x^(q-2), ~380 field operations) of the lane's total; backward
+// it peels 1/z_i = inverse * prefix_i, inverse *= z_i.  About 12 products per element plus the inversion
+// shared by the lane's ~32 elements, against one inversion per element before.  A zero z (not a group
+// element; Fq::inverse returns None there) yields a zero record and is kept out of the product.
+constexpr int AFFINE_PER_LANE = 32;
+__device__ __forceinline__ fe load_z_or_one(const uint64_t* xyzt, size_t i, bool* was_zero) {
+  uint32_t w[8];
+  load32(reinterpret_cast<const uint8_t*>(xyzt), 4 * i + 2, w);
+  const fe z = fe_from_mont256_words(w);
+  *was_zero = fe_is_zero(z);
+  return fe_select(*was_zero, fe_const(FE_ONE), z);
+}
 __global__ void __launch_bounds__(BLOCK) k_to_affine(const uint64_t* xyzt, size_t n, uint64_t* xy) {
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    const ge g = load_ge_mont256(xyzt, i);
-    const fe zi = fe_invert(g.z);
-    uint8_t* b = reinterpret_cast<uint8_t*>(xy);
+  const size_t T = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= n) return;
+  uint32_t* slots = reinterpret_cast<uint32_t*>(xy);       // 16 words per element
+  fe p = fe_const(FE_ONE);
+  size_t last = t;
+  for (size_t i = t; i < n; i += T) {
+    bool zz;
+    const fe z = load_z_or_one(xyzt, i, &zz);
+    slot_store(slots + 16 * i, p);                          // product of this lane's earlier z's
+    p = fe_mul(p, z);
+    last = i;
+  }
+  fe inv = fe_invert(p);
+  for (size_t i = last;; i -= T) {
+    bool zz;
+    const fe z = load_z_or_one(xyzt, i, &zz);
+    const fe zi = fe_mul(inv, slot_load(slots + 16 * i));   // 1 / z_i
+    inv = fe_mul(inv, z);
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
+    uint8_t* o = reinterpret_cast<uint8_t*>(xy);
     uint32_t w[8];
-    fe_to_mont256_words(fe_mul(g.x, zi), w); store32(b, 2 * i, w);
-    fe_to_mont256_words(fe_mul(g.y, zi), w); store32(b, 2 * i + 1, w);
+    load32(b, 4 * i + 0, w);
+    const fe x = fe_from_mont256_words(w);
+    load32(b, 4 * i + 1, w);
+    const fe y = fe_from_mont256_words(w);
+    fe_to_mont256_words(fe_mul(x, zi), w);
+    if (zz) store32_zero(o, 2 * i); else store32(o, 2 * i, w);
+    fe_to_mont256_words(fe_mul(y, zi), w);
+    if (zz) store32_zero(o, 2 * i + 1); else store32(o, 2 * i + 1, w);
+    if (i == t) break;
   }
 }
 
@@ -539,9 +576,19 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_encode_to_curve_wide, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
                          op == OP_ENCODE_WIDE48 ? 48 : 64, n, (uint8_t*)out0);
       break;
-    case OP_AFFINE:
-      hipLaunchKernelGGL(k_to_affine, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
+    case OP_AFFINE: {
+      // ~AFFINE_PER_LANE elements per lane so that one inversion serves many, but never fewer lanes than one
+      // wave per SIMD.  Measured (tools/affine_bench.py, 2^20 elements): 0.28 / 0.40 / 0.65 / 1.14 ms at 1 / 2 / 4 / 8
+      // blocks per CU -- every extra lane is an extra 380-operation inversion -- against 2.7 ms for one inversion
+      // per element.  D377_AFFINE_BLOCKS_PER_CU is a developer override for that sweep.
+      size_t lanes = (n + AFFINE_PER_LANE - 1) / AFFINE_PER_LANE;
+      size_t fill = (size_t)d.cus * BLOCK;
+      if (const char* e = getenv("D377_AFFINE_BLOCKS_PER_CU")) fill = (size_t)d.cus * (size_t)(atoi(e) > 0 ? atoi(e) : 1) * BLOCK;
+      if (lanes < fill) lanes = fill < n ? fill : n;
+      const int ga = (int)((lanes + BLOCK - 1) / BLOCK);
+      hipLaunchKernelGGL(k_to_affine, dim3(ga), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
+    }
     case OP_FQ_BIN:
     case OP_FQ_UN:
       hipLaunchKernelGGL(k_fq_op, dim3(g), dim3(BLOCK), 0, s, aux, (const uint64_t*)in0, (const uint64_t*)in1, n,

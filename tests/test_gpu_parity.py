@@ -388,6 +388,16 @@ def test_wide_bytes_and_affine(ctx, oracle):
     P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
     xy = ctx.to_affine(P)
     assert (xy == oracle.to_affine(P)).all()
+    # batched inversion (Montgomery's trick per lane): sizes around the lanes-per-launch boundary, and
+    # records with z = 0 (no inverse: zero output) that must not poison their lane's other elements
+    for m in (1, 2, 255, 257, 70000, (1 << 19) + 11):
+        big = np.tile(P, (m // n + 1, 1))[:m].copy()
+        big[::1237, 8:12] = 0
+        want = oracle.to_affine(big[: min(m, 5000)])
+        got = ctx.to_affine(big)
+        assert (got[: want.shape[0]] == want).all()
+        assert not got[::1237].any()
+        assert (got[-3:] == oracle.to_affine(big[-3:])).all()
 
 
 def test_api_contract_edges(ctx, torch_mod, oracle):
