@@ -1,76 +1,90 @@
 //! `decaf377::gpu` — batch entry points backed by libdecaf377_amd.so (MI355X).
 //!
-//! UNBUILT SOURCE (no Rust toolchain in the build image). Mirrors include/decaf377_amd.h.
+//! UNBUILT SOURCE (no Rust toolchain in the build image).  Intended placement: `src/gpu.rs` inside the
+//! crate behind a `gpu` feature, with `src/gpu/ffi.rs` = rust/src/ffi.rs (generated from
+//! include/decaf377_amd.h).  tests/test_rust_shim.py checks every `ffi::d377_*` call below against
+//! the header (name and argument count) and the extern block against the header (every type).
+//!
 //! Per-element semantics are those of the existing methods:
-//!   Encoding::vartime_decompress   src/ark_curve/encoding.rs:32-83
-//!   Element::vartime_compress      src/ark_curve/encoding.rs:116-128
-//!   Element::encode_to_curve       src/ark_curve/elligator.rs:74-76
-//!   Element::hash_to_curve         src/ark_curve/elligator.rs:67-71
-//!   Element * Fr                   src/ark_curve/ops/projective.rs:106-131
+//!   Encoding::vartime_decompress      src/ark_curve/encoding.rs:32-83
+//!   Element::vartime_compress         src/ark_curve/encoding.rs:116-128
+//!   Element::encode_to_curve          src/ark_curve/elligator.rs:74-76
+//!   Element::hash_to_curve            src/ark_curve/elligator.rs:67-71
+//!   Element + / double / neg / ==     src/ark_curve/ops/projective.rs:5-104, element/projective.rs:65-86
+//!   Element * Fr                      src/ark_curve/ops/projective.rs:106-131
 //!   Element::vartime_multiscalar_mul  src/ark_curve/element/projective.rs:99-117
-//!   Fq::sqrt_ratio_zeta            src/ark_curve/invsqrt.rs:75-166
+//!   CurveGroup::normalize_batch       src/ark_curve/element.rs:74-81
+//!   Fq::sqrt_ratio_zeta               src/ark_curve/invsqrt.rs:75-166 (min_curve: src/min_curve/invsqrt.rs:73-95)
+//!   Fq add/sub/mul/square/neg/inverse src/fields/fq/u64/wrapper.rs:99-132
+//!   Fq::from_le_bytes_mod_order       src/fields/fq.rs:90-102
+//!
+//! One three-line addition to the crate is needed: `Fq` keeps its arkworks value private to
+//! `src/fields/fq/u64/wrapper.rs`, and the C ABI exchanges Elements as Montgomery limbs, so that file gets
+//!
+//!     pub(crate) fn to_montgomery_limbs(&self) -> [u64; N] { self.0 .0 .0 }
+//!
+//! next to the existing `pub const fn from_montgomery_limbs` (wrapper.rs:82-85).
 #![cfg(feature = "gpu")]
 
-use core::ffi::{c_char, c_int};
+use core::ffi::c_void;
 use std::ffi::CStr;
 
+use crate::ark_curve::EdwardsProjective;
 use crate::{Element, Encoding, EncodingError, Fq, Fr};
 
-#[repr(C)]
-pub struct D377Ctx {
-    _private: [u8; 0],
+#[path = "gpu/ffi.rs"]
+pub mod ffi;
+
+/// Which backend's root `sqrt_ratio_zeta_batch` returns (the flags are the same).
+#[derive(Copy, Clone, Debug, PartialEq, Eq)]
+pub enum SqrtRoot {
+    /// `Fq::sqrt_ratio_zeta` of the `arkworks` backend (Sarkar tables).
+    Ark = ffi::D377_SQRT_ROOT_ARK as isize,
+    /// `Fq::non_arkworks_sqrt_ratio_zeta` of the `min_curve` backend (Tonelli-Shanks, seed 11^m).
+    MinCurve = ffi::D377_SQRT_ROOT_MIN_CURVE as isize,
 }
 
-#[allow(non_snake_case)]
-extern "C" {
-    fn d377_ctx_create(device_ids: *const c_int, n_dev: c_int, out: *mut *mut D377Ctx) -> c_int;
-    fn d377_ctx_destroy(ctx: *mut D377Ctx);
-    fn d377_last_error() -> *const c_char;
-    fn d377_batch_sqrt_ratio_zeta(ctx: *mut D377Ctx, num32: *const u8, den32: *const u8, n: usize,
-                                  root32: *mut u8, was_square: *mut u8) -> c_int;
-    fn d377_batch_decompress(ctx: *mut D377Ctx, enc32: *const u8, n: usize, xyzt: *mut u64, status: *mut u8) -> c_int;
-    fn d377_batch_compress(ctx: *mut D377Ctx, xyzt: *const u64, n: usize, enc32: *mut u8) -> c_int;
-    fn d377_batch_scalar_mul_base(ctx: *mut D377Ctx, scalar32: *const u8, n: usize, out32: *mut u8) -> c_int;
-    fn d377_batch_scalar_mul_var(ctx: *mut D377Ctx, enc32: *const u8, scalar32: *const u8, n: usize,
-                                 out32: *mut u8, status: *mut u8) -> c_int;
-    fn d377_batch_encode_to_curve(ctx: *mut D377Ctx, fq32: *const u8, n: usize, out32: *mut u8) -> c_int;
-    fn d377_batch_hash_to_curve(ctx: *mut D377Ctx, r1: *const u8, r2: *const u8, n: usize, out32: *mut u8) -> c_int;
-    fn d377_msm(ctx: *mut D377Ctx, xyzt: *const u64, scalar32: *const u8, n: usize, enc32_out: *mut u8,
-                xyzt_out: *mut u64) -> c_int;
-}
-
-/// Owns one `d377_ctx` (device tables + scratch). `Send`, not `Sync`: one call in flight.
-pub struct GpuContext(*mut D377Ctx);
+/// Owns one `d377_ctx` (device tables, streams, scratch).  Calls on one context are serialised inside the
+/// library, so `&GpuContext` may be shared between threads.
+pub struct GpuContext(*mut ffi::D377Ctx);
 unsafe impl Send for GpuContext {}
+unsafe impl Sync for GpuContext {}
 
 #[derive(Debug)]
 pub struct GpuError(pub i32, pub String);
 
-fn check(rc: c_int) -> Result<(), GpuError> {
-    if rc == 0 {
+fn check(rc: i32) -> Result<(), GpuError> {
+    if rc == ffi::D377_OK {
         return Ok(());
     }
-    let msg = unsafe { CStr::from_ptr(d377_last_error()) }.to_string_lossy().into_owned();
+    let msg = unsafe { CStr::from_ptr(ffi::d377_last_error()) }.to_string_lossy().into_owned();
     Err(GpuError(rc, msg))
 }
 
 impl GpuContext {
+    /// `device_ids` empty = device 0.  Several ids: host batches are split into contiguous slices over them.
     pub fn new(device_ids: &[i32]) -> Result<Self, GpuError> {
         let mut p = core::ptr::null_mut();
-        check(unsafe { d377_ctx_create(device_ids.as_ptr(), device_ids.len() as c_int, &mut p) })?;
+        check(unsafe { ffi::d377_ctx_create(device_ids.as_ptr(), device_ids.len() as i32, &mut p) })?;
         Ok(Self(p))
+    }
+    pub fn num_devices(&self) -> usize {
+        unsafe { ffi::d377_ctx_num_devices(self.0) as usize }
     }
 }
 impl Drop for GpuContext {
     fn drop(&mut self) {
-        unsafe { d377_ctx_destroy(self.0) }
+        unsafe { ffi::d377_ctx_destroy(self.0) }
     }
 }
 
 // ---- record conversions ------------------------------------------------------------------------
-// Encoding(pub [u8; 32]) is repr-transparent over the bytes, so &[Encoding] is already packed.
+// Encoding(pub [u8; 32]) is a newtype over the bytes, so &[Encoding] is already a packed [n][32] array.
 fn enc_ptr(e: &[Encoding]) -> *const u8 {
     e.as_ptr() as *const u8
+}
+fn enc_mut_ptr(e: &mut [Encoding]) -> *mut u8 {
+    e.as_mut_ptr() as *mut u8
 }
 fn pack32<T>(xs: &[T], f: impl Fn(&T) -> [u8; 32]) -> Vec<u8> {
     let mut v = Vec::with_capacity(32 * xs.len());
@@ -79,105 +93,306 @@ fn pack32<T>(xs: &[T], f: impl Fn(&T) -> [u8; 32]) -> Vec<u8> {
     }
     v
 }
+fn fq_from_canonical(bytes: &[u8]) -> Fq {
+    let mut r = [0u8; 32];
+    r.copy_from_slice(bytes);
+    Fq::from_bytes_checked(&r).expect("the library returns canonical bytes")
+}
+fn results<T>(status: &[u8], mut ok: impl FnMut(usize) -> T) -> Vec<Result<T, EncodingError>> {
+    (0..status.len())
+        .map(|i| if status[i] == 0 { Ok(ok(i)) } else { Err(EncodingError::InvalidEncoding) })
+        .collect()
+}
 /// X, Y, Z, T Montgomery limbs (the C ABI order); ark's Projective stores (x, y, t, z).
-fn element_to_xyzt(e: &Element) -> [u64; 16] {
+fn element_to_xyzt(e: &Element, o: &mut [u64]) {
     let p = &e.inner;
-    let mut o = [0u64; 16];
-    o[0..4].copy_from_slice(&p.x.0 .0 .0);
-    o[4..8].copy_from_slice(&p.y.0 .0 .0);
-    o[8..12].copy_from_slice(&p.z.0 .0 .0);
-    o[12..16].copy_from_slice(&p.t.0 .0 .0);
-    o
+    o[0..4].copy_from_slice(&p.x.to_montgomery_limbs());
+    o[4..8].copy_from_slice(&p.y.to_montgomery_limbs());
+    o[8..12].copy_from_slice(&p.z.to_montgomery_limbs());
+    o[12..16].copy_from_slice(&p.t.to_montgomery_limbs());
+}
+fn elements_to_xyzt(es: &[Element]) -> Vec<u64> {
+    let mut v = vec![0u64; 16 * es.len()];
+    for (e, o) in es.iter().zip(v.chunks_exact_mut(16)) {
+        element_to_xyzt(e, o);
+    }
+    v
+}
+fn fq_limbs(l: &[u64]) -> Fq {
+    Fq::from_montgomery_limbs([l[0], l[1], l[2], l[3]])
 }
 fn element_from_xyzt(o: &[u64]) -> Element {
-    let f = |l: &[u64]| Fq::from_montgomery_limbs([l[0], l[1], l[2], l[3]]);
+    // `Decaf377EdwardsConfig::BaseField` is the crate's own `Fq` (src/ark_curve/edwards.rs:21), and
+    // `Projective::new_unchecked` takes (x, y, t, z)
     Element {
-        inner: crate::ark_curve::edwards::EdwardsProjective::new_unchecked(
-            f(&o[0..4]).0, f(&o[4..8]).0, f(&o[12..16]).0, f(&o[8..12]).0, // (x, y, t, z)
-        ),
+        inner: EdwardsProjective::new_unchecked(fq_limbs(&o[0..4]), fq_limbs(&o[4..8]), fq_limbs(&o[12..16]), fq_limbs(&o[8..12])),
     }
 }
+fn elements_from_xyzt(v: &[u64]) -> Vec<Element> {
+    v.chunks_exact(16).map(element_from_xyzt).collect()
+}
+fn fqs_to_limbs(xs: &[Fq]) -> Vec<u64> {
+    xs.iter().flat_map(|x| x.to_montgomery_limbs()).collect()
+}
 
-// ---- batch API ---------------------------------------------------------------------------------
+// ---- Encoding ----------------------------------------------------------------------------------
 impl Encoding {
-    /// One `Result` per input, same order as `encs`.
-    pub fn vartime_decompress_batch(ctx: &mut GpuContext, encs: &[Encoding])
-        -> Result<Vec<Result<Element, EncodingError>>, GpuError> {
+    /// Batch form of `vartime_decompress`: one `Result` per input, same order.
+    pub fn vartime_decompress_batch(ctx: &GpuContext, encs: &[Encoding]) -> Result<Vec<Result<Element, EncodingError>>, GpuError> {
         let n = encs.len();
         let mut xyzt = vec![0u64; 16 * n];
         let mut st = vec![0u8; n];
-        check(unsafe { d377_batch_decompress(ctx.0, enc_ptr(encs), n, xyzt.as_mut_ptr(), st.as_mut_ptr()) })?;
-        Ok((0..n)
-            .map(|i| if st[i] == 0 { Ok(element_from_xyzt(&xyzt[16 * i..16 * i + 16])) } else { Err(EncodingError::InvalidEncoding) })
-            .collect())
+        check(unsafe { ffi::d377_batch_decompress(ctx.0, enc_ptr(encs), n, xyzt.as_mut_ptr(), st.as_mut_ptr()) })?;
+        Ok(results(&st, |i| element_from_xyzt(&xyzt[16 * i..16 * i + 16])))
+    }
+    /// decompress then compress (the round trip of tests/encoding.rs:97-107): `Ok(e)` has `e == input`.
+    pub fn roundtrip_batch(ctx: &GpuContext, encs: &[Encoding]) -> Result<Vec<Result<Encoding, EncodingError>>, GpuError> {
+        let n = encs.len();
+        let mut out = vec![Encoding([0u8; 32]); n];
+        let mut st = vec![0u8; n];
+        check(unsafe { ffi::d377_batch_roundtrip(ctx.0, enc_ptr(encs), n, enc_mut_ptr(&mut out), st.as_mut_ptr()) })?;
+        Ok(results(&st, |i| out[i]))
     }
 }
 
+// ---- Element -----------------------------------------------------------------------------------
 impl Element {
-    pub fn vartime_compress_batch(ctx: &mut GpuContext, els: &[Element]) -> Result<Vec<Encoding>, GpuError> {
-        let n = els.len();
-        let xyzt: Vec<u64> = els.iter().flat_map(|e| element_to_xyzt(e)).collect();
-        let mut out = vec![Encoding([0u8; 32]); n];
-        check(unsafe { d377_batch_compress(ctx.0, xyzt.as_ptr(), n, out.as_mut_ptr() as *mut u8) })?;
+    pub fn vartime_compress_batch(ctx: &GpuContext, els: &[Element]) -> Result<Vec<Encoding>, GpuError> {
+        let xyzt = elements_to_xyzt(els);
+        let mut out = vec![Encoding([0u8; 32]); els.len()];
+        check(unsafe { ffi::d377_batch_compress(ctx.0, xyzt.as_ptr(), els.len(), enc_mut_ptr(&mut out)) })?;
         Ok(out)
     }
-    pub fn encode_to_curve_batch(ctx: &mut GpuContext, rs: &[Fq]) -> Result<Vec<Encoding>, GpuError> {
+    pub fn encode_to_curve_batch(ctx: &GpuContext, rs: &[Fq]) -> Result<Vec<Encoding>, GpuError> {
         let bytes = pack32(rs, |r| r.to_bytes());
         let mut out = vec![Encoding([0u8; 32]); rs.len()];
-        check(unsafe { d377_batch_encode_to_curve(ctx.0, bytes.as_ptr(), rs.len(), out.as_mut_ptr() as *mut u8) })?;
+        check(unsafe { ffi::d377_batch_encode_to_curve(ctx.0, bytes.as_ptr(), rs.len(), enc_mut_ptr(&mut out)) })?;
         Ok(out)
     }
-    pub fn hash_to_curve_batch(ctx: &mut GpuContext, r1: &[Fq], r2: &[Fq]) -> Result<Vec<Encoding>, GpuError> {
+    /// `encode_to_curve(Fq::from_le_bytes_mod_order(h))` for 48- or 64-byte hash outputs, fused on the device.
+    pub fn encode_to_curve_wide_batch(ctx: &GpuContext, hashes: &[u8], len: usize) -> Result<Vec<Encoding>, GpuError> {
+        assert!(len == 48 || len == 64);
+        assert_eq!(hashes.len() % len, 0);
+        let n = hashes.len() / len;
+        let mut out = vec![Encoding([0u8; 32]); n];
+        check(unsafe { ffi::d377_batch_encode_to_curve_wide(ctx.0, hashes.as_ptr(), len, n, enc_mut_ptr(&mut out)) })?;
+        Ok(out)
+    }
+    pub fn hash_to_curve_batch(ctx: &GpuContext, r1: &[Fq], r2: &[Fq]) -> Result<Vec<Encoding>, GpuError> {
         assert_eq!(r1.len(), r2.len());
         let (a, b) = (pack32(r1, |r| r.to_bytes()), pack32(r2, |r| r.to_bytes()));
         let mut out = vec![Encoding([0u8; 32]); r1.len()];
-        check(unsafe { d377_batch_hash_to_curve(ctx.0, a.as_ptr(), b.as_ptr(), r1.len(), out.as_mut_ptr() as *mut u8) })?;
+        check(unsafe { ffi::d377_batch_hash_to_curve(ctx.0, a.as_ptr(), b.as_ptr(), r1.len(), enc_mut_ptr(&mut out)) })?;
         Ok(out)
     }
     /// `Element::GENERATOR * k` for every k.
-    pub fn mul_generator_batch(ctx: &mut GpuContext, ks: &[Fr]) -> Result<Vec<Encoding>, GpuError> {
+    pub fn mul_generator_batch(ctx: &GpuContext, ks: &[Fr]) -> Result<Vec<Encoding>, GpuError> {
         let bytes = pack32(ks, |k| k.to_bytes());
         let mut out = vec![Encoding([0u8; 32]); ks.len()];
-        check(unsafe { d377_batch_scalar_mul_base(ctx.0, bytes.as_ptr(), ks.len(), out.as_mut_ptr() as *mut u8) })?;
+        check(unsafe { ffi::d377_batch_scalar_mul_base(ctx.0, bytes.as_ptr(), ks.len(), enc_mut_ptr(&mut out)) })?;
         Ok(out)
     }
     /// `decompress(P_i)? * k_i`, compressed.
-    pub fn scalar_mul_batch(ctx: &mut GpuContext, ps: &[Encoding], ks: &[Fr])
-        -> Result<Vec<Result<Encoding, EncodingError>>, GpuError> {
+    pub fn scalar_mul_batch(ctx: &GpuContext, ps: &[Encoding], ks: &[Fr]) -> Result<Vec<Result<Encoding, EncodingError>>, GpuError> {
         assert_eq!(ps.len(), ks.len());
         let n = ps.len();
         let bytes = pack32(ks, |k| k.to_bytes());
         let mut out = vec![Encoding([0u8; 32]); n];
         let mut st = vec![0u8; n];
-        check(unsafe { d377_batch_scalar_mul_var(ctx.0, enc_ptr(ps), bytes.as_ptr(), n, out.as_mut_ptr() as *mut u8, st.as_mut_ptr()) })?;
-        Ok((0..n).map(|i| if st[i] == 0 { Ok(out[i]) } else { Err(EncodingError::InvalidEncoding) }).collect())
+        check(unsafe {
+            ffi::d377_batch_scalar_mul_var(ctx.0, enc_ptr(ps), bytes.as_ptr(), n, enc_mut_ptr(&mut out), st.as_mut_ptr())
+        })?;
+        Ok(results(&st, |i| out[i]))
     }
-    /// GPU form of `vartime_multiscalar_mul` (Pippenger).
-    pub fn vartime_multiscalar_mul_gpu(ctx: &mut GpuContext, scalars: &[Fr], points: &[Element]) -> Result<Element, GpuError> {
+    pub fn add_batch(ctx: &GpuContext, ps: &[Element], qs: &[Element]) -> Result<Vec<Element>, GpuError> {
+        assert_eq!(ps.len(), qs.len());
+        let (a, b) = (elements_to_xyzt(ps), elements_to_xyzt(qs));
+        let mut out = vec![0u64; 16 * ps.len()];
+        check(unsafe { ffi::d377_batch_add(ctx.0, a.as_ptr(), b.as_ptr(), ps.len(), out.as_mut_ptr()) })?;
+        Ok(elements_from_xyzt(&out))
+    }
+    pub fn double_batch(ctx: &GpuContext, ps: &[Element]) -> Result<Vec<Element>, GpuError> {
+        let a = elements_to_xyzt(ps);
+        let mut out = vec![0u64; 16 * ps.len()];
+        check(unsafe { ffi::d377_batch_double(ctx.0, a.as_ptr(), ps.len(), out.as_mut_ptr()) })?;
+        Ok(elements_from_xyzt(&out))
+    }
+    pub fn neg_batch(ctx: &GpuContext, ps: &[Element]) -> Result<Vec<Element>, GpuError> {
+        let a = elements_to_xyzt(ps);
+        let mut out = vec![0u64; 16 * ps.len()];
+        check(unsafe { ffi::d377_batch_neg(ctx.0, a.as_ptr(), ps.len(), out.as_mut_ptr()) })?;
+        Ok(elements_from_xyzt(&out))
+    }
+    /// `PartialEq` for every pair (x1*y2 == x2*y1).
+    pub fn eq_batch(ctx: &GpuContext, ps: &[Element], qs: &[Element]) -> Result<Vec<bool>, GpuError> {
+        assert_eq!(ps.len(), qs.len());
+        let (a, b) = (elements_to_xyzt(ps), elements_to_xyzt(qs));
+        let mut eq = vec![0u8; ps.len()];
+        check(unsafe { ffi::d377_batch_eq(ctx.0, a.as_ptr(), b.as_ptr(), ps.len(), eq.as_mut_ptr()) })?;
+        Ok(eq.into_iter().map(|v| v != 0).collect())
+    }
+    pub fn is_identity_batch(ctx: &GpuContext, ps: &[Element]) -> Result<Vec<bool>, GpuError> {
+        let a = elements_to_xyzt(ps);
+        let mut id = vec![0u8; ps.len()];
+        check(unsafe { ffi::d377_batch_is_identity(ctx.0, a.as_ptr(), ps.len(), id.as_mut_ptr()) })?;
+        Ok(id.into_iter().map(|v| v != 0).collect())
+    }
+    /// `CurveGroup::normalize_batch`: affine (x, y) of every element (one batched inversion per device lane).
+    pub fn normalize_batch_gpu(ctx: &GpuContext, ps: &[Element]) -> Result<Vec<(Fq, Fq)>, GpuError> {
+        let a = elements_to_xyzt(ps);
+        let mut xy = vec![0u64; 8 * ps.len()];
+        check(unsafe { ffi::d377_batch_to_affine(ctx.0, a.as_ptr(), ps.len(), xy.as_mut_ptr()) })?;
+        Ok(xy.chunks_exact(8).map(|c| (fq_limbs(&c[0..4]), fq_limbs(&c[4..8]))).collect())
+    }
+    /// GPU form of `vartime_multiscalar_mul` (Pippenger bucket method).
+    pub fn vartime_multiscalar_mul_gpu(ctx: &GpuContext, scalars: &[Fr], points: &[Element]) -> Result<Element, GpuError> {
         assert_eq!(scalars.len(), points.len());
-        let xyzt: Vec<u64> = points.iter().flat_map(|e| element_to_xyzt(e)).collect();
+        let xyzt = elements_to_xyzt(points);
         let bytes = pack32(scalars, |k| k.to_bytes());
         let mut enc = [0u8; 32];
         let mut out = [0u64; 16];
-        check(unsafe { d377_msm(ctx.0, xyzt.as_ptr(), bytes.as_ptr(), points.len(), enc.as_mut_ptr(), out.as_mut_ptr()) })?;
+        check(unsafe { ffi::d377_msm(ctx.0, xyzt.as_ptr(), bytes.as_ptr(), points.len(), enc.as_mut_ptr(), out.as_mut_ptr()) })?;
         Ok(element_from_xyzt(&out))
+    }
+    /// The same over Encodings: invalid ones are reported and left out of the sum.
+    pub fn vartime_multiscalar_mul_encoded_gpu(ctx: &GpuContext, scalars: &[Fr], points: &[Encoding])
+        -> Result<(Element, Vec<Result<(), EncodingError>>), GpuError> {
+        assert_eq!(scalars.len(), points.len());
+        let bytes = pack32(scalars, |k| k.to_bytes());
+        let mut enc = [0u8; 32];
+        let mut out = [0u64; 16];
+        let mut st = vec![0u8; points.len()];
+        check(unsafe {
+            ffi::d377_msm_encoded(ctx.0, enc_ptr(points), bytes.as_ptr(), points.len(), enc.as_mut_ptr(), out.as_mut_ptr(), st.as_mut_ptr())
+        })?;
+        Ok((element_from_xyzt(&out), results(&st, |_| ())))
     }
 }
 
+// ---- Fq / Fr -----------------------------------------------------------------------------------
+/// Which `Fq` operator `fq_op_batch` applies (D377_FQ_*).
+#[derive(Copy, Clone, Debug)]
+pub enum FqOp {
+    Add = ffi::D377_FQ_ADD as isize,
+    Sub = ffi::D377_FQ_SUB as isize,
+    Mul = ffi::D377_FQ_MUL as isize,
+    Square = ffi::D377_FQ_SQUARE as isize,
+    Neg = ffi::D377_FQ_NEG as isize,
+    Inverse = ffi::D377_FQ_INVERSE as isize,
+}
+
 impl Fq {
-    pub fn sqrt_ratio_zeta_batch(ctx: &mut GpuContext, num: &[Fq], den: &[Fq]) -> Result<Vec<(bool, Fq)>, GpuError> {
+    pub fn sqrt_ratio_zeta_batch(ctx: &GpuContext, root: SqrtRoot, num: &[Fq], den: &[Fq]) -> Result<Vec<(bool, Fq)>, GpuError> {
         assert_eq!(num.len(), den.len());
         let n = num.len();
         let (a, b) = (pack32(num, |x| x.to_bytes()), pack32(den, |x| x.to_bytes()));
-        let mut root = vec![0u8; 32 * n];
+        let mut out = vec![0u8; 32 * n];
         let mut ws = vec![0u8; n];
-        check(unsafe { d377_batch_sqrt_ratio_zeta(ctx.0, a.as_ptr(), b.as_ptr(), n, root.as_mut_ptr(), ws.as_mut_ptr()) })?;
-        Ok((0..n)
-            .map(|i| {
-                let mut r = [0u8; 32];
-                r.copy_from_slice(&root[32 * i..32 * i + 32]);
-                (ws[i] != 0, Fq::from_bytes_checked(&r).expect("library returns canonical bytes"))
-            })
-            .collect())
+        check(unsafe {
+            ffi::d377_batch_sqrt_ratio_zeta_ex(ctx.0, root as i32, a.as_ptr(), b.as_ptr(), n, out.as_mut_ptr(), ws.as_mut_ptr())
+        })?;
+        Ok((0..n).map(|i| (ws[i] != 0, fq_from_canonical(&out[32 * i..32 * i + 32]))).collect())
+    }
+    /// Element-wise operator; `Inverse` yields `None` for zero inputs like `Fq::inverse`.
+    pub fn op_batch(ctx: &GpuContext, op: FqOp, a: &[Fq], b: Option<&[Fq]>) -> Result<Vec<Option<Fq>>, GpuError> {
+        let n = a.len();
+        let la = fqs_to_limbs(a);
+        let lb = b.map(|b| {
+            assert_eq!(b.len(), n);
+            fqs_to_limbs(b)
+        });
+        let mut out = vec![0u64; 4 * n];
+        let mut st = vec![0u8; n];
+        check(unsafe {
+            ffi::d377_batch_fq_op(ctx.0, op as i32, la.as_ptr(), lb.as_ref().map_or(core::ptr::null(), |v| v.as_ptr()), n,
+                                  out.as_mut_ptr(), st.as_mut_ptr())
+        })?;
+        Ok((0..n).map(|i| if st[i] == 0 { Some(fq_limbs(&out[4 * i..4 * i + 4])) } else { None }).collect())
+    }
+    /// `Fq::from_le_bytes_mod_order` on 48- or 64-byte strings.
+    pub fn from_wide_bytes_batch(ctx: &GpuContext, bytes: &[u8], len: usize) -> Result<Vec<Fq>, GpuError> {
+        assert!(len == 48 || len == 64);
+        assert_eq!(bytes.len() % len, 0);
+        let n = bytes.len() / len;
+        let mut out = vec![0u8; 32 * n];
+        check(unsafe { ffi::d377_batch_fq_from_wide_bytes(ctx.0, bytes.as_ptr(), len, n, out.as_mut_ptr()) })?;
+        Ok(out.chunks_exact(32).map(fq_from_canonical).collect())
+    }
+    /// `Fq::from_bytes_checked` for every 32-byte string.
+    pub fn from_bytes_checked_batch(ctx: &GpuContext, bytes: &[[u8; 32]]) -> Result<Vec<Result<Fq, EncodingError>>, GpuError> {
+        let n = bytes.len();
+        let mut out = vec![0u64; 4 * n];
+        let mut st = vec![0u8; n];
+        check(unsafe { ffi::d377_batch_fq_from_bytes_checked(ctx.0, bytes.as_ptr() as *const u8, n, out.as_mut_ptr(), st.as_mut_ptr()) })?;
+        Ok(results(&st, |i| fq_limbs(&out[4 * i..4 * i + 4])))
+    }
+    pub fn to_bytes_batch(ctx: &GpuContext, xs: &[Fq]) -> Result<Vec<[u8; 32]>, GpuError> {
+        let l = fqs_to_limbs(xs);
+        let mut out = vec![[0u8; 32]; xs.len()];
+        check(unsafe { ffi::d377_batch_fq_to_bytes(ctx.0, l.as_ptr(), xs.len(), out.as_mut_ptr() as *mut u8) })?;
+        Ok(out)
+    }
+}
+
+impl Fr {
+    /// `Fr::from_le_bytes_mod_order` for every 32-byte string -> canonical bytes.
+    pub fn from_le_bytes_mod_order_batch(ctx: &GpuContext, bytes: &[[u8; 32]]) -> Result<Vec<[u8; 32]>, GpuError> {
+        let mut out = vec![[0u8; 32]; bytes.len()];
+        check(unsafe {
+            ffi::d377_batch_fr_from_le_bytes_mod_order(ctx.0, bytes.as_ptr() as *const u8, bytes.len(), out.as_mut_ptr() as *mut u8)
+        })?;
+        Ok(out)
+    }
+    /// `Fr::from_bytes_checked`: `Err` for strings >= r.
+    pub fn from_bytes_checked_batch(ctx: &GpuContext, bytes: &[[u8; 32]]) -> Result<Vec<Result<[u8; 32], EncodingError>>, GpuError> {
+        let mut out = vec![[0u8; 32]; bytes.len()];
+        let mut st = vec![0u8; bytes.len()];
+        check(unsafe {
+            ffi::d377_batch_fr_from_bytes_checked(ctx.0, bytes.as_ptr() as *const u8, bytes.len(), out.as_mut_ptr() as *mut u8, st.as_mut_ptr())
+        })?;
+        Ok(results(&st, |i| out[i]))
+    }
+}
+
+// ---- device-pointer forms -----------------------------------------------------------------------
+/// Batches that already live in HBM (hipMalloc'ed by the caller, 16-byte aligned): no copies, enqueued on
+/// `stream` (a `hipStream_t`), no host synchronisation.  Thin `unsafe` pass-throughs: the caller owns the
+/// device memory and its lifetime.
+pub mod dev {
+    use super::*;
+
+    /// `Encoding` records in, `Encoding` records + status bytes out.
+    pub unsafe fn scalar_mul_var(ctx: &GpuContext, dev: i32, stream: *mut c_void, enc32: *const u8, scalar32: *const u8, n: usize,
+                                 enc32_out: *mut u8, status: *mut u8) -> Result<(), GpuError> {
+        check(ffi::d377_batch_scalar_mul_var_dev(ctx.0, dev, stream, enc32, scalar32, n, enc32_out, status))
+    }
+    pub unsafe fn scalar_mul_base(ctx: &GpuContext, dev: i32, stream: *mut c_void, scalar32: *const u8, n: usize, enc32_out: *mut u8)
+        -> Result<(), GpuError> {
+        check(ffi::d377_batch_scalar_mul_base_dev(ctx.0, dev, stream, scalar32, n, enc32_out))
+    }
+    pub unsafe fn decompress(ctx: &GpuContext, dev: i32, stream: *mut c_void, enc32: *const u8, n: usize, xyzt: *mut u64, status: *mut u8)
+        -> Result<(), GpuError> {
+        check(ffi::d377_batch_decompress_dev(ctx.0, dev, stream, enc32, n, xyzt, status))
+    }
+    pub unsafe fn compress(ctx: &GpuContext, dev: i32, stream: *mut c_void, xyzt: *const u64, n: usize, enc32: *mut u8) -> Result<(), GpuError> {
+        check(ffi::d377_batch_compress_dev(ctx.0, dev, stream, xyzt, n, enc32))
+    }
+    pub unsafe fn roundtrip(ctx: &GpuContext, dev: i32, stream: *mut c_void, enc32: *const u8, n: usize, enc32_out: *mut u8, status: *mut u8)
+        -> Result<(), GpuError> {
+        check(ffi::d377_batch_roundtrip_dev(ctx.0, dev, stream, enc32, n, enc32_out, status))
+    }
+    pub unsafe fn encode_to_curve(ctx: &GpuContext, dev: i32, stream: *mut c_void, fq32: *const u8, n: usize, enc32_out: *mut u8)
+        -> Result<(), GpuError> {
+        check(ffi::d377_batch_encode_to_curve_dev(ctx.0, dev, stream, fq32, n, enc32_out))
+    }
+    pub unsafe fn msm(ctx: &GpuContext, dev: i32, stream: *mut c_void, xyzt: *const u64, scalar32: *const u8, n: usize, enc32_out: *mut u8,
+                      xyzt_out: *mut u64) -> Result<(), GpuError> {
+        check(ffi::d377_msm_dev(ctx.0, dev, stream, xyzt, scalar32, n, enc32_out, xyzt_out))
+    }
+    /// An HBM-resident batch on device `root_dev`, split over all the context's GPUs by peer copies (xGMI).
+    /// `op` is one of `ffi::D377_OP_*`; buffers are those of the matching `_dev` entry point, unused ones null.
+    pub unsafe fn sharded(ctx: &GpuContext, root_dev: i32, stream: *mut c_void, op: i32, in0: *const c_void, in1: *const c_void, n: usize,
+                          out0: *mut c_void, out1: *mut c_void) -> Result<(), GpuError> {
+        check(ffi::d377_batch_sharded_dev(ctx.0, root_dev, stream, op, in0, in1, n, out0, out1))
     }
 }
