@@ -29,6 +29,7 @@ EXPORTS = [
     "d377_batch_roundtrip_dev", "d377_batch_scalar_mul_base_dev", "d377_batch_scalar_mul_var_dev",
     "d377_batch_encode_to_curve_dev", "d377_batch_hash_to_curve_dev",
     "d377_batch_sqrt_ratio_zeta_ex", "d377_batch_sqrt_ratio_zeta_ex_dev", "d377_batch_sharded_dev",
+    "d377_ctx_invariant_failures",
 ]
 
 _lib = None
@@ -65,6 +66,8 @@ def load():
     lib.d377_ctx_destroy.restype = None
     lib.d377_ctx_num_devices.argtypes = [vp]
     lib.d377_ctx_device_id.argtypes = [vp, i32]
+    lib.d377_ctx_invariant_failures.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
+    lib.d377_ctx_invariant_failures.restype = i32
     host = {
         "d377_batch_sqrt_ratio_zeta": [vp, vp, vp, sz, vp, vp],
         "d377_batch_decompress": [vp, vp, sz, vp, vp],

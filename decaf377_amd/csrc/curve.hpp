@@ -28,6 +28,7 @@ constexpr int S_HASH_BITS = 12;
 struct SqrtTables {
   const uint32_t* gtab;      // [6][256][GT_STRIDE]
   const uint8_t* s_lookup;   // [1 << S_HASH_BITS]
+  uint32_t* inv_fail;        // -DD377_CHECK_INVARIANTS builds: device counter of violated invariants (else unused)
 };
 
 #include "s_hash.inc"        // defines D377_S_HASH_K (searched offline, verified at init)
@@ -335,6 +336,28 @@ D377_HD ge ge_select(bool c, const ge& a, const ge& b) {
   return r;
 }
 
+// ---- debug invariants ------------------------------------------------------------------------
+// The reference re-checks the curve equation whenever it builds an Element under debug assertions
+// (`Element::new`, src/min_curve/element.rs:84-110; the arkworks path asserts `is_on_curve()`,
+// src/ark_curve/encoding.rs:75-78, on_curve.rs:14-39) and its CI profile keeps them on.  A build with
+// -DD377_CHECK_INVARIANTS does the same on the device after decompression, the Elligator map and the
+// scalar-multiplication loops: -X^2 + Y^2 = Z^2 + d T^2, T Z = X Y, Z != 0 (the [2r]P = 0 test of
+// on_curve.rs:26-35 costs a scalar multiplication per element and is left to the parity tests).
+// A violation bumps a counter in device memory (d377_ctx_invariant_failures); nothing traps.
+D377_HD bool ge_invariants_hold(const ge& p) {
+  const fe lhs = fe_sub(fe_sqr(p.y), fe_sqr(p.x));
+  const fe rhs = fe_add(fe_sqr(p.z), fe_mul(fe_const(FE_D), fe_sqr(p.t)));
+  const bool on_curve = fe_eq(lhs, rhs);
+  const bool segre = fe_eq(fe_mul(p.t, p.z), fe_mul(p.x, p.y));
+  return on_curve && segre && !fe_is_zero(p.z);
+}
+#if defined(D377_CHECK_INVARIANTS) && defined(__HIP_DEVICE_COMPILE__)
+#define D377_INVARIANT(T, point, enabled)                                            \
+  do { if ((enabled) && !ge_invariants_hold(point)) atomicAdd((T).inv_fail, 1u); } while (0)
+#else
+#define D377_INVARIANT(T, point, enabled) do { } while (0)
+#endif
+
 // ---- encoding ------------------------------------------------------------------------------
 // Encoding::vartime_decompress, src/ark_curve/encoding.rs:32-83.  Returns status
 // (0 ok, 1 InvalidEncoding); on failure *out is unspecified (callers write zeros).
@@ -357,12 +380,16 @@ D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8],
   out->y = fe_mul(fe_mul(fe_add(fe_const(FE_ONE), ss), v), u1);   // :71
   out->z = fe_const(FE_ONE);
   out->t = fe_mul(out->x, out->y);
+  D377_INVARIANT(T, *out, bad == 0);                      // encoding.rs:75-78 / element.rs:104-110
   return bad;
 }
 
 // Element::vartime_compress, src/ark_curve/encoding.rs:91-128 -> canonical words of s
 template <class PT>
-D377_HD void ge_compress(const SqrtTables& T, PT& pt, const ge& p, uint32_t w[8]) {
+D377_HD void ge_compress(const SqrtTables& T, PT& pt, const ge& p, uint32_t w[8], bool is_element = true) {
+  // every Element the reference can hold satisfies the invariants (Element::new); lanes that carry the
+  // leftovers of a failed decompression pass is_element = false
+  D377_INVARIANT(T, p, is_element);
   const fe a_minus_d = fe_const(FE_A_MINUS_D);
   fe u1 = fe_mul(fe_add(p.x, p.t), fe_sub(p.x, p.t));                       // :97
   fe v;
@@ -396,6 +423,7 @@ D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0) {
   fe g = fe_add(one, ss);                                                         // 1 - a s^2
   ge o;
   o.x = fe_mul(e, t); o.y = fe_mul(f, g); o.z = fe_mul(f, t); o.t = fe_mul(e, g); // :52-54
+  D377_INVARIANT(T, o, true);                                                     // :56-59
   return o;
 }
 

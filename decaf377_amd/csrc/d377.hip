@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_roundtrip(SqrtTables 
     load32(enc32, i, w);
     ge g;
     const uint32_t bad = ge_decompress(T, pt, w, &g);
-    ge_compress(T, pt, g, w);
+    ge_compress(T, pt, g, w, bad == 0);
     status[i] = (uint8_t)bad;
     if (bad) store32_zero(out32, i); else store32(out32, i, w);
   }
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
     fr_reduce_words(k);
     fr_recode_signed16(k, dg);
     ge r = ge_scalar_mul_w4(g, dg, tab);
-    ge_compress(T, pt, r, w);
+    ge_compress(T, pt, r, w, bad == 0);
     status[i] = (uint8_t)bad;
     if (bad) store32_zero(out32, i); else store32(out32, i, w);
   }
@@ -483,6 +483,8 @@ int init_device(DeviceState& d) {
   HIP_TRY(hipMalloc(&d.gtab, (size_t)6 * 256 * GT_STRIDE * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&d.s_lookup, (size_t)1 << S_HASH_BITS));
   HIP_TRY(hipMalloc(&d.fbase, (size_t)FB_WINDOWS * FB_ENTRIES * FBW_ENTRY_WORDS * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&d.inv_fail, sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(d.inv_fail, 0, sizeof(uint32_t), d.stream));
   // variable-base window tables: one per resident lane, fixed grid, grid-stride over the batch
   d.vb_blocks = d.cus * WAVES_PER_SIMD;        // exactly the resident blocks: 2 per CU
   HIP_TRY(hipMalloc(&d.vb_scratch, (size_t)d.vb_blocks * BLOCK * VB_ENTRIES * VB_ENTRY_WORDS * sizeof(uint32_t)));
@@ -503,7 +505,7 @@ void free_device(DeviceState& d) {
   if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
   (void)d.vb_guard.drain();
   (void)d.msm.guard.drain();
-  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch);
+  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.inv_fail);
   for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); (void)hipFree(d.shard[i]); }
   for (int i = 0; i < 2; ++i) {
     if (d.ev_in[i]) (void)hipEventDestroy(d.ev_in[i]);
@@ -894,6 +896,23 @@ void d377_ctx_destroy(d377_ctx* ctx) {
   delete ctx;
 }
 int d377_ctx_num_devices(const d377_ctx* ctx) { return ctx ? (int)ctx->devs.size() : 0; }
+int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count) {
+  if (!ctx || !count) return fail(D377_ERR_ARG, "%s", "null argument");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+#if defined(D377_CHECK_INVARIANTS)
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceState& d = ctx->devs[(size_t)dev];
+  HIP_TRY(hipSetDevice(d.id));
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t v = 0;
+  HIP_TRY(hipMemcpy(&v, d.inv_fail, sizeof v, hipMemcpyDeviceToHost));
+  *count = v;
+  return 1;                                   // the checks are compiled in
+#else
+  *count = 0;
+  return D377_OK;                             // not a checking build
+#endif
+}
 int d377_ctx_device_id(const d377_ctx* ctx, int dev) {
   if (!ctx || dev < 0 || (size_t)dev >= ctx->devs.size()) return -1;
   return ctx->devs[(size_t)dev].id;

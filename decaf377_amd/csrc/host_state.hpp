@@ -54,6 +54,7 @@ struct DeviceState {
   uint32_t* fbase = nullptr;
   uint32_t* vb_scratch = nullptr;
   int vb_blocks = 0;
+  uint32_t* inv_fail = nullptr;          // device counter of the -DD377_CHECK_INVARIANTS build (always allocated)
   ScratchGuard vb_guard;
   hipStream_t stream = nullptr;          // compute stream of the host-pointer entry points
   hipStream_t copy_stream = nullptr;     // PCIe copies of the pipelined host path
@@ -69,7 +70,7 @@ struct DeviceState {
   size_t shard_cap[4] = {0, 0, 0, 0};
   hipEvent_t ev_shard = nullptr;
   MsmWorkspace msm;
-  SqrtTables tables() const { return SqrtTables{gtab, s_lookup}; }
+  SqrtTables tables() const { return SqrtTables{gtab, s_lookup, inv_fail}; }
 };
 
 inline int grow(uint8_t*& p, size_t& cap, size_t bytes, size_t slack) {

@@ -79,6 +79,15 @@ class Context:
         self.device_ids = [self._lib.d377_ctx_device_id(self._h, i)
                            for i in range(self._lib.d377_ctx_num_devices(self._h))]
 
+    def invariant_failures(self, dev=0):
+        """(checks compiled in?, count): d377_ctx_invariant_failures -- the -DD377_CHECK_INVARIANTS build's
+        counterpart of the reference's debug assertions (src/min_curve/element.rs:104-110)."""
+        c = ctypes.c_uint64(0)
+        rc = self._lib.d377_ctx_invariant_failures(self._h, dev, ctypes.byref(c))
+        if rc < 0:
+            _native.check(rc)
+        return rc == 1, int(c.value)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.d377_ctx_destroy(self._h)

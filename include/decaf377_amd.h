@@ -68,6 +68,12 @@ int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out);
 void d377_ctx_destroy(d377_ctx* ctx);
 int d377_ctx_num_devices(const d377_ctx* ctx);
 int d377_ctx_device_id(const d377_ctx* ctx, int dev);
+/* Debug builds (-DD377_CHECK_INVARIANTS, the counterpart of the reference's debug assertions in
+ * Element::new, src/min_curve/element.rs:104-110, and is_on_curve, src/ark_curve/on_curve.rs:14-39): how many
+ * group elements failed the curve equation / T Z = X Y / Z != 0 after decompression, the Elligator map or on
+ * their way into compression since the context was created.  Synchronises the device.  Returns 1 when the
+ * checks are compiled in, 0 (and *count = 0) in a normal build, negative on error. */
+int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
 
 /* Fq::sqrt_ratio_zeta(num, den) -> (was_square, root)        src/ark_curve/invsqrt.rs:75-166
  * num32/den32: 32-byte strings reduced mod q like Fq::from_le_bytes_mod_order.

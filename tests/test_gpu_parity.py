@@ -881,3 +881,52 @@ def test_engine_rejects_malformed_arrays(ctx, torch_mod):
         ctx.scalar_mul_var(torch.from_numpy(enc).to(dev), torch.from_numpy(k))       # second operand on the CPU
     with pytest.raises(ValueError):
         ctx.add(torch.zeros((8, 16), dtype=torch.int64, device=dev), torch.zeros((8, 15), dtype=torch.int64, device=dev))
+
+
+def test_check_invariants_build(oracle):
+    """The -DD377_CHECK_INVARIANTS build (libdecaf377_amd_check.so): the curve equation, T Z = X Y and Z != 0
+    are re-checked on the device after decompression, the Elligator map, the scalar-multiplication loops and on
+    the way into compression -- the reference's debug assertions (src/min_curve/element.rs:104-110,
+    src/ark_curve/on_curve.rs:14-39; its CI profile keeps them on).  Valid and invalid inputs through every
+    group-level kernel leave the counter at 0 with results equal to the oracle's; records that are not curve
+    points, pushed into compress, are counted."""
+    import subprocess
+    lib = os.path.join(ROOT, "decaf377_amd", "lib", "libdecaf377_amd_check.so")
+    assert os.path.exists(lib), "build() makes it next to the product library"
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import decaf377_amd as d
+from _oracle import Oracle
+orc = Oracle(); ctx = d.Context([0])
+on, cnt = ctx.invariant_failures()
+assert on and cnt == 0
+rng = np.random.default_rng(901); n = 6000
+r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8); r1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+enc = ctx.encode_to_curve(r0)
+assert (enc == orc.encode_to_curve(r0)).all()
+raw = enc.copy(); raw[::5] = rng.integers(0, 256, (len(raw[::5]), 32), dtype=np.uint8)
+out, st = ctx.scalar_mul_var(raw, k); o_out, o_st = orc.scalar_mul_var(raw, k)
+assert (out == o_out).all() and (st == o_st).all() and st.any()
+rt, st = ctx.roundtrip(raw); o_rt, o_st = orc.roundtrip(raw)
+assert (rt == o_rt).all() and (st == o_st).all()
+assert (ctx.hash_to_curve(r0, r1) == orc.hash_to_curve(r0, r1)).all()
+assert (ctx.scalar_mul_base(k) == orc.scalar_mul_base(k)).all()
+xyzt, st = ctx.decompress(enc)
+assert (ctx.compress(ctx.double(ctx.add(xyzt, xyzt[::-1].copy()))) == orc.compress(orc.double_xyzt(orc.add_xyzt(xyzt, xyzt[::-1].copy())))).all()
+e, _, _ = ctx.msm(enc[:3000], k[:3000]); assert bytes(e) == bytes(orc.msm(xyzt[:3000], k[:3000])[0])
+assert ctx.invariant_failures() == (True, 0)
+bad = xyzt[:100].copy(); bad[:, 0] ^= np.uint64(2)          # x limb flipped: not on the curve any more
+ctx.compress(bad)
+on, cnt = ctx.invariant_failures()
+assert on and cnt == 100, cnt
+print("INVARIANTS_OK")
+"""
+    env = dict(os.environ, D377_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "INVARIANTS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    import decaf377_amd as d
+    c = d.Context([0])
+    assert c.invariant_failures() == (False, 0)         # the product build compiles the checks out
+    c.close()
