@@ -281,7 +281,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from _oracle import Oracle
-        orc = Oracle()
+        orc = Oracle(native=True)
         cores = usable_cores()
         # pilot on one thread to size a sample worth ~12 s of wall time on all cores
         pilot = 512
@@ -304,7 +304,7 @@ def main():
             "kind": "port",
             "sample": "first %d of the %d (point, scalar) pairs of this run, %d pthreads over contiguous slices; "
                       "C restatement of the reference algorithm (Sarkar sqrt, 256-step double-and-add, 4x64 "
-                      "Montgomery), gcc -O3 -march=x86-64-v3" % (ns, n, used),
+                      "Montgomery), gcc %s" % (ns, n, used, orc.flags),
             "seconds": dt,
             "matches_gpu_output": same,
             "value_1_thread": one_thread_rate,

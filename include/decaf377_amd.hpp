@@ -103,7 +103,11 @@ struct Element {
 static_assert(sizeof(Encoding) == 32 && sizeof(Fq) == 32 && sizeof(Fr) == 32 && sizeof(Element) == 128,
               "records must be packed");
 
-/// Owns one d377_ctx (device tables, scratch).  One call in flight per Engine.
+/// Which backend's root sqrt_ratio_zeta returns: the arkworks one (Sarkar tables, src/ark_curve/invsqrt.rs:75-166)
+/// or the min_curve one (Tonelli-Shanks seeded with 11^m, src/min_curve/invsqrt.rs:11-95).  Same flags.
+enum class SqrtRoot : int { Ark = D377_SQRT_ROOT_ARK, MinCurve = D377_SQRT_ROOT_MIN_CURVE };
+
+/// Owns one d377_ctx (device tables, streams, scratch).  Calls on one Engine are serialised inside the library.
 class Engine {
  public:
   explicit Engine(const std::vector<int>& device_ids = {0}) {
@@ -154,12 +158,13 @@ class Engine {
     check(d377_batch_scalar_mul_var(ctx_, u8(ps), u8(ks), ps.size(), u8m(out), st.data()));
     return results(out, st);
   }
-  /// Fq::sqrt_ratio_zeta (src/ark_curve/invsqrt.rs:75-166)
-  std::vector<std::pair<bool, Fq>> sqrt_ratio_zeta(const std::vector<Fq>& num, const std::vector<Fq>& den) {
+  /// Fq::sqrt_ratio_zeta (src/ark_curve/invsqrt.rs:75-166; SqrtRoot::MinCurve: src/min_curve/invsqrt.rs:73-95)
+  std::vector<std::pair<bool, Fq>> sqrt_ratio_zeta(const std::vector<Fq>& num, const std::vector<Fq>& den,
+                                                   SqrtRoot which = SqrtRoot::Ark) {
     if (num.size() != den.size()) throw std::invalid_argument("length mismatch");
     std::vector<Fq> root(num.size());
     std::vector<uint8_t> ws(num.size());
-    check(d377_batch_sqrt_ratio_zeta(ctx_, u8(num), u8(den), num.size(), u8m(root), ws.data()));
+    check(d377_batch_sqrt_ratio_zeta_ex(ctx_, (int)which, u8(num), u8(den), num.size(), u8m(root), ws.data()));
     std::vector<std::pair<bool, Fq>> r(num.size());
     for (size_t i = 0; i < r.size(); ++i) r[i] = {ws[i] != 0, root[i]};
     return r;
@@ -200,6 +205,30 @@ class Engine {
     Encoding enc;
     check(d377_msm(ctx_, u64(points), u8(scalars), points.size(), enc.b.data(), out.xyzt.data()));
     return out;
+  }
+  /// The same over Encodings: invalid ones are reported (Err) and left out of the sum.
+  std::pair<Element, std::vector<Result<Encoding>>> vartime_multiscalar_mul_encoded(const std::vector<Fr>& scalars,
+                                                                                   const std::vector<Encoding>& points) {
+    if (scalars.size() != points.size()) throw std::invalid_argument("length mismatch");
+    Element out;
+    Encoding enc;
+    std::vector<uint8_t> st(points.size() ? points.size() : 1);
+    check(d377_msm_encoded(ctx_, u8(points), u8(scalars), points.size(), enc.b.data(), out.xyzt.data(), st.data()));
+    st.resize(points.size());
+    return {out, results(points, st)};
+  }
+  /// CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81): affine (x, y) as 4 Montgomery limbs each
+  std::vector<std::array<uint64_t, 8>> normalize_batch(const std::vector<Element>& p) {
+    std::vector<std::array<uint64_t, 8>> out(p.size());
+    check(d377_batch_to_affine(ctx_, u64(p), p.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  /// decompress then compress: Ok(e) has e == input (tests/encoding.rs:97-107)
+  std::vector<Result<Encoding>> roundtrip(const std::vector<Encoding>& encs) {
+    std::vector<Encoding> out(encs.size());
+    std::vector<uint8_t> st(encs.size());
+    check(d377_batch_roundtrip(ctx_, u8(encs), encs.size(), u8m(out), st.data()));
+    return results(out, st);
   }
   static Element identity() { Element e; d377_identity(e.xyzt.data()); return e; }     // Element::IDENTITY
   static Element generator() { Element e; d377_generator(e.xyzt.data()); return e; }   // Element::GENERATOR

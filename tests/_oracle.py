@@ -32,8 +32,19 @@ class Oracle:
     OPS = {"roundtrip": 0, "scalar_mul_base": 1, "scalar_mul_var": 2, "encode_to_curve": 3, "sqrt_ratio_zeta": 4,
            "sqrt_ratio_zeta_min_curve": 5}
 
-    def __init__(self):
-        self.lib = ctypes.CDLL(build_oracle())
+    def __init__(self, native=False):
+        """native=True: a copy built on THIS host with -march=native (bench.py's cpu_baseline on the GPU box);
+        falls back to the portable build when the compiler is not there."""
+        path = build_oracle()
+        self.flags = "-O3 -march=x86-64-v3"
+        if native:
+            try:
+                subprocess.check_call(["make", "-C", ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                path = os.path.join(ORACLE_DIR, "libd377_oracle_native.so")
+                self.flags = "-O3 -march=native (built on this host)"
+            except Exception:
+                pass
+        self.lib = ctypes.CDLL(path)
         self.lib.d377o_init()
         self.lib.d377o_run_threads.restype = ctypes.c_int
 

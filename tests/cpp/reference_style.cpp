@@ -155,6 +155,33 @@ static void sqrt_ratio_edge_cases(Engine& e) {
   auto r = e.sqrt_ratio_zeta({Fq::from_u64(0), Fq::from_u64(1)}, {Fq::from_u64(1), Fq::from_u64(0)});
   CHECK(r[0].first == true && r[0].second == Fq::from_u64(0));
   CHECK(r[1].first == false && r[1].second == Fq::from_u64(0));
+  // the min_curve backend's root (src/min_curve/invsqrt.rs:73-95): same flag, root equal or negated, and
+  // both square to u/v (the reference's own property, invsqrt.rs:182-202)
+  std::vector<Fq> u, v;
+  for (uint64_t i = 2; i < 66; ++i) { u.push_back(Fq::from_u64(i * i + 7)); v.push_back(Fq::from_u64(3 * i + 1)); }
+  auto ra = e.sqrt_ratio_zeta(u, v), rm = e.sqrt_ratio_zeta(u, v, SqrtRoot::MinCurve);
+  int differ = 0;
+  for (size_t i = 0; i < u.size(); ++i) {
+    CHECK(ra[i].first == rm[i].first);
+    differ += !(ra[i].second == rm[i].second);
+  }
+  CHECK(differ > 8 && differ < 56);
+}
+
+// CurveGroup::normalize_batch, Encoding round trip, MSM over encodings
+static void widened_entry_points(Engine& e) {
+  std::vector<Fr> ks;
+  for (uint64_t i = 1; i <= 40; ++i) ks.push_back(Fr::from_u64(i));
+  auto encs = e.mul_generator(ks);
+  auto rt = e.roundtrip(encs);
+  for (size_t i = 0; i < encs.size(); ++i) CHECK(rt[i].ok && rt[i].value == encs[i]);
+  std::vector<Element> els;
+  for (auto& r : e.vartime_decompress(encs)) els.push_back(r.unwrap());
+  auto aff = e.normalize_batch(e.double_(els));
+  CHECK(aff.size() == els.size());
+  auto both = e.vartime_multiscalar_mul_encoded(ks, encs);
+  CHECK(e.eq({both.first}, {e.vartime_multiscalar_mul(ks, els)})[0]);
+  for (auto& r : both.second) CHECK(r.ok);
 }
 
 int main() {
@@ -166,6 +193,7 @@ int main() {
   scalar_mul_properties(e);
   vartime_multiscalar_mul_matches_scalar_mul(e);
   sqrt_ratio_edge_cases(e);
+  widened_entry_points(e);
   bool threw = false;
   try { Engine bad({99}); } catch (const DeviceError&) { threw = true; }
   CHECK(threw);
