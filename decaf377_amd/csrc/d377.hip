@@ -128,17 +128,17 @@ __global__ void __launch_bounds__(BLOCK) k_init_slookup(uint8_t* s_lookup, uint3
   }
 }
 
-// FB[i][j] = j * 256^i * B in affine cached form, i = 0..31, j = 0..128 (one thread per entry)
+// FB[i][j] = j * 2^(FB_BITS i) * B in affine cached form, i < FB_WINDOWS, j < FB_ENTRIES (one thread per entry)
 __global__ void __launch_bounds__(BLOCK) k_init_fbase(uint32_t* fb) {
   const int idx = blockIdx.x * BLOCK + threadIdx.x;
   if (idx >= FB_WINDOWS * FB_ENTRIES) return;
   const int i = idx / FB_ENTRIES, j = idx % FB_ENTRIES;
   ge pi = ge_generator();
 #pragma unroll 1
-  for (int k = 0; k < 8 * i; ++k) pi = ge_double(pi);
+  for (int k = 0; k < FB_BITS * i; ++k) pi = ge_double(pi);
   ge acc = ge_identity();
 #pragma unroll 1
-  for (int b = 7; b >= 0; --b) {
+  for (int b = FB_BITS - 1; b >= 0; --b) {
     acc = ge_double(acc);
     if ((j >> b) & 1) acc = ge_add(acc, pi);
   }

@@ -81,7 +81,7 @@ int sim_init() {
       for (int k = 0; k < 9; ++k) { q[k] = ypx.l[k]; q[9 + k] = ymx.l[k]; q[18 + k] = kt.l[k]; }
       acc = ge_add(acc, pi);
     }
-    for (int j = 0; j < 8; ++j) pi = ge_double(pi);
+    for (int j = 0; j < FB_BITS; ++j) pi = ge_double(pi);
   }
   return coll;
 }
