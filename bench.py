@@ -121,8 +121,9 @@ def main():
         local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # under torch.distributed.run, also with a single rank (RCCL smoke path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -325,7 +326,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

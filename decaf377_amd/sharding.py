@@ -155,7 +155,7 @@ def run_job(mode, n, steps, warmup, make_inputs, compute, device, sync=lambda: N
 
     def one_step(timed):
         nonlocal coll, outs
-        if from_root and world > 1:
+        if from_root and dist.is_initialized():          # also at world size 1: the collectives then run through the backend
             t0 = time.perf_counter()
             ins = [scatter_records(full[i].to(cdev) if rank == 0 else None, n, specs[i][0], specs[i][1], cdev, 0,
                                    group).to(device) for i in range(len(specs))]

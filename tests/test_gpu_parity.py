@@ -930,3 +930,45 @@ print("INVARIANTS_OK")
     c = d.Context([0])
     assert c.invariant_failures() == (False, 0)         # the product build compiles the checks out
     c.close()
+
+
+def test_bench_modes_and_rccl_single_rank():
+    """bench.py's strong-scaling and from-root modes on the GPU.  (1) One rank under torch.distributed.run with
+    the real `nccl` backend (= RCCL): process-group creation on the device, the scatter of HBM input tensors,
+    the gather of outputs and the MAX all-reduce of the timings all go through RCCL -- with one rank they
+    move nothing between GPUs, but it is the code path the driver's N > 1 runs take, executed on hardware.
+    (2) Two ranks sharing GPU 0 over gloo (the collectives stage through the host): strong scaling halves the
+    per-rank shard and the from-root line reports its collective share."""
+    import json
+    import socket
+    import subprocess
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--master-addr", "127.0.0.1"]
+    common = ["--steps", "2", "--warmup", "1", "--log2n", "16", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(base + ["--nproc-per-node", "1", "--master-port", str(port()), os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                               "--scaling", "strong", "--from-root"] + common, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["mode"] == "from-root"
+    assert line["config"]["elements_total"] == 1 << 16 and line["collective_ms"] > 0 and line["value"] > 0
+    r = subprocess.run(base + ["--nproc-per-node", "2", "--master-port", str(port()), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                               "--scaling", "strong", "--from-root", "--backend", "gloo", "--same-device"] + common,
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["elements_total"] == 1 << 16 and line["config"]["elements_per_gpu"] == 1 << 15
+    assert line["collective_ms"] > 0
+
+
+def test_rccl_sharding_single_rank():
+    """decaf377_amd/sharding.py on HBM tensors over the real `nccl` backend (RCCL): scatter / gather of records,
+    the all-gather of MSM partial sums and the timing all-reduce, one rank (the builder's boxes have one GPU; the
+    same worker runs unchanged on N ranks)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL_OK world=1" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
