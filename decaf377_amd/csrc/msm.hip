@@ -5,10 +5,14 @@
 // signed c-bit windows, laid out for one-lane-per-bucket execution:
 //
 //   k_msm_prepare   one lane per (point, scalar): [decompress,] cached form of the point -> HBM,
-//                   scalar mod r -> W signed digits, histogram of |digit| per window (atomics)
-//   k_msm_scan      one workgroup per window: exclusive prefix sum of the histogram
-//   k_msm_scatter   one lane per point: its index (sign in bit 31) into each window's bucket run,
-//                   at offset + the rank the histogram atomic returned (no second round of atomics)
+//                   scalar mod r -> W signed digits
+//   k_msm_count     counting sort, pass 1: workgroup (window, slice) builds the histogram of |digit| over
+//                   its slice of the points in LDS (the whole histogram of a window, <= 2^13 + 1 counters,
+//                   fits) and writes it out
+//   k_msm_scan      one workgroup per window: per-bucket prefix over the slices, then the exclusive prefix
+//                   sum over buckets: every (window, slice, bucket) gets its base position
+//   k_msm_place     pass 2: the same workgroup reloads its bases into LDS as cursors and writes each point's
+//                   index (sign in bit 31) to its bucket run (LDS atomics hand out the positions)
 //   k_msm_segments  one lane per 32-point segment of a bucket run: cached additions (8 M each)
 //   k_msm_buckets   one lane per bucket: sum of its segment partials
 //   k_msm_chunks    one lane per 32 consecutive buckets: running-sum trick inside the chunk,
@@ -41,15 +45,31 @@ constexpr int CHUNK = 8;                // buckets per lane in k_msm_chunks (sho
 constexpr int FOLD = 32;                // points per lane in k_msm_fold
 constexpr int SEG = 32;                 // points per lane in k_msm_segments
 
+// the cached form of every input point: 4 x 9 limbs packed into 144 bytes (nine 16-byte loads).  These records
+// are gathered once per window in bucket order -- n x W x 144 B is the MSM's dominant HBM traffic -- so they
+// carry no padding (the 192-byte slot layout is kept for the partial sums, which are read once).
+constexpr int CP_WORDS = 4 * NL;        // 36
 __device__ __forceinline__ void pt_store_cached(uint32_t* p, const gec& c) {
-  slot_store(p, c.ypx); slot_store(p + SLOT, c.ymx); slot_store(p + 2 * SLOT, c.z2); slot_store(p + 3 * SLOT, c.kt);
+  uint32_t w[CP_WORDS];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { w[i] = c.ypx.l[i]; w[NL + i] = c.ymx.l[i]; w[2 * NL + i] = c.z2.l[i]; w[3 * NL + i] = c.kt.l[i]; }
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < CP_WORDS / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 __device__ __forceinline__ gec pt_load_cached(const uint32_t* p, bool swap) {
+  uint32_t w[CP_WORDS];
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < CP_WORDS / 4; ++i) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
   gec c;
-  c.ypx = slot_load(p + (swap ? SLOT : 0));
-  c.ymx = slot_load(p + (swap ? 0 : SLOT));
-  c.z2 = slot_load(p + 2 * SLOT);
-  c.kt = slot_load(p + 3 * SLOT);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    c.ypx.l[i] = swap ? w[NL + i] : w[i];
+    c.ymx.l[i] = swap ? w[i] : w[NL + i];
+    c.z2.l[i] = w[2 * NL + i];
+    c.kt.l[i] = w[3 * NL + i];
+  }
   return c;
 }
 __device__ __forceinline__ void pt_store_ext(uint32_t* p, const ge& g) {
@@ -80,8 +100,8 @@ template <> struct PrepareLds<false> { uint32_t tab[1]; };
 
 template <bool ENCODED>
 __global__ void __launch_bounds__(BLOCK, ENCODED ? WAVES_PER_SIMD : 4)
-k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, int c, int W, int nb,
-              uint32_t* pts, int16_t* digits, uint32_t* rank, uint32_t* count, uint8_t* status) {
+k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, int c, int W,
+              uint32_t* pts, int16_t* digits, uint8_t* status) {
   __shared__ PrepareLds<ENCODED> lds_;
   LdsPowTab pt;
   pt.col = lds_.tab + threadIdx.x;
@@ -96,7 +116,7 @@ k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t 
     } else {
       g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), i);
     }
-    pt_store_cached(pts + i * PT_WORDS, ge_to_cached(g));
+    pt_store_cached(pts + i * CP_WORDS, ge_to_cached(g));
     uint32_t k[8];
     load32(scalar32, i, k);
     fr_reduce_words(k);
@@ -106,59 +126,89 @@ k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t 
       int d = msm_digit(k, w, c, W, carry);
       if (bad) d = 0;                                   // invalid points contribute nothing
       digits[(size_t)w * n + i] = (int16_t)d;
-      // the histogram atomic also hands out this point's rank inside its bucket, so the scatter
-      // below needs no second round of atomics
-      if (d != 0) rank[(size_t)w * n + i] = atomicAdd(&count[(size_t)w * (nb + 1) + (d < 0 ? -d : d)], 1u);
     }
   }
 }
 
-// exclusive scan of count[w][0..nb] -> offs[w][0..nb] (offs[w][nb] = total), cursor = offs; and the
-// same for the number of SEG-point segments of every bucket run -> segoff[w][0..nb]
-__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* count, uint32_t* offs, uint32_t* cursor,
-                                                   uint32_t* segoff, int nb) {
+// Counting sort of the points of every window by |digit|.  The histogram of a whole window (nb <= 2^13 + 1
+// counters for the widths pick_window chooses) lives in LDS, so neither pass issues a global atomic: round 1's
+// histogram of returning global atomics (one per point and window, each its own L2 round trip) and the
+// scattered rank reads cost 5.7 ms of a 12.6 ms MSM at 2^22.
+constexpr int SORT_THREADS = 1024;
+// slice s of window w covers points [s * per, min(n, (s + 1) * per))
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digits, size_t n, int nb, int S, size_t per,
+                                                            uint32_t* blockhist) {
+  extern __shared__ uint32_t h[];
+  const int w = blockIdx.x / S, sl = blockIdx.x % S;
+  for (int j = threadIdx.x; j < nb; j += SORT_THREADS) h[j] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)sl * per, hi = (lo + per < n) ? lo + per : n;
+  const int16_t* dw = digits + (size_t)w * n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+    const int d = dw[i];
+    if (d != 0) atomicAdd(&h[d < 0 ? -d : d], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = blockhist + (size_t)blockIdx.x * nb;
+  for (int j = threadIdx.x; j < nb; j += SORT_THREADS) out[j] = h[j];
+}
+
+// One workgroup per window.  In: blockhist[w][s][b] = points of slice s in bucket b.  Out: blockhist[w][s][b] =
+// position of the first such point in the window's index array; offs[w][0..nb] = exclusive prefix of the bucket
+// sizes (offs[w][nb] = total); segoff[w][0..nb] = the same for the number of SEG-point segments per bucket.
+// Buckets are taken 1024 at a time, thread t on bucket chunk + t, so every slice row is read and written coalesced.
+__global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, int nb, int S) {
   __shared__ uint32_t part[1024];
   __shared__ uint32_t part2[1024];
   const int w = blockIdx.x, t = threadIdx.x;
   const int len = nb + 1;
-  const int per = (len + 1023) / 1024;
-  const uint32_t* cw = count + (size_t)w * len;
-  uint32_t s = 0, s2 = 0;
-  for (int j = t * per; j < (t + 1) * per && j < len; ++j) {
-    const uint32_t c = (j < nb) ? cw[j] : 0u;                 // slot nb is the sentinel
-    s += c;
-    s2 += (c + SEG - 1) / SEG;
-  }
-  part[t] = s; part2[t] = s2;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = (t >= off) ? part[t - off] : 0u, v2 = (t >= off) ? part2[t - off] : 0u;
+  uint32_t* bh = blockhist + (size_t)w * S * nb;
+  uint32_t carry = 0, carry2 = 0;                                 // totals of the chunks before this one
+  for (int chunk = 0; chunk < len; chunk += 1024) {
+    const int j = chunk + t;
+    uint32_t c = 0;
+    if (j < nb)
+      for (int sl = 0; sl < S; ++sl) {                            // exclusive prefix over the slices, in place
+        const uint32_t v = bh[(size_t)sl * nb + j];
+        bh[(size_t)sl * nb + j] = c;
+        c += v;
+      }
+    const uint32_t c2 = (c + SEG - 1) / SEG;
+    part[t] = c; part2[t] = c2;
     __syncthreads();
-    part[t] += v; part2[t] += v2;
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t v = (t >= off) ? part[t - off] : 0u, v2 = (t >= off) ? part2[t - off] : 0u;
+      __syncthreads();
+      part[t] += v; part2[t] += v2;
+      __syncthreads();
+    }
+    const uint32_t run = carry + part[t] - c, run2 = carry2 + part2[t] - c2;   // exclusive
+    if (j < len) {                                                // slot nb is the sentinel: total
+      offs[(size_t)w * len + j] = run;
+      segoff[(size_t)w * len + j] = run2;
+    }
+    if (j < nb)
+      for (int sl = 0; sl < S; ++sl) bh[(size_t)sl * nb + j] += run;           // slice-relative -> absolute position
+    carry += part[1023]; carry2 += part2[1023];
     __syncthreads();
-  }
-  uint32_t run = part[t] - s, run2 = part2[t] - s2;
-  for (int j = t * per; j < (t + 1) * per && j < len; ++j) {
-    offs[(size_t)w * len + j] = run;
-    cursor[(size_t)w * len + j] = run;
-    segoff[(size_t)w * len + j] = run2;
-    const uint32_t c = (j < nb) ? cw[j] : 0u;
-    run += c;
-    run2 += (c + SEG - 1) / SEG;
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_msm_scatter(const int16_t* digits, const uint32_t* rank, size_t n, int W, int nb,
-                                                       const uint32_t* offs, uint32_t* idx) {
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-#pragma unroll 1
-    for (int w = 0; w < W; ++w) {
-      const int d = digits[(size_t)w * n + i];
-      if (d == 0) continue;
-      const uint32_t b = (uint32_t)(d < 0 ? -d : d);
-      const uint32_t pos = offs[(size_t)w * (nb + 1) + b] + rank[(size_t)w * n + i];
-      idx[(size_t)w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
-    }
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_place(const int16_t* digits, size_t n, int nb, int S, size_t per,
+                                                            const uint32_t* blockhist, uint32_t* idx) {
+  extern __shared__ uint32_t h[];
+  const int w = blockIdx.x / S, sl = blockIdx.x % S;
+  const uint32_t* base = blockhist + (size_t)blockIdx.x * nb;
+  for (int j = threadIdx.x; j < nb; j += SORT_THREADS) h[j] = base[j];
+  __syncthreads();
+  const size_t lo = (size_t)sl * per, hi = (lo + per < n) ? lo + per : n;
+  const int16_t* dw = digits + (size_t)w * n;
+  uint32_t* iw = idx + (size_t)w * n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+    const int d = dw[i];
+    if (d == 0) continue;
+    const uint32_t pos = atomicAdd(&h[d < 0 ? -d : d], 1u);       // LDS: a cursor per bucket
+    iw[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
   }
 }
 
@@ -196,14 +246,14 @@ k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, c
     ge acc = ge_identity();
     if (lo < hi) {
       uint32_t e = idx[(size_t)w * n + lo];
-      gec q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * PT_WORDS, (e >> 31) != 0);
+      gec q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * CP_WORDS, (e >> 31) != 0);
 #pragma unroll 1
       for (uint32_t j = lo; j < hi; ++j) {
         const bool neg = (e >> 31) != 0;
         const gec cur = q;
         if (j + 1 < hi) {
           e = idx[(size_t)w * n + j + 1];
-          q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * PT_WORDS, (e >> 31) != 0);
+          q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * CP_WORDS, (e >> 31) != 0);
         }
         acc = ge_add_cached(acc, cur, neg, true);
       }
@@ -398,16 +448,20 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   // workspace carve-up
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-  const size_t o_pts = carve(n * PT_WORDS * 4);
+  // slices per window of the counting sort: enough workgroups to cover the chip, never less than 8192 points each
+  int S = (int)((size_t)2 * d.cus / (size_t)W) + 1;
+  if (const char* e = getenv("D377_MSM_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 4096) S = v; }   // developer override (sweeps)
+  if ((size_t)S > (n + 8191) / 8192) S = (int)((n + 8191) / 8192);
+  if (S < 1) S = 1;
+  const size_t per = (n + (size_t)S - 1) / (size_t)S;
+  const size_t o_pts = carve(n * CP_WORDS * 4);
   const size_t o_dig = carve((size_t)W * n * 2);
-  const size_t o_cnt = carve((size_t)W * (nb + 1) * 4);
+  const size_t o_bh = carve((size_t)W * S * nb * 4);
   const size_t o_off = carve((size_t)W * (nb + 1) * 4);
-  const size_t o_cur = carve((size_t)W * (nb + 1) * 4);
   const size_t o_seg = carve((size_t)W * (nb + 1) * 4);
   const size_t max_segs = ((size_t)n * W) / SEG + (size_t)W * nb;      // sum of ceil(run / SEG) never exceeds this
   const size_t o_par = carve(max_segs * PT_WORDS * 4);
   const size_t o_idx = carve((size_t)W * n * 4);
-  const size_t o_rank = carve((size_t)W * n * 4);
   const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
   const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
   // ping-pong buffers of the 32-to-1 folds, sized from the fold sequence itself: the first fold writes
@@ -427,22 +481,24 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   uint8_t* m = d.msm.mem;
   uint32_t* pts = (uint32_t*)(m + o_pts);
   int16_t* dig = (int16_t*)(m + o_dig);
-  uint32_t *cnt = (uint32_t*)(m + o_cnt), *offs = (uint32_t*)(m + o_off), *cur = (uint32_t*)(m + o_cur);
+  uint32_t *bh = (uint32_t*)(m + o_bh), *offs = (uint32_t*)(m + o_off);
   uint32_t *segoff = (uint32_t*)(m + o_seg), *partial = (uint32_t*)(m + o_par);
   uint32_t* idx = (uint32_t*)(m + o_idx);
-  uint32_t* rank = (uint32_t*)(m + o_rank);
   uint32_t *bkt = (uint32_t*)(m + o_bkt), *ch = (uint32_t*)(m + o_ch), *f0 = (uint32_t*)(m + o_f0), *f1 = (uint32_t*)(m + o_f1);
   const SqrtTables T = d.tables();
+  const size_t hist_bytes = (size_t)nb * 4;                  // one window's histogram in LDS (<= 128 KiB at c = 16)
+  if (hist_bytes > 64 * 1024) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+  }
 
-  HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)W * (nb + 1) * 4, s));
   if (encoded)
-    hipLaunchKernelGGL(k_msm_prepare<true>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, nb, pts,
-                       dig, rank, cnt, status);
+    hipLaunchKernelGGL(k_msm_prepare<true>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, pts, dig, status);
   else
-    hipLaunchKernelGGL(k_msm_prepare<false>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, nb, pts,
-                       dig, rank, cnt, status);
-  hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, cnt, offs, cur, segoff, nb);
-  hipLaunchKernelGGL(k_msm_scatter, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, dig, rank, n, W, nb, offs, idx);
+    hipLaunchKernelGGL(k_msm_prepare<false>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, pts, dig, status);
+  hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
+  hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, bh, offs, segoff, nb, S);
+  hipLaunchKernelGGL(k_msm_place, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh, idx);
   hipLaunchKernelGGL(k_msm_segments, dim3(grid_of(d, max_segs)), dim3(BLOCK), 0, s, pts, idx, offs, segoff, n, W, nb,
                      max_segs, partial);
   hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, partial, segoff, W, nb, bkt);
