@@ -37,7 +37,7 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
 # instrumented host build of the same headers (tests/test_host_sim.py::test_bench_mac_counts):
 # variable base = 2 square roots (288 S + 83 M with the Elligator-free callers' extras) + 63 windows x
 # (4 doublings of 3 S + 4 M, + 1 M for T, + a 7 M cached addition) + the 9-entry table.
-KERNEL_OPS = {"scalar_mul_var": (1750, 1340), "roundtrip": (177, 580), "scalar_mul_base": (312, 289),
+KERNEL_OPS = {"scalar_mul_var": (1750, 1340), "roundtrip": (177, 580), "scalar_mul_base": (235, 289),
               "sqrt_ratio_zeta": (83, 288)}
 MACS_PER_MUL, MACS_PER_SQR = 153, 117
 KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR for k, (m, s) in KERNEL_OPS.items()}   # scalar_mul_var: 424530

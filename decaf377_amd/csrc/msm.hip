@@ -42,7 +42,7 @@ namespace {
 
 constexpr int PT_WORDS = 4 * SLOT;      // one cached or extended point record: 192 B
 constexpr int CHUNK = 8;                // buckets per lane in k_msm_chunks (short chains: this phase is latency-bound)
-constexpr int FOLD = 32;                // points per lane in k_msm_fold
+constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a serial chain per lane: short chains, more levels)
 constexpr int SEG = 32;                 // points per lane in k_msm_segments
 
 // the cached form of every input point: 4 x 9 limbs packed into 144 bytes (nine 16-byte loads).  These records
@@ -314,9 +314,9 @@ k_msm_fold(const uint32_t* in, int W, int m, int mout, uint32_t* out) {
     const int w = gi / mout, g = gi % mout;
     int hi = (g + 1) * FOLD;
     if (hi > m) hi = m;
-    ge acc = ge_identity();
+    ge acc = pt_load_ext(in + ((size_t)w * m + (size_t)g * FOLD) * PT_WORDS);
 #pragma unroll 1
-    for (int j = g * FOLD; j < hi; ++j) acc = ge_add(acc, pt_load_ext(in + ((size_t)w * m + j) * PT_WORDS));
+    for (int j = g * FOLD + 1; j < hi; ++j) acc = ge_add(acc, pt_load_ext(in + ((size_t)w * m + j) * PT_WORDS));
     pt_store_ext(out + (size_t)gi * PT_WORDS, acc);
   }
 }

@@ -322,3 +322,41 @@ def test_doubling_variants_agree(sim, oracle):
     back = oracle.neg_xyzt(negd)
     assert oracle.eq_xyzt(back, ref).all() and (oracle.compress(back) == oracle.compress(ref)).all()
     assert oracle.is_identity(oracle.add_xyzt(negd, ref)).all()
+
+
+def test_bench_mac_counts():
+    """bench.py's KERNEL_OPS (field products / squarings per element, the numerator of roofline_valu) are the
+    counts the instrumented host build of the same headers reports for one element of each operation."""
+    import importlib.util
+    import sys
+    lib = os.path.join(SIM_DIR, "libd377_sim_bounds.so")
+    if not os.path.exists(lib):
+        pytest.skip("bounds build not present (test_static_bounds builds it)")
+    code = r"""
+import ctypes, sys, numpy as np
+L = ctypes.CDLL(sys.argv[1]); L.sim_init.restype = ctypes.c_int; assert L.sim_init() == 0
+p = lambda a: a.ctypes.data_as(ctypes.c_void_p); n_ = ctypes.c_size_t
+rng = np.random.default_rng(1); n = 4
+r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8); k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+enc = np.zeros((n, 32), np.uint8); out = np.zeros((n, 32), np.uint8); st = np.zeros(n, np.uint8); xyzt = np.zeros((n, 16), np.uint64)
+m = ctypes.c_ulong(); s = ctypes.c_ulong()
+def cnt():
+    L.sim_op_counts(ctypes.byref(m), ctypes.byref(s)); return m.value // n, s.value // n
+L.sim_encode_to_curve(p(r0), n_(n), p(enc), p(xyzt)); cnt()
+L.sim_scalar_mul_var(p(enc), p(k), n_(n), p(out), p(st)); print("scalar_mul_var", *cnt())
+L.sim_roundtrip(p(enc), n_(n), p(out), p(st)); print("roundtrip", *cnt())
+L.sim_scalar_mul_base(p(k), n_(n), p(out)); print("scalar_mul_base_w8", *cnt())
+L.sim_sqrt_ratio_zeta(p(r0), p(k), n_(n), p(out), p(st)); print("sqrt_ratio_zeta", *cnt())
+"""
+    r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in r.stdout.splitlines() if l.strip()}
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for name in ("scalar_mul_var", "roundtrip", "sqrt_ratio_zeta"):
+        assert got[name] == b.KERNEL_OPS[name], (name, got[name])
+    # the bounds build uses the 8-bit comb (32 mixed additions of 7 products); the product build's 12-bit comb has 21
+    m8, s8 = got["scalar_mul_base_w8"]
+    assert (m8 - 11 * 7, s8) == b.KERNEL_OPS["scalar_mul_base"]
+    assert b.KERNEL_MACS["scalar_mul_var"] == 1750 * 153 + 1340 * 117
