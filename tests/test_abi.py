@@ -69,3 +69,29 @@ def test_every_dev_export_is_named_in_a_gpu_test():
     for name in _native.EXPORTS:
         if name.endswith("_dev"):
             assert '"%s"' % name in text, name
+
+
+def _build_c99(libpath):
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "c", "abi_c99")
+    src = os.path.join(ROOT, "tests", "c", "abi_c99.c")
+    libdir = os.path.dirname(libpath)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L" + libdir, "-ldecaf377_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+                           "-lamdhip64"])
+    return exe
+
+
+def test_header_is_plain_c99(libpath):
+    """include/decaf377_amd.h compiles as C99 with -pedantic -Werror and links against the library: the boundary
+    is a C ABI, not a C++ one."""
+    import subprocess
+    r = subprocess.run([_build_c99(libpath)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "C_ABI_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_c99_client_runs(libpath):
+    import subprocess
+    r = subprocess.run([_build_c99(libpath), "--run"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C_ABI_RUN_OK" in r.stdout, r.stdout + r.stderr

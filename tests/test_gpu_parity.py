@@ -972,3 +972,47 @@ def test_rccl_sharding_single_rank():
                         "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py")], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL_OK world=1" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_structured_invalid_encodings_2_18(ctx, oracle):
+    """Decompression's four rejection rules (src/ark_curve/encoding.rs:34-60: high bits set, s >= q, s negative,
+    u2*u1^2 not a square) and the valid path, 2^18 records built to hit each rule on purpose rather than by
+    chance: valid encodings, their negations q - s, s + q (non-canonical), valid with each of the top three bits
+    set, even field elements that are not on the curve, values around q and 2^253.  Status and all four
+    coordinates equal the oracle's; scalar multiplication and the round trip zero exactly the rejected records."""
+    rng = np.random.default_rng(910)
+    base = oracle.encode_to_curve(rng.integers(0, 256, (1 << 15, 32), dtype=np.uint8))
+    ints = [int.from_bytes(bytes(x), "little") for x in base[:4096]]
+    def pack(vals):
+        return np.array([list(int(v % (1 << 256)).to_bytes(32, "little")) for v in vals], dtype=np.uint8)
+    groups = [base]
+    groups.append(pack([(Q - v) % Q for v in ints]))                     # negative s (odd) or zero
+    groups.append(pack([v + Q for v in ints]))                            # same residue, non-canonical
+    for bit in (253, 254, 255):
+        g = base[:4096].copy()
+        g[:, 31] |= np.uint8(1 << (bit - 248))
+        groups.append(g)
+    even = rng.integers(0, 256, (1 << 15, 32), dtype=np.uint8)
+    even[:, 0] &= 0xFE
+    even[:, 31] &= 0x0F                                                   # < 2^252 < q, non-negative: ~half are not squares
+    groups.append(even)
+    groups.append(pack([Q - 2, Q - 1, Q, Q + 1, Q + 2, (1 << 253) - 2, (1 << 253), (1 << 256) - 2, 0, 2, 4, 6]))
+    enc = np.concatenate(groups)
+    reps = (1 << 18) // enc.shape[0] + 1
+    enc = np.tile(enc, (reps, 1))[: 1 << 18]
+    enc = enc[rng.permutation(enc.shape[0])]                              # valid and invalid lanes mixed inside every wave
+    n = enc.shape[0]
+    xyzt, st = ctx.decompress(enc)
+    o_out, o_st, _ = oracle.run_threads("roundtrip", enc, None, os.cpu_count() or 4)
+    assert (st == o_st).all()
+    assert 0.2 < st.mean() < 0.8
+    rt, st2 = ctx.roundtrip(enc)
+    assert (st2 == o_st).all() and (rt == o_out).all()
+    assert not rt[st2 == 1].any() and not xyzt[st == 1].any()
+    sample = np.concatenate([np.nonzero(st == 0)[0][:3000], np.nonzero(st == 1)[0][:3000]])
+    o_xyzt, o_s = oracle.decompress(enc[sample])
+    assert (xyzt[sample] == o_xyzt).all() and (st[sample] == o_s).all()
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    out, st3 = ctx.scalar_mul_var(enc, k)
+    o3, o3s, _ = oracle.run_threads("scalar_mul_var", enc[:20000], k[:20000], os.cpu_count() or 4)
+    assert (st3 == o_st).all() and (out[:20000] == o3).all() and not out[st3 == 1].any()
