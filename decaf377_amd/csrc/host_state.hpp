@@ -34,8 +34,15 @@ struct ScratchGuard {
   bool used = false;
   int init() { HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); return D377_OK; }
   void destroy() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; used = false; }
-  int acquire(hipStream_t s) { if (used) HIP_TRY(hipStreamWaitEvent(s, ev, 0)); return D377_OK; }
-  int release(hipStream_t s) { HIP_TRY(hipEventRecord(ev, s)); used = true; return D377_OK; }
+  // A stream that is being captured into a hipGraph takes no part in the hand-over (an event recorded outside
+  // the capture cannot be waited on inside it): within the graph the launches keep their stream order, and a
+  // caller who replays graphs on several streams at once owns that ordering, as with any graph.
+  static bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+  }
+  int acquire(hipStream_t s) { if (used && !capturing(s)) HIP_TRY(hipStreamWaitEvent(s, ev, 0)); return D377_OK; }
+  int release(hipStream_t s) { if (capturing(s)) return D377_OK; HIP_TRY(hipEventRecord(ev, s)); used = true; return D377_OK; }
   int drain() { if (used) HIP_TRY(hipEventSynchronize(ev)); return D377_OK; }   // before freeing the area
 };
 

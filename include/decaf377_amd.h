@@ -25,6 +25,9 @@
  * workspace) are handed from one launch to the next by events on the device, so such launches queue
  * up behind each other instead of racing -- results are the same as if the calls had been made one
  * after another; only their overlap is lost.  Kernels that use no scratch overlap freely.
+ * `_dev` calls only enqueue kernels (no host synchronisation, no allocation once the workspaces have grown
+ * to the batch size), so a sequence of them can be captured into a hipGraph and replayed; the scratch
+ * hand-over is skipped on a capturing stream (the graph keeps its own order).
  *
  * Three families:
  *   d377_batch_*          host pointers; the library copies to the context's GPU(s), shards

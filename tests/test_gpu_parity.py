@@ -1016,3 +1016,37 @@ def test_structured_invalid_encodings_2_18(ctx, oracle):
     out, st3 = ctx.scalar_mul_var(enc, k)
     o3, o3s, _ = oracle.run_threads("scalar_mul_var", enc[:20000], k[:20000], os.cpu_count() or 4)
     assert (st3 == o_st).all() and (out[:20000] == o3).all() and not out[st3 == 1].any()
+
+
+def test_dev_calls_capture_into_a_hip_graph(ctx, oracle, torch_mod):
+    """Launch-bound use (many small batches): the `_dev` entry points enqueue kernels only -- no host
+    synchronisation, no allocation once the workspaces have grown -- so a sequence of them captures into a
+    hipGraph (here through torch.cuda.graph, which captures torch's current stream) and replays with new inputs
+    written into the same buffers."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(920)
+    n = 512
+    r0 = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(dev)
+    k = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(dev)
+    enc = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    st = torch.empty((n,), dtype=torch.uint8, device=dev)
+    ctx.encode_to_curve(r0, outs=[enc]); ctx.scalar_mul_var(enc, k, outs=[out, st]); ctx.msm(enc, k)      # warm up: grow every workspace
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ctx.encode_to_curve(r0, outs=[enc])
+        ctx.scalar_mul_var(enc, k, outs=[out, st])
+        m_enc, _, m_st = ctx.msm(enc, k)
+    for rep in range(3):
+        r0.copy_(torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+        k.copy_(torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+        g.replay()
+        torch.cuda.synchronize()
+        e_h = oracle.encode_to_curve(r0.cpu().numpy())
+        assert (enc.cpu().numpy() == e_h).all()
+        o_out, o_st = oracle.scalar_mul_var(e_h, k.cpu().numpy())
+        assert (out.cpu().numpy() == o_out).all() and not st.cpu().numpy().any()
+        xyzt, _ = oracle.decompress(e_h)
+        assert bytes(m_enc.cpu().numpy()) == bytes(oracle.msm(xyzt, k.cpu().numpy())[0])
