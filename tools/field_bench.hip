@@ -1,4 +1,4 @@
-// Cycles per fe_mul / fe_sqr per SIMD at 1, 2, 4, 8 waves per SIMD (register-only chains).
+// Cycles per fe_mul / fe_sqr per SIMD at 1, 2, 4, 8 waves per SIMD (register-only chains of the hand-written streams).
 // Build: hipcc -O3 --offload-arch=gfx950 -Idecaf377_amd/csrc tools/field_bench.hip -o tools/field_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -17,11 +17,17 @@ __global__ void __launch_bounds__(256) k_sqr(const uint32_t* in, uint32_t* out) 
   for (int i = 0; i < ITERS; ++i) a = fe_sqr(a);
   st(out + blockIdx.x % 2 * 9 * 256, threadIdx.x, a);
 }
-__global__ void __launch_bounds__(256) k_sqr2(const uint32_t* in, uint32_t* out) {   // two independent chains
+__global__ void __launch_bounds__(256) k_sqr2(const uint32_t* in, uint32_t* out) {   // 2 a^2 (fe_sqr2x)
+  fe a = ld(in, threadIdx.x);
+#pragma unroll 1
+  for (int i = 0; i < ITERS; ++i) a = fe_sqr2x(a);
+  st(out + blockIdx.x % 2 * 9 * 256, threadIdx.x, a);
+}
+__global__ void __launch_bounds__(256) k_mul_strict(const uint32_t* in, uint32_t* out) {
   fe a = ld(in, threadIdx.x), b = ld(in + 9 * 256, threadIdx.x);
 #pragma unroll 1
-  for (int i = 0; i < ITERS / 2; ++i) { a = fe_sqr(a); b = fe_sqr(b); }
-  st(out, threadIdx.x, fe_add(a, b));
+  for (int i = 0; i < ITERS; ++i) a = fe_mul_strict(a, b);
+  st(out + blockIdx.x % 2 * 9 * 256, threadIdx.x, a);
 }
 __global__ void __launch_bounds__(256) k_mul(const uint32_t* in, uint32_t* out) {
   fe a = ld(in, threadIdx.x), b = ld(in + 9 * 256, threadIdx.x);
@@ -41,8 +47,9 @@ int main() {
   int cus = p.multiProcessorCount;
   uint32_t *in, *out; CK(hipMalloc(&in, 18 * 256 * 4)); CK(hipMalloc(&out, 18 * 256 * 4));
   CK(hipMemset(in, 0x5a, 18 * 256 * 4));
-  struct { const char* n; kern_t k; double ops; } ks[] = {{"fe_sqr (1 chain)", k_sqr, ITERS}, {"fe_sqr (2 chains)", k_sqr2, ITERS},
-                                                          {"fe_mul", k_mul, ITERS}, {"fe_sub", k_sub, ITERS * 4.0}};
+  struct { const char* n; kern_t k; double ops; } ks[] = {{"fe_sqr (168 instr)", k_sqr, ITERS}, {"fe_sqr2x (169)", k_sqr2, ITERS},
+                                                          {"fe_mul (196)", k_mul, ITERS}, {"fe_mul_strict (205)", k_mul_strict, ITERS},
+                                                          {"fe_sub (45)", k_sub, ITERS * 4.0}};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("cycles per operation per SIMD at 2.3 GHz (wave-ops: one op for 64 lanes)\n%-20s", "op \\ waves/SIMD");
   for (int w : {1, 2, 4, 8}) printf("   w=%d", w);
