@@ -149,7 +149,9 @@ class Context:
         for a, spec in zip(ins, in_specs):
             _check(a, spec, n, name + " input")
         if outs is None:
-            outs = [np.empty((n,) + tail, dtype=np_dt[k]) for tail, k in out_specs]   # np.zeros would page-fault inside the D2H copy
+            # fresh arrays of this size are mmap'ed anew on every call and fault their pages in during the copy back;
+            # a caller that cares passes `outs` it allocated once (tools/host_path_bench.py: 2^20 round trips 7-9 ms vs 4.8 ms)
+            outs = [np.empty((n,) + tail, dtype=np_dt[k]) for tail, k in out_specs]
         else:
             if len(outs) != len(out_specs):
                 raise ValueError("%s: expected %d output arrays" % (name, len(out_specs)))
