@@ -4,8 +4,8 @@
 // `acc + scalar * point`.  Same result, different schedule: Pippenger's bucket method with
 // signed c-bit windows, laid out for one-lane-per-bucket execution:
 //
-//   k_msm_prepare   one lane per (point, scalar): [decompress,] cached form of the point -> HBM,
-//                   scalar mod r -> W signed digits
+//   k_msm_prepare_* one lane per (point, scalar): decompress (Encodings) or batched-inversion normalisation
+//                   (Elements) -> cached AFFINE record in HBM (128 bytes); scalar mod r -> W signed digits
 //   k_msm_count     counting sort, pass 1: workgroup (window, slice) builds the histogram of |digit| over
 //                   its slice of the points in LDS (the whole histogram of a window, <= 2^13 + 1 counters,
 //                   fits) and writes it out
@@ -13,7 +13,7 @@
 //                   sum over buckets: every (window, slice, bucket) gets its base position
 //   k_msm_place     pass 2: the same workgroup reloads its bases into LDS as cursors and writes each point's
 //                   index (sign in bit 31) to its bucket run (LDS atomics hand out the positions)
-//   k_msm_segments  one lane per 32-point segment of a bucket run: cached additions (8 M each)
+//   k_msm_segments  one lane per 32-point segment of a bucket run: mixed additions (7 M each)
 //   k_msm_buckets   one lane per bucket: sum of its segment partials
 //   k_msm_chunks    one lane per 32 consecutive buckets: running-sum trick inside the chunk,
 //                   plus (lo - 1) * (chunk total) by double-and-add:  sum_b b * B_b
@@ -45,31 +45,42 @@ constexpr int CHUNK = 8;                // buckets per lane in k_msm_chunks (sho
 constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a serial chain per lane: short chains, more levels)
 constexpr int SEG = 32;                 // points per lane in k_msm_segments
 
-// the cached form of every input point: 4 x 9 limbs packed into 144 bytes (nine 16-byte loads).  These records
-// are gathered once per window in bucket order -- n x W x 144 B is the MSM's dominant HBM traffic -- so they
-// carry no padding (the 192-byte slot layout is kept for the partial sums, which are read once).
-constexpr int CP_WORDS = 4 * NL;        // 36
-__device__ __forceinline__ void pt_store_cached(uint32_t* p, const gec& c) {
-  uint32_t w[CP_WORDS];
+// Every input point is normalised to affine form once (Z = 1 already after decompression; one batched inversion
+// per lane for Element inputs) and stored as a cached AFFINE record: Y+X, Y-X (both carried: a negative digit
+// swaps them by address), 2dXY -- 27 limbs in a 128-byte, 128-byte-aligned slot.  These records are gathered
+// once per window in bucket order (n x W records: the MSM's dominant HBM traffic), so two 64-byte sectors
+// instead of the three of a projective cached point, and a mixed addition (7 products) instead of 8.
+constexpr int AP_WORDS = 32;
+__device__ __forceinline__ void pt_store_affine(uint32_t* p, const gea& c) {
+  uint32_t w[AP_WORDS];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) { w[i] = c.ypx.l[i]; w[NL + i] = c.ymx.l[i]; w[2 * NL + i] = c.z2.l[i]; w[3 * NL + i] = c.kt.l[i]; }
+  for (int i = 0; i < NL; ++i) { w[i] = c.ypx.l[i]; w[NL + i] = c.ymx.l[i]; w[2 * NL + i] = c.kt.l[i]; }
+#pragma unroll
+  for (int i = 3 * NL; i < AP_WORDS; ++i) w[i] = 0;
   uint4* q = reinterpret_cast<uint4*>(p);
 #pragma unroll
-  for (int i = 0; i < CP_WORDS / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+  for (int i = 0; i < AP_WORDS / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-__device__ __forceinline__ gec pt_load_cached(const uint32_t* p, bool swap) {
-  uint32_t w[CP_WORDS];
+__device__ __forceinline__ gea pt_load_affine(const uint32_t* p, bool swap) {
+  uint32_t w[28];
   const uint4* q = reinterpret_cast<const uint4*>(p);
 #pragma unroll
-  for (int i = 0; i < CP_WORDS / 4; ++i) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
-  gec c;
+  for (int i = 0; i < 7; ++i) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+  gea c;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     c.ypx.l[i] = swap ? w[NL + i] : w[i];
     c.ymx.l[i] = swap ? w[i] : w[NL + i];
-    c.z2.l[i] = w[2 * NL + i];
-    c.kt.l[i] = w[3 * NL + i];
+    c.kt.l[i] = w[2 * NL + i];
   }
+  return c;
+}
+// affine (x, y) -> cached affine; the identity (0, 1) for a point that contributes nothing
+__device__ __forceinline__ gea gea_from_affine(const fe& x, const fe& y) {
+  gea c;
+  c.ypx = fe_carry(fe_add(y, x));
+  c.ymx = fe_sub(y, x);
+  c.kt = fe_mul(fe_mul(fe_const(FE_K), x), y);
   return c;
 }
 __device__ __forceinline__ void pt_store_ext(uint32_t* p, const ge& g) {
@@ -93,40 +104,78 @@ __device__ __forceinline__ int msm_digit(const uint32_t k[8], int w, int c, int 
   return (int)d;
 }
 
-// the square-root power table lives in LDS only in the instantiation that decompresses: the Element
-// form needs none, and 72 KiB of LDS per block would cap it at 2 blocks per CU for nothing
-template <bool ENCODED> struct PrepareLds { uint32_t tab[POW_TAB * NL * BLOCK]; };
-template <> struct PrepareLds<false> { uint32_t tab[1]; };
-
-template <bool ENCODED>
-__global__ void __launch_bounds__(BLOCK, ENCODED ? WAVES_PER_SIMD : 4)
-k_msm_prepare(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, int c, int W,
-              uint32_t* pts, int16_t* digits, uint8_t* status) {
-  __shared__ PrepareLds<ENCODED> lds_;
-  LdsPowTab pt;
-  pt.col = lds_.tab + threadIdx.x;
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    ge g;
-    uint32_t bad = 0;
-    if constexpr (ENCODED) {
-      uint32_t w[8];
-      load32(reinterpret_cast<const uint8_t*>(pts_in), i, w);
-      bad = ge_decompress(T, pt, w, &g);
-      status[i] = (uint8_t)bad;
-    } else {
-      g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), i);
-    }
-    pt_store_cached(pts + i * CP_WORDS, ge_to_cached(g));
-    uint32_t k[8];
-    load32(scalar32, i, k);
-    fr_reduce_words(k);
-    uint32_t carry = 0;
+__device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t i, size_t n, int c, int W, bool skip, int16_t* digits) {
+  uint32_t k[8];
+  load32(scalar32, i, k);
+  fr_reduce_words(k);
+  uint32_t carry = 0;
 #pragma unroll 1
-    for (int w = 0; w < W; ++w) {
-      int d = msm_digit(k, w, c, W, carry);
-      if (bad) d = 0;                                   // invalid points contribute nothing
-      digits[(size_t)w * n + i] = (int16_t)d;
-    }
+  for (int w = 0; w < W; ++w) {
+    int d = msm_digit(k, w, c, W, carry);
+    if (skip) d = 0;                                    // invalid points contribute nothing
+    digits[(size_t)w * n + i] = (int16_t)d;
+  }
+}
+
+// Encodings: one lane per point; decompression leaves Z = 1, so the affine record costs nothing extra.
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, int c, int W,
+                  uint32_t* pts, int16_t* digits, uint8_t* status) {
+  D377_POW_LDS();
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(enc32, i, w);
+    ge g;
+    const uint32_t bad = ge_decompress(T, pt, w, &g);
+    status[i] = (uint8_t)bad;
+    const fe x = fe_select(bad != 0, fe_zero(), g.x), y = fe_select(bad != 0, fe_const(FE_ONE), g.y);
+    pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
+    msm_write_digits(scalar32, i, n, c, W, bad != 0, digits);
+  }
+}
+
+// Elements (any Z): Montgomery's trick per lane, as in k_to_affine -- forward pass multiplies the z's of the
+// lane's grid-stride elements up, parking each prefix product in the element's own record slot; one inversion;
+// the backward pass peels 1/z_i off, writes the affine record and the digits.  A record with z = 0 is no group
+// element: it becomes the identity with digits 0.
+__global__ void __launch_bounds__(BLOCK, 4)
+k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c, int W, uint32_t* pts, int16_t* digits) {
+  const size_t Tn = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= n) return;
+  const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
+  fe p = fe_const(FE_ONE);
+  size_t last = t;
+  bool all_one = true;                                 // every Z of this lane is the canonical 1 (decompress output)
+  for (size_t i = t; i < n; i += Tn) {
+    uint32_t w[8];
+    load32(b, 4 * i + 2, w);
+    for (int k = 0; k < 8; ++k) all_one &= w[k] == ONE_MONT256_WORDS[k];
+    fe z = fe_from_mont256_words(w);
+    z = fe_select(fe_is_zero(z), fe_const(FE_ONE), z);
+    slot_store(pts + i * AP_WORDS, p);
+    p = fe_mul(p, z);
+    last = i;
+  }
+  // a wave whose points are all affine already (p = 1 in every lane) skips the ~260-multiplication inversion
+  fe inv = fe_const(FE_ONE);
+  if (__any(!all_one)) inv = fe_invert(p);
+  for (size_t i = last;; i -= Tn) {
+    uint32_t w[8];
+    load32(b, 4 * i + 2, w);
+    fe z = fe_from_mont256_words(w);
+    const bool zz = fe_is_zero(z);
+    z = fe_select(zz, fe_const(FE_ONE), z);
+    const fe zi = fe_mul(inv, slot_load(pts + i * AP_WORDS));
+    inv = fe_mul(inv, z);
+    load32(b, 4 * i + 0, w);
+    fe x = fe_mul(fe_from_mont256_words(w), zi);
+    load32(b, 4 * i + 1, w);
+    fe y = fe_mul(fe_from_mont256_words(w), zi);
+    x = fe_select(zz, fe_zero(), x);
+    y = fe_select(zz, fe_const(FE_ONE), y);
+    pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
+    msm_write_digits(scalar32, i, n, c, W, zz, digits);
+    if (i == t) break;
   }
 }
 
@@ -246,16 +295,16 @@ k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, c
     ge acc = ge_identity();
     if (lo < hi) {
       uint32_t e = idx[(size_t)w * n + lo];
-      gec q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * CP_WORDS, (e >> 31) != 0);
+      gea q = pt_load_affine(pts + (size_t)(e & 0x7FFFFFFFu) * AP_WORDS, (e >> 31) != 0);
 #pragma unroll 1
       for (uint32_t j = lo; j < hi; ++j) {
         const bool neg = (e >> 31) != 0;
-        const gec cur = q;
+        const gea cur = q;
         if (j + 1 < hi) {
           e = idx[(size_t)w * n + j + 1];
-          q = pt_load_cached(pts + (size_t)(e & 0x7FFFFFFFu) * CP_WORDS, (e >> 31) != 0);
+          q = pt_load_affine(pts + (size_t)(e & 0x7FFFFFFFu) * AP_WORDS, (e >> 31) != 0);
         }
-        acc = ge_add_cached(acc, cur, neg, true);
+        acc = ge_add_affine(acc, cur, neg, true);
       }
     }
     pt_store_ext(partial + gi * PT_WORDS, acc);
@@ -454,7 +503,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   if ((size_t)S > (n + 8191) / 8192) S = (int)((n + 8191) / 8192);
   if (S < 1) S = 1;
   const size_t per = (n + (size_t)S - 1) / (size_t)S;
-  const size_t o_pts = carve(n * CP_WORDS * 4);
+  const size_t o_pts = carve(n * AP_WORDS * 4);
   const size_t o_dig = carve((size_t)W * n * 2);
   const size_t o_bh = carve((size_t)W * S * nb * 4);
   const size_t o_off = carve((size_t)W * (nb + 1) * 4);
@@ -492,10 +541,19 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
   }
 
-  if (encoded)
-    hipLaunchKernelGGL(k_msm_prepare<true>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, pts, dig, status);
-  else
-    hipLaunchKernelGGL(k_msm_prepare<false>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, pts_in, scalars, n, c, W, pts, dig, status);
+  if (n) {
+    if (encoded) {
+      hipLaunchKernelGGL(k_msm_prepare_enc, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, c, W, pts,
+                         dig, status);
+    } else {
+      // ~32 elements per lane share one inversion, but never fewer lanes than one wave per SIMD (see k_to_affine)
+      size_t lanes = (n + 31) / 32;
+      const size_t fill = (size_t)d.cus * BLOCK;
+      if (lanes < fill) lanes = fill < n ? fill : n;
+      hipLaunchKernelGGL(k_msm_prepare_el, dim3((unsigned)((lanes + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, (const uint64_t*)pts_in,
+                         scalars, n, c, W, pts, dig);
+    }
+  }
   hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
   hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, bh, offs, segoff, nb, S);
   hipLaunchKernelGGL(k_msm_place, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh, idx);

@@ -59,6 +59,34 @@ def test_msm_matches_oracle(ctx, oracle, n):
 
 
 @pytest.mark.gpu
+def test_msm_affine_and_projective_inputs_mixed(ctx, oracle):
+    """Element inputs are normalised to affine records with one inversion per lane, which a wave skips when
+    every Z it sees is the canonical 1.  Waves of affine-only points (decompress output), waves of projective
+    ones and waves holding both, plus identities in both forms, give the oracle's sum; a record with Z = 0 (not
+    a valid Element) counts as the identity."""
+    rng = np.random.default_rng(704)
+    n = 1000
+    proj = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))          # Z != 1
+    aff, st = oracle.decompress(oracle.compress(proj))                                       # same points, Z = 1
+    assert not st.any() and not np.array_equal(proj[:, 8:12], aff[:, 8:12])
+    P = proj.copy()
+    P[:256] = aff[:256]                       # four waves that skip the inversion
+    P[320:1000:2] = aff[320:1000:2]           # mixed waves
+    ident = oracle.identity_xyzt()
+    P[300] = ident                                                                           # identity, Z = 1
+    P[301] = oracle.add_xyzt(proj[301:302], oracle.neg_xyzt(proj[301:302]))[0]               # identity, Z != 1
+    P[10] = ident
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    enc, xyzt, _ = ctx.msm(P, k)
+    assert bytes(enc) == bytes(oracle.msm(P, k)[0])
+    bad = P.copy()
+    bad[500, 8:12] = 0
+    keep = np.ones(n, bool)
+    keep[500] = False
+    assert bytes(ctx.msm(bad, k)[0]) == bytes(oracle.msm(P[keep], k[keep])[0])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("window", [4, 5, 7, 12, 14, 16])
 def test_msm_every_window_width(oracle, window):
     """Same inputs through different bucket widths (developer override) give the same bytes."""
