@@ -11,8 +11,9 @@
 //                   fits) and writes it out
 //   k_msm_scan      one workgroup per window: per-bucket prefix over the slices, then the exclusive prefix
 //                   sum over buckets: every (window, slice, bucket) gets its base position
-//   k_msm_place     pass 2: the same workgroup reloads its bases into LDS as cursors and writes each point's
-//                   index (sign in bit 31) to its bucket run (LDS atomics hand out the positions)
+//   k_msm_place1    pass 2, level 1: the same workgroup scatters each point's index (sign in bit 31) into the
+//                   super-bucket (128 consecutive buckets) it belongs to; LDS atomics hand out the positions
+//   k_msm_place2    level 2: workgroup (window, super-bucket) spreads its entries over the 128 bucket runs
 //   k_msm_segments  one lane per 32-point segment of a bucket run: mixed additions (7 M each)
 //   k_msm_buckets   one lane per bucket: sum of its segment partials
 //   k_msm_chunks    one lane per 32 consecutive buckets: running-sum trick inside the chunk,
@@ -143,22 +144,38 @@ k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c,
   const size_t Tn = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (t >= n) return;
   const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
-  fe p = fe_const(FE_ONE);
-  size_t last = t;
-  bool all_one = true;                                 // every Z of this lane is the canonical 1 (decompress output)
+  // Pass 0: is every Z this wave will see the canonical 1 (decompress output, the common case)?  Then the points
+  // are affine already: convert x and y and build the records, no products of Z and no inversion.
+  bool all_one = true;
   for (size_t i = t; i < n; i += Tn) {
     uint32_t w[8];
     load32(b, 4 * i + 2, w);
     for (int k = 0; k < 8; ++k) all_one &= w[k] == ONE_MONT256_WORDS[k];
+  }
+  if (!__any(!all_one)) {
+    for (size_t i = t; i < n; i += Tn) {
+      uint32_t w[8];
+      load32(b, 4 * i + 0, w);
+      const fe x = fe_from_mont256_words(w);
+      load32(b, 4 * i + 1, w);
+      const fe y = fe_from_mont256_words(w);
+      pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
+      msm_write_digits(scalar32, i, n, c, W, false, digits);
+    }
+    return;
+  }
+  fe p = fe_const(FE_ONE);
+  size_t last = t;
+  for (size_t i = t; i < n; i += Tn) {
+    uint32_t w[8];
+    load32(b, 4 * i + 2, w);
     fe z = fe_from_mont256_words(w);
     z = fe_select(fe_is_zero(z), fe_const(FE_ONE), z);
     slot_store(pts + i * AP_WORDS, p);
     p = fe_mul(p, z);
     last = i;
   }
-  // a wave whose points are all affine already (p = 1 in every lane) skips the ~260-multiplication inversion
-  fe inv = fe_const(FE_ONE);
-  if (__any(!all_one)) inv = fe_invert(p);
+  fe inv = fe_invert(p);
   for (size_t i = last;; i -= Tn) {
     uint32_t w[8];
     load32(b, 4 * i + 2, w);
@@ -243,21 +260,60 @@ __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* blockhist, uint32_t
   }
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_place(const int16_t* digits, size_t n, int nb, int S, size_t per,
-                                                            const uint32_t* blockhist, uint32_t* idx) {
-  extern __shared__ uint32_t h[];
+// Placement in two levels.  Scattering straight into the nb (8193 at c = 14) bucket runs of a window keeps
+// W x S x nb partly written lines open at once -- far more than the L2s hold from 2^21 points up, so each 4-byte
+// index left the chip as its own masked line write (1.7 ms of an 8.4 ms MSM at 2^22).  Level 1 scatters into
+// super-buckets of SUPER consecutive buckets (<= 65 open runs per workgroup: lines fill before they are evicted),
+// level 2 takes one super-bucket per workgroup and spreads it over its SUPER bucket runs.
+constexpr int SUPER_BITS = 7, SUPER = 1 << SUPER_BITS;
+constexpr int MAX_SUPER = ((1 << 15) + 1 + SUPER - 1) / SUPER;         // c <= 16
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const int16_t* digits, size_t n, int nb, int S, size_t per,
+                                                             const uint32_t* blockhist, const uint32_t* offs,
+                                                             uint32_t* tmp_idx, uint8_t* tmp_sub) {
+  __shared__ uint32_t cur[MAX_SUPER];
   const int w = blockIdx.x / S, sl = blockIdx.x % S;
-  const uint32_t* base = blockhist + (size_t)blockIdx.x * nb;
-  for (int j = threadIdx.x; j < nb; j += SORT_THREADS) h[j] = base[j];
+  const int nsuper = (nb + SUPER - 1) >> SUPER_BITS;
+  const uint32_t* base = blockhist + (size_t)blockIdx.x * nb;           // first position of (slice, bucket) in bucket order
+  const uint32_t* ow = offs + (size_t)w * (nb + 1);
+  for (int j = threadIdx.x; j < nsuper; j += SORT_THREADS) cur[j] = ow[j << SUPER_BITS];
+  __syncthreads();
+  // points of earlier slices in the same super-bucket come first: base - offs = their number, per bucket
+  for (int j = threadIdx.x; j < nb; j += SORT_THREADS) {
+    const uint32_t before = base[j] - ow[j];
+    if (before) atomicAdd(&cur[j >> SUPER_BITS], before);
+  }
   __syncthreads();
   const size_t lo = (size_t)sl * per, hi = (lo + per < n) ? lo + per : n;
   const int16_t* dw = digits + (size_t)w * n;
-  uint32_t* iw = idx + (size_t)w * n;
+  uint32_t* iw = tmp_idx + (size_t)w * n;
+  uint8_t* sw = tmp_sub + (size_t)w * n;
   for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
     const int d = dw[i];
     if (d == 0) continue;
-    const uint32_t pos = atomicAdd(&h[d < 0 ? -d : d], 1u);       // LDS: a cursor per bucket
+    const int b = d < 0 ? -d : d;
+    const uint32_t pos = atomicAdd(&cur[b >> SUPER_BITS], 1u);
     iw[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    sw[pos] = (uint8_t)(b & (SUPER - 1));
+  }
+}
+
+// workgroup (window, super-bucket): its entries are contiguous in tmp_*, at the positions the bucket runs will occupy
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_place2(const uint32_t* tmp_idx, const uint8_t* tmp_sub, size_t n, int nb,
+                                                             const uint32_t* offs, uint32_t* idx) {
+  __shared__ uint32_t cur[SUPER];
+  const int nsuper = (nb + SUPER - 1) >> SUPER_BITS;
+  const int w = blockIdx.x / nsuper, B = blockIdx.x % nsuper;
+  const uint32_t* ow = offs + (size_t)w * (nb + 1);
+  const int first = B << SUPER_BITS, last = (first + SUPER < nb) ? first + SUPER : nb;
+  if ((int)threadIdx.x < last - first) cur[threadIdx.x] = ow[first + threadIdx.x];
+  __syncthreads();
+  const uint32_t lo = ow[first], hi = ow[last];
+  const uint32_t* ti = tmp_idx + (size_t)w * n;
+  const uint8_t* ts = tmp_sub + (size_t)w * n;
+  uint32_t* iw = idx + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+    const uint32_t pos = atomicAdd(&cur[ts[i]], 1u);
+    iw[pos] = ti[i];
   }
 }
 
@@ -511,6 +567,8 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t max_segs = ((size_t)n * W) / SEG + (size_t)W * nb;      // sum of ceil(run / SEG) never exceeds this
   const size_t o_par = carve(max_segs * PT_WORDS * 4);
   const size_t o_idx = carve((size_t)W * n * 4);
+  const size_t o_sub = carve((size_t)W * n);                            // level-1 placement: bucket index within the super-bucket
+  static_assert(PT_WORDS >= SEG, "the level-1 index array borrows the segment partials' area");
   const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
   const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
   // ping-pong buffers of the 32-to-1 folds, sized from the fold sequence itself: the first fold writes
@@ -533,12 +591,13 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   uint32_t *bh = (uint32_t*)(m + o_bh), *offs = (uint32_t*)(m + o_off);
   uint32_t *segoff = (uint32_t*)(m + o_seg), *partial = (uint32_t*)(m + o_par);
   uint32_t* idx = (uint32_t*)(m + o_idx);
+  uint32_t* tmp_idx = partial;                                // W * n words <= max_segs records: free until k_msm_segments writes it
+  uint8_t* tmp_sub = m + o_sub;
   uint32_t *bkt = (uint32_t*)(m + o_bkt), *ch = (uint32_t*)(m + o_ch), *f0 = (uint32_t*)(m + o_f0), *f1 = (uint32_t*)(m + o_f1);
   const SqrtTables T = d.tables();
   const size_t hist_bytes = (size_t)nb * 4;                  // one window's histogram in LDS (<= 128 KiB at c = 16)
   if (hist_bytes > 64 * 1024) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
   }
 
   if (n) {
@@ -556,7 +615,8 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   }
   hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
   hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, bh, offs, segoff, nb, S);
-  hipLaunchKernelGGL(k_msm_place, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh, idx);
+  hipLaunchKernelGGL(k_msm_place1, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
+  hipLaunchKernelGGL(k_msm_place2, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
   hipLaunchKernelGGL(k_msm_segments, dim3(grid_of(d, max_segs)), dim3(BLOCK), 0, s, pts, idx, offs, segoff, n, W, nb,
                      max_segs, partial);
   hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, partial, segoff, W, nb, bkt);

@@ -14,7 +14,8 @@ for lg in (12, 16, 20, 22):
     k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
     encs = ctx.encode_to_curve(r0)
     P, _ = ctx.decompress(encs)
-    for name, pts in (("elements", P), ("encodings", encs)):
+    P2 = ctx.double(P)                                     # projective (Z != 1): the normalisation's inversion is not skipped
+    for name, pts in (("elements", P), ("encodings", encs), ("el. Z!=1", P2)):
         ctx.msm(pts, k)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
