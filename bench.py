@@ -275,6 +275,13 @@ def main():
         aff = torch.empty((ne, 8), dtype=torch.int64, device=dev)
         ker, _ = time_op(torch, lambda: ctx.to_affine(pm, outs=[aff]), 3, 1)
         extra["to_affine"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}
+        # `Element * Fr` with the reference's own signature (Elements in and out: no square root at either end) and
+        # Fr products on 32-byte scalars (the one HBM-priced op here: 96 algorithmic bytes per product)
+        pm2 = torch.empty_like(pm)
+        ker, _ = time_op(torch, lambda: ctx.scalar_mul_var_element(pm, scalars[:ne], outs=[pm2]), 3, 1)
+        extra["scalar_mul_var_element"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}
+        ker, _ = time_op(torch, lambda: ctx.fr_op("mul", scalars[:ne], r0[:ne], outs=[o1, s1]), 3, 1)
+        extra["fr_mul"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3), "algo_GBps": 97 * ne / (ker * 1e-3) / 1e9}
         extra["encodes_per_sec"] = extra["roundtrip"]["per_sec_all_gpus"]          # whole job, all GPUs
         extra["elligator_encodes_per_sec"] = extra["encode_to_curve"]["per_sec_all_gpus"]
         line["extra"] = extra

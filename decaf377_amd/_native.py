@@ -30,6 +30,11 @@ EXPORTS = [
     "d377_batch_encode_to_curve_dev", "d377_batch_hash_to_curve_dev",
     "d377_batch_sqrt_ratio_zeta_ex", "d377_batch_sqrt_ratio_zeta_ex_dev", "d377_batch_sharded_dev",
     "d377_ctx_invariant_failures",
+    "d377_batch_scalar_mul_var_element", "d377_batch_scalar_mul_base_element", "d377_batch_compress_to_field",
+    "d377_batch_encode_to_curve_element", "d377_batch_hash_to_curve_element",
+    "d377_batch_scalar_mul_var_element_dev", "d377_batch_scalar_mul_base_element_dev", "d377_batch_compress_to_field_dev",
+    "d377_batch_encode_to_curve_element_dev", "d377_batch_hash_to_curve_element_dev",
+    "d377_batch_fr_op", "d377_batch_fr_op_dev", "d377_batch_fr_from_wide_bytes", "d377_batch_fr_from_wide_bytes_dev",
 ]
 
 _lib = None
@@ -82,6 +87,11 @@ def load():
         "d377_batch_eq": [vp, vp, vp, sz, vp],
         "d377_batch_neg": [vp, vp, sz, vp],
         "d377_batch_is_identity": [vp, vp, sz, vp],
+        "d377_batch_scalar_mul_var_element": [vp, vp, vp, sz, vp],
+        "d377_batch_scalar_mul_base_element": [vp, vp, sz, vp],
+        "d377_batch_compress_to_field": [vp, vp, sz, vp],
+        "d377_batch_encode_to_curve_element": [vp, vp, sz, vp],
+        "d377_batch_hash_to_curve_element": [vp, vp, vp, sz, vp],
     }
     for name, args in host.items():
         getattr(lib, name).argtypes = args
@@ -92,6 +102,12 @@ def load():
     lib.d377_batch_fq_from_wide_bytes.argtypes = [vp, vp, sz, sz, vp]
     lib.d377_batch_encode_to_curve_wide.argtypes = [vp, vp, sz, sz, vp]
     lib.d377_batch_to_affine.argtypes = [vp, vp, sz, vp]
+    lib.d377_batch_fr_from_wide_bytes.argtypes = [vp, vp, sz, sz, vp]
+    lib.d377_batch_fr_from_wide_bytes_dev.argtypes = [vp, i32, vp, vp, sz, sz, vp]
+    lib.d377_batch_fr_op.argtypes = [vp, i32, vp, vp, sz, vp, vp]
+    lib.d377_batch_fr_op_dev.argtypes = [vp, i32, vp, i32, vp, vp, sz, vp, vp]
+    for name in ("d377_batch_fr_from_wide_bytes", "d377_batch_fr_from_wide_bytes_dev", "d377_batch_fr_op", "d377_batch_fr_op_dev"):
+        getattr(lib, name).restype = i32
     lib.d377_batch_fq_from_wide_bytes_dev.argtypes = [vp, i32, vp, vp, sz, sz, vp]
     lib.d377_batch_encode_to_curve_wide_dev.argtypes = [vp, i32, vp, vp, sz, sz, vp]
     lib.d377_batch_to_affine_dev.argtypes = [vp, i32, vp, vp, sz, vp]

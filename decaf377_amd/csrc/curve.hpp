@@ -454,6 +454,118 @@ D377_HD void fr_reduce_words(uint32_t k[8]) {
   // started >= 63r, impossible for a 256-bit value (2^256 / r < 54)
 }
 
+// ---- scalar-field arithmetic on canonical values (eight 32-bit words, < r) --------------------
+// Fr add / sub / mul / neg / square / inverse: src/fields/fr/u64/wrapper.rs:76-108 (-> ark-ff MontBackend).
+// Scalars cross the boundary as canonical 32-byte strings (Fr::to_bytes_le, :63-70), so these take and return
+// canonical words; the Montgomery form (R = 2^256, word-level CIOS) is internal to a product.
+D377_HD void fr_const_words(const uint32_t (&c)[8], uint32_t out[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = c[i];
+}
+D377_HD void fr_cond_sub_r(uint32_t a[8], uint32_t top) {           // a + top * 2^256 < 2r  ->  a mod r
+  uint32_t d[8];
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t t = (uint64_t)a[i] - FR_ORDER_W_LIT[i] - borrow;
+    d[i] = (uint32_t)t;
+    borrow = (t >> 63) & 1u;
+  }
+  if (top != 0 || borrow == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = d[i];
+  }
+}
+D377_HD void fr_addmod(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c += (uint64_t)a[i] + b[i]; out[i] = (uint32_t)c; c >>= 32; }
+  fr_cond_sub_r(out, (uint32_t)c);                                   // a, b < r < 2^251: no carry out, kept for clarity
+}
+D377_HD void fr_submod(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t t = (uint64_t)a[i] - b[i] - borrow;
+    out[i] = (uint32_t)t;
+    borrow = (t >> 63) & 1u;
+  }
+  if (borrow) {                                                      // a < b: add r back
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c += (uint64_t)out[i] + FR_ORDER_W_LIT[i]; out[i] = (uint32_t)c; c >>= 32; }
+  }
+}
+// a * b / 2^256 mod r for a, b < r: CIOS, one word of b per round; the running value stays below 2r
+D377_HD void fr_montmul(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
+  uint32_t t[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      c += (uint64_t)a[j] * b[i] + t[j];
+      t[j] = (uint32_t)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[8] = (uint32_t)c;
+    t[9] = (uint32_t)(c >> 32);
+    const uint32_t m = t[0] * FR_NINV32;
+    c = ((uint64_t)m * FR_ORDER_W_LIT[0] + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      c += (uint64_t)m * FR_ORDER_W_LIT[j] + t[j];
+      t[j - 1] = (uint32_t)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[7] = (uint32_t)c;
+    t[8] = t[9] + (uint32_t)(c >> 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = t[i];
+  fr_cond_sub_r(out, t[8]);
+}
+D377_HD void fr_mulmod(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
+  uint32_t t[8], r2[8];
+  fr_const_words(FR_R2_W_LIT, r2);
+  fr_montmul(a, b, t);                                               // ab / R
+  fr_montmul(t, r2, out);                                            // ab
+}
+// a^(r-2); returns false (and zero) for a = 0, as Fr::inverse returns None (wrapper.rs:80-86)
+D377_HD bool fr_invmod(const uint32_t a[8], uint32_t out[8]) {
+  uint32_t x[8], acc[8], c[8];
+  fr_const_words(FR_R2_W_LIT, c);
+  fr_montmul(a, c, x);                                               // a R
+  fr_const_words(FR_R1_W_LIT, acc);                                  // 1 R
+#pragma unroll 1
+  for (int i = 250; i >= 0; --i) {                                   // r - 2 < 2^251
+    fr_montmul(acc, acc, acc);
+    if ((FR_ORDER_MINUS_2_W_LIT[i >> 5] >> (i & 31)) & 1u) fr_montmul(acc, x, acc);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c[i] = i == 0 ? 1u : 0u;
+  fr_montmul(acc, c, out);                                           // out of Montgomery form
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) nz |= a[i];
+  return nz != 0;
+}
+// Fr::from_le_bytes_mod_order for 33..64 bytes (src/fields/fr.rs:82-94): lo + hi * 2^256 mod r
+D377_HD void fr_from_wide_words(const uint32_t lo_in[8], const uint32_t hi_in[8], uint32_t out[8]) {
+  uint32_t lo[8], hi[8], r2[8], t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { lo[i] = lo_in[i]; hi[i] = hi_in[i]; }
+  fr_reduce_words(lo);
+  fr_reduce_words(hi);
+  fr_const_words(FR_R2_W_LIT, r2);
+  fr_montmul(hi, r2, t);                                             // hi * 2^256
+  fr_addmod(lo, t, out);
+}
+
 // signed radix-16 recoding of k < r < 2^251: k = sum d_i 16^i, d_i in [-8, 8), i = 0..63.
 // Packed as 64 nibbles (two's complement 4-bit) in 8 words.
 D377_HD void fr_recode_signed16(const uint32_t k[8], uint32_t digits[8]) {

@@ -273,14 +273,73 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
   }
 }
 
+// The reference's own signatures for these operations take and return Elements (`Element * Fr`,
+// src/min_curve/ops.rs:89-95; `Element::encode_to_curve`, `hash_to_curve`, src/min_curve/element.rs:235-244;
+// `vartime_compress_to_field`, :163-181): the same per-lane code as above without the encoding step at either
+// end.  An Element leaves as whatever projective representative the schedule here produces -- the group element
+// (and so its encoding, and decaf equality) is the reference's; its X:Y:Z:T need not be.
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n,
+                                                                             uint64_t* out, uint32_t* scratch) {
+  GlobalTab tab;
+  tab.base = scratch;
+  tab.nthreads = (size_t)gridDim.x * BLOCK;
+  tab.tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  for (size_t i = tab.tid; i < n; i += tab.nthreads) {
+    uint32_t k[8], dg[8];
+    load32(scalar32, i, k);
+    const ge g = load_ge_mont256(xyzt, i);
+    fr_reduce_words(k);
+    fr_recode_signed16(k, dg);
+    store_ge_mont256(out, i, ge_scalar_mul_w4(g, dg, tab));
+  }
+}
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base_el(const uint32_t* fbase, const uint8_t* scalar32, size_t n,
+                                                                              uint64_t* out) {
+  FixedTab ft{fbase};
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t k[8];
+    load32(scalar32, i, k);
+    fr_reduce_words(k);
+    store_ge_mont256(out, i, ge_scalar_mul_base_w8(k, ft));
+  }
+}
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_compress_to_field(SqrtTables T, const uint64_t* xyzt, size_t n, uint64_t* out) {
+  D377_POW_LDS();
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    ge_compress(T, pt, load_ge_mont256(xyzt, i), w);                 // canonical s
+    fe_to_mont256_words(fe_from_words_mod_order(w), w);
+    store32(reinterpret_cast<uint8_t*>(out), i, w);
+  }
+}
+// second input null: encode_to_curve; otherwise hash_to_curve (two maps and an addition)
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_map_to_element(SqrtTables T, const uint8_t* r1, const uint8_t* r2, size_t n,
+                                                                          uint64_t* out) {
+  D377_POW_LDS();
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(r1, i, w);
+    ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w));
+    if (r2) {
+      load32(r2, i, w);
+      a = ge_add(a, ge_elligator_map(T, pt, fe_from_words_mod_order(w)));
+    }
+    store_ge_mont256(out, i, a);
+  }
+}
+
 // wide byte strings (48 or 64 bytes per record) -> Fq, optionally straight into the Elligator map
-__device__ __forceinline__ fe load_wide(const uint8_t* in, size_t i, int len) {
+__device__ __forceinline__ void load_wide_words(const uint8_t* in, size_t i, int len, uint32_t lo[8], uint32_t hi[8]) {
   const uint4* p = reinterpret_cast<const uint4*>(in + (size_t)len * i);
   uint4 a = p[0], b = p[1], c = p[2];
   uint4 d = make_uint4(0, 0, 0, 0);
   if (len == 64) d = p[3];
-  const uint32_t lo[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  const uint32_t hi[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+  lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; lo[3] = a.w; lo[4] = b.x; lo[5] = b.y; lo[6] = b.z; lo[7] = b.w;
+  hi[0] = c.x; hi[1] = c.y; hi[2] = c.z; hi[3] = c.w; hi[4] = d.x; hi[5] = d.y; hi[6] = d.z; hi[7] = d.w;
+}
+__device__ __forceinline__ fe load_wide(const uint8_t* in, size_t i, int len) {
+  uint32_t lo[8], hi[8];
+  load_wide_words(in, i, len, lo, hi);
   return fe_from_wide_words(lo, hi);
 }
 __global__ void __launch_bounds__(BLOCK) k_fq_from_wide(const uint8_t* in, int len, size_t n, uint8_t* out32) {
@@ -408,6 +467,38 @@ __global__ void __launch_bounds__(BLOCK) k_fr_bytes(const uint8_t* in, size_t n,
     }
   }
 }
+// Fr arithmetic on 32-byte little-endian records (any value: reduced mod r first, as from_le_bytes_mod_order does)
+__global__ void __launch_bounds__(BLOCK) k_fr_op(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t x[8], y[8], r[8];
+    load32(a, i, x);
+    fr_reduce_words(x);
+    if (op <= D377_FQ_MUL) { load32(b, i, y); fr_reduce_words(y); }
+    uint32_t st = 0;
+    switch (op) {
+      case D377_FQ_ADD: fr_addmod(x, y, r); break;
+      case D377_FQ_SUB: fr_submod(x, y, r); break;
+      case D377_FQ_MUL: fr_mulmod(x, y, r); break;
+      case D377_FQ_SQUARE: fr_mulmod(x, x, r); break;
+      case D377_FQ_NEG: {
+        for (int k = 0; k < 8; ++k) y[k] = 0;
+        fr_submod(y, x, r);
+        break;
+      }
+      default: st = fr_invmod(x, r) ? 0u : 1u; break;               // zero record, status 1 for x = 0
+    }
+    store32(out, i, r);
+    if (status) status[i] = (uint8_t)st;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_fr_from_wide(const uint8_t* in, int len, size_t n, uint8_t* out32) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t lo[8], hi[8], r[8];
+    load_wide_words(in, i, len, lo, hi);
+    fr_from_wide_words(lo, hi, r);
+    store32(out32, i, r);
+  }
+}
 __global__ void __launch_bounds__(BLOCK) k_neg(const uint64_t* p, size_t n, uint64_t* out) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
     store_ge_mont256(out, i, ge_neg(load_ge_mont256(p, i)));
@@ -520,7 +611,7 @@ void free_device(DeviceState& d) {
 }
 
 // launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null).
-// aux: the D377_FQ_* selector of OP_FQ_BIN / OP_FQ_UN, the D377_SQRT_ROOT_* convention of OP_SQRT.
+// aux: the D377_FQ_* selector of OP_FQ_BIN / OP_FQ_UN / OP_FR_BIN / OP_FR_UN, the D377_SQRT_ROOT_* convention of OP_SQRT.
 // The caller holds ctx->mu (the scratch guards are host state).
 int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const void* in1, size_t n, void* out0, void* out1) {
   if (n == 0) return D377_OK;
@@ -611,6 +702,36 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     case OP_NEG:
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
+    case OP_MUL_VAR_EL: {
+      int gv = g < d.vb_blocks ? g : d.vb_blocks;
+      if ((rc = d.vb_guard.acquire(s))) return rc;
+      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3(gv), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
+                         (uint64_t*)out0, d.vb_scratch);
+      if ((rc = d.vb_guard.release(s))) return rc;
+      break;
+    }
+    case OP_MUL_BASE_EL:
+      hipLaunchKernelGGL(k_scalar_mul_base_el, dim3(g), dim3(BLOCK), 0, s, d.fbase, (const uint8_t*)in0, n, (uint64_t*)out0);
+      break;
+    case OP_COMPRESS_FIELD:
+      hipLaunchKernelGGL(k_compress_to_field, dim3(g), dim3(BLOCK), 0, s, T, (const uint64_t*)in0, n, (uint64_t*)out0);
+      break;
+    case OP_ENCODE_EL:
+      hipLaunchKernelGGL(k_map_to_element, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)nullptr, n, (uint64_t*)out0);
+      break;
+    case OP_HASH_EL:
+      hipLaunchKernelGGL(k_map_to_element, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n, (uint64_t*)out0);
+      break;
+    case OP_FR_BIN:
+    case OP_FR_UN:
+      hipLaunchKernelGGL(k_fr_op, dim3(g), dim3(BLOCK), 0, s, aux, (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0,
+                         (uint8_t*)out1);
+      break;
+    case OP_FR_WIDE48:
+    case OP_FR_WIDE64:
+      hipLaunchKernelGGL(k_fr_from_wide, dim3(g), dim3(BLOCK), 0, s, (const uint8_t*)in0, op == OP_FR_WIDE48 ? 48 : 64, n,
+                         (uint8_t*)out0);
+      break;
     case OP_IS_IDENTITY:
       hipLaunchKernelGGL(k_is_identity, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint8_t*)out0);
       break;
@@ -645,6 +766,15 @@ OpShape shape_of(Op op) {
     case OP_FR_MOD: return {32, 0, 32, 0};
     case OP_FR_CHECKED: return {32, 0, 32, 1};
     case OP_NEG: return {128, 0, 128, 0};
+    case OP_MUL_VAR_EL: return {128, 32, 128, 0};
+    case OP_MUL_BASE_EL: return {32, 0, 128, 0};
+    case OP_COMPRESS_FIELD: return {128, 0, 32, 0};
+    case OP_ENCODE_EL: return {32, 0, 128, 0};
+    case OP_HASH_EL: return {32, 32, 128, 0};
+    case OP_FR_BIN: return {32, 32, 32, 1};
+    case OP_FR_UN: return {32, 0, 32, 1};
+    case OP_FR_WIDE48: return {48, 0, 32, 0};
+    case OP_FR_WIDE64: return {64, 0, 32, 0};
     case OP_IS_IDENTITY: return {128, 0, 1, 0};
   }
   return {0, 0, 0, 0};
@@ -767,7 +897,7 @@ int check_dev_args(d377_ctx* ctx, int dev, Op op, const void* in0, const void* i
   if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
   if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
   const OpShape sh = shape_of(op);
-  const bool out1_optional = (op == OP_FQ_BIN || op == OP_FQ_UN);
+  const bool out1_optional = (op == OP_FQ_BIN || op == OP_FQ_UN || op == OP_FR_BIN || op == OP_FR_UN);
   if (n && (!in0 || (sh.in1 && !in1) || !out0 || (sh.out1 && !out1 && !out1_optional))) return fail(D377_ERR_ARG, "%s", "null buffer");
   if (!aligned16(in0) || !aligned16(in1) || (sh.out0 >= 16 && !aligned16(out0)))
     return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
@@ -841,7 +971,7 @@ int run_sharded_dev(d377_ctx* ctx, int root, void* stream, Op op, int aux, const
 
 extern "C" {
 
-const char* d377_version(void) { return "decaf377_amd 0.2.0 (gfx950)"; }
+const char* d377_version(void) { return "decaf377_amd 0.3.0 (gfx950)"; }
 const char* d377_last_error(void) { return d377_g_err; }
 
 int d377_device_count(void) {
@@ -1001,6 +1131,52 @@ int d377_batch_fr_from_le_bytes_mod_order(d377_ctx* ctx, const uint8_t* bytes32,
 int d377_batch_fr_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out, uint8_t* status) {
   return run_host(ctx, OP_FR_CHECKED, 0, bytes32, nullptr, n, fr32_out, status);
 }
+int d377_batch_fr_op(d377_ctx* ctx, int op, const uint8_t* a32, const uint8_t* b32, size_t n, uint8_t* out32, uint8_t* status) {
+  if (op < D377_FQ_ADD || op > D377_FQ_INVERSE) return fail(D377_ERR_ARG, "%s", "unknown Fr operation");
+  std::vector<uint8_t> scratch;
+  if (!status) { scratch.resize(n ? n : 1); status = scratch.data(); }
+  return run_host(ctx, op <= D377_FQ_MUL ? OP_FR_BIN : OP_FR_UN, op, a32, op <= D377_FQ_MUL ? b32 : nullptr, n, out32, status);
+}
+int d377_batch_fr_op_dev(d377_ctx* ctx, int dev, void* stream, int op, const uint8_t* a32, const uint8_t* b32, size_t n,
+                         uint8_t* out32, uint8_t* status) {
+  if (op < D377_FQ_ADD || op > D377_FQ_INVERSE) return fail(D377_ERR_ARG, "%s", "unknown Fr operation");
+  if (op == D377_FQ_INVERSE && !status) return fail(D377_ERR_ARG, "%s", "INVERSE needs a status buffer");
+  return run_dev(ctx, dev, stream, op <= D377_FQ_MUL ? OP_FR_BIN : OP_FR_UN, op, a32, op <= D377_FQ_MUL ? b32 : nullptr, n, out32,
+                 status);
+}
+int d377_batch_scalar_mul_var_element(d377_ctx* ctx, const uint64_t* p_xyzt, const uint8_t* scalar32, size_t n, uint64_t* out_xyzt) {
+  return run_host(ctx, OP_MUL_VAR_EL, 0, p_xyzt, scalar32, n, out_xyzt, nullptr);
+}
+int d377_batch_scalar_mul_base_element(d377_ctx* ctx, const uint8_t* scalar32, size_t n, uint64_t* out_xyzt) {
+  return run_host(ctx, OP_MUL_BASE_EL, 0, scalar32, nullptr, n, out_xyzt, nullptr);
+}
+int d377_batch_compress_to_field(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* fq_out) {
+  return run_host(ctx, OP_COMPRESS_FIELD, 0, p_xyzt, nullptr, n, fq_out, nullptr);
+}
+int d377_batch_encode_to_curve_element(d377_ctx* ctx, const uint8_t* fq32, size_t n, uint64_t* out_xyzt) {
+  return run_host(ctx, OP_ENCODE_EL, 0, fq32, nullptr, n, out_xyzt, nullptr);
+}
+int d377_batch_hash_to_curve_element(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t* r2_32, size_t n, uint64_t* out_xyzt) {
+  return run_host(ctx, OP_HASH_EL, 0, r1_32, r2_32, n, out_xyzt, nullptr);
+}
+int d377_batch_scalar_mul_var_element_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint8_t* scalar32,
+                                          size_t n, uint64_t* out_xyzt) {
+  return run_dev(ctx, dev, stream, OP_MUL_VAR_EL, 0, p_xyzt, scalar32, n, out_xyzt, nullptr);
+}
+int d377_batch_scalar_mul_base_element_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* scalar32, size_t n,
+                                           uint64_t* out_xyzt) {
+  return run_dev(ctx, dev, stream, OP_MUL_BASE_EL, 0, scalar32, nullptr, n, out_xyzt, nullptr);
+}
+int d377_batch_compress_to_field_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n, uint64_t* fq_out) {
+  return run_dev(ctx, dev, stream, OP_COMPRESS_FIELD, 0, p_xyzt, nullptr, n, fq_out, nullptr);
+}
+int d377_batch_encode_to_curve_element_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* fq32, size_t n, uint64_t* out_xyzt) {
+  return run_dev(ctx, dev, stream, OP_ENCODE_EL, 0, fq32, nullptr, n, out_xyzt, nullptr);
+}
+int d377_batch_hash_to_curve_element_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* r1_32, const uint8_t* r2_32,
+                                         size_t n, uint64_t* out_xyzt) {
+  return run_dev(ctx, dev, stream, OP_HASH_EL, 0, r1_32, r2_32, n, out_xyzt, nullptr);
+}
 int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
   return run_host(ctx, OP_NEG, 0, p_xyzt, nullptr, n, out_xyzt, nullptr);
 }
@@ -1038,6 +1214,15 @@ static int wide_op(size_t len, Op o48, Op o64, Op* out) {
 int d377_batch_fq_from_wide_bytes(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* fq32_out) {
   Op op; int rc = wide_op(len, OP_WIDE48, OP_WIDE64, &op);
   return rc ? rc : run_host(ctx, op, 0, bytes, nullptr, n, fq32_out, nullptr);
+}
+int d377_batch_fr_from_wide_bytes(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* fr32_out) {
+  Op op; int rc = wide_op(len, OP_FR_WIDE48, OP_FR_WIDE64, &op);
+  return rc ? rc : run_host(ctx, op, 0, bytes, nullptr, n, fr32_out, nullptr);
+}
+int d377_batch_fr_from_wide_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len, size_t n,
+                                      uint8_t* fr32_out) {
+  Op op; int rc = wide_op(len, OP_FR_WIDE48, OP_FR_WIDE64, &op);
+  return rc ? rc : run_dev(ctx, dev, stream, op, 0, bytes, nullptr, n, fr32_out, nullptr);
 }
 int d377_batch_encode_to_curve_wide(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* enc32_out) {
   Op op; int rc = wide_op(len, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, &op);
@@ -1109,6 +1294,8 @@ int d377_batch_sharded_dev(d377_ctx* ctx, int root_dev, void* stream, int op, co
     case D377_OP_SCALAR_MUL_VAR: o = OP_MUL_VAR; break;
     case D377_OP_ENCODE_TO_CURVE: o = OP_ENCODE; break;
     case D377_OP_HASH_TO_CURVE: o = OP_HASH; break;
+    case D377_OP_SCALAR_MUL_VAR_ELEMENT: o = OP_MUL_VAR_EL; break;
+    case D377_OP_SCALAR_MUL_BASE_ELEMENT: o = OP_MUL_BASE_EL; break;
     default: return fail(D377_ERR_ARG, "%s", "unknown D377_OP_* code");
   }
   return run_sharded_dev(ctx, root_dev, stream, o, 0, in0, in1, n, out0, out1);

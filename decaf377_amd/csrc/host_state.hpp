@@ -114,7 +114,8 @@ struct SyncOnError {
 // op codes of the generic launcher in d377.hip (shared with the sharded path)
 enum Op { OP_SQRT, OP_DECOMPRESS, OP_COMPRESS, OP_ROUNDTRIP, OP_MUL_BASE, OP_MUL_VAR, OP_ENCODE, OP_HASH, OP_ADD, OP_DOUBLE,
           OP_EQ, OP_WIDE48, OP_WIDE64, OP_ENCODE_WIDE48, OP_ENCODE_WIDE64, OP_AFFINE, OP_NEG, OP_IS_IDENTITY, OP_FQ_BIN,
-          OP_FQ_UN, OP_FQ_CHECKED, OP_FQ_TO_BYTES, OP_FR_MOD, OP_FR_CHECKED };
+          OP_FQ_UN, OP_FQ_CHECKED, OP_FQ_TO_BYTES, OP_FR_MOD, OP_FR_CHECKED, OP_MUL_VAR_EL, OP_MUL_BASE_EL, OP_COMPRESS_FIELD,
+          OP_ENCODE_EL, OP_HASH_EL, OP_FR_BIN, OP_FR_UN, OP_FR_WIDE48, OP_FR_WIDE64 };
 
 // D377_DEBUG_DEVICE_DELAY_MS (tests only): every per-device worker of a multi-device host call sleeps this
 // long before it touches its device, which makes "the devices work concurrently" observable on a box

@@ -44,7 +44,8 @@ AFF = ((8,), "u64")          # affine x, y
 FLAG = ((), "u8")            # one status / flag byte per element
 SQRT_ROOT = {"ark": 0, "arkworks": 0, "min_curve": 1}
 SHARD_OPS = {"sqrt_ratio_zeta": 0, "decompress": 1, "compress": 2, "roundtrip": 3, "scalar_mul_base": 4,
-             "scalar_mul_var": 5, "encode_to_curve": 6, "hash_to_curve": 7}
+             "scalar_mul_var": 5, "encode_to_curve": 6, "hash_to_curve": 7, "scalar_mul_var_element": 8,
+             "scalar_mul_base_element": 9}
 
 
 def _check(a, spec, n, what, device=None):
@@ -107,11 +108,12 @@ class Context:
             raise _native.NativeError("tensor on cuda:%s but context owns %s" % (dev.index, self.device_ids))
         return self.device_ids.index(dev.index)
 
-    def _run(self, name, ins, in_specs, out_specs, outs=None, pre=(), sharded_op=None):
+    def _run(self, name, ins, in_specs, out_specs, outs=None, pre=(), sharded_op=None, in_slots=None):
         """ins: input arrays (specs in `in_specs`); out_specs: row layouts of the outputs.  Host or
         device path by the type of the first input; `pre` = extra integer arguments that precede the
         buffers in the C signature; `outs` lets a caller reuse output arrays (checked like inputs).
-        sharded_op: run through d377_batch_sharded_dev (HBM-resident batch split over the context's GPUs)."""
+        sharded_op: run through d377_batch_sharded_dev (HBM-resident batch split over the context's GPUs).
+        in_slots: input-pointer parameters of the C signature when some are unused by this call (passed NULL)."""
         n = _rows(ins[0])
         np_dt = {"u8": np.uint8, "u64": np.uint64}
         if _is_torch(ins[0]):
@@ -140,6 +142,7 @@ class Context:
                 _native.check(self._lib.d377_batch_sharded_dev(self._h, di, ctypes.c_void_p(stream), sharded_op,
                                                                bufs[0], bufs[1], ctypes.c_size_t(n), obufs[0], obufs[1]))
                 return outs
+            bufs += [None] * ((in_slots or len(bufs)) - len(bufs))
             args = [self._h, di, ctypes.c_void_p(stream)] + list(pre) + bufs + [ctypes.c_size_t(n)] + obufs
             _native.check(getattr(self._lib, name + "_dev")(*args))
             return outs
@@ -159,7 +162,8 @@ class Context:
                 _check(a, spec, n, name + " output")
                 if not a.flags["C_CONTIGUOUS"]:
                     raise ValueError("%s output must be contiguous" % name)
-        args = [self._h] + list(pre) + [a.ctypes.data_as(ctypes.c_void_p) for a in ins] + [ctypes.c_size_t(n)]
+        args = [self._h] + list(pre) + [a.ctypes.data_as(ctypes.c_void_p) for a in ins]
+        args += [None] * ((in_slots or len(ins)) - len(ins)) + [ctypes.c_size_t(n)]
         args += [a.ctypes.data_as(ctypes.c_void_p) for a in outs]
         _native.check(getattr(self._lib, name)(*args))
         return outs
@@ -192,6 +196,25 @@ class Context:
     def hash_to_curve(self, r1_32, r2_32, outs=None):
         return self._run("d377_batch_hash_to_curve", [r1_32, r2_32], [ENC, ENC], [ENC], outs)[0]
 
+    # The reference's own signatures: Elements in and out, no encoding step (src/min_curve/ops.rs:89-95,
+    # src/min_curve/element.rs:163-181, 190-244).  A scalar multiplication returns some extended representative
+    # of the reference's group element: compare with eq() or through compress().
+    def scalar_mul_var_element(self, p_xyzt, scalar32, outs=None):
+        return self._run("d377_batch_scalar_mul_var_element", [p_xyzt, scalar32], [ELEM, ENC], [ELEM], outs)[0]
+
+    def scalar_mul_base_element(self, scalar32, outs=None):
+        return self._run("d377_batch_scalar_mul_base_element", [scalar32], [ENC], [ELEM], outs)[0]
+
+    def compress_to_field(self, p_xyzt, outs=None):
+        """Element::vartime_compress_to_field -> [n, 4] u64 Montgomery limbs of s."""
+        return self._run("d377_batch_compress_to_field", [p_xyzt], [ELEM], [FQM], outs)[0]
+
+    def encode_to_curve_element(self, fq32, outs=None):
+        return self._run("d377_batch_encode_to_curve_element", [fq32], [ENC], [ELEM], outs)[0]
+
+    def hash_to_curve_element(self, r1_32, r2_32, outs=None):
+        return self._run("d377_batch_hash_to_curve_element", [r1_32, r2_32], [ENC, ENC], [ELEM], outs)[0]
+
     def add(self, p_xyzt, q_xyzt, outs=None):
         return self._run("d377_batch_add", [p_xyzt, q_xyzt], [ELEM, ELEM], [ELEM], outs)[0]
 
@@ -214,7 +237,8 @@ class Context:
         specs = {"sqrt_ratio_zeta": ([ENC, ENC], [ENC, FLAG]), "decompress": ([ENC], [ELEM, FLAG]),
                  "compress": ([ELEM], [ENC]), "roundtrip": ([ENC], [ENC, FLAG]), "scalar_mul_base": ([ENC], [ENC]),
                  "scalar_mul_var": ([ENC, ENC], [ENC, FLAG]), "encode_to_curve": ([ENC], [ENC]),
-                 "hash_to_curve": ([ENC, ENC], [ENC])}[op]
+                 "hash_to_curve": ([ENC, ENC], [ENC]), "scalar_mul_var_element": ([ELEM, ENC], [ELEM]),
+                 "scalar_mul_base_element": ([ENC], [ELEM])}[op]
         ins = [in0] if in1 is None else [in0, in1]
         if len(ins) != len(specs[0]):
             raise ValueError("%s takes %d input arrays" % (op, len(specs[0])))
@@ -253,6 +277,21 @@ class Context:
             self._h, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b.shape[0]),
             out.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p)))
         return out, st[:b.shape[0]]
+
+    def fr_op(self, op, a32, b32=None, outs=None):
+        """Fr add/sub/mul (binary) and square/neg/inverse (unary) on [n, 32] little-endian scalars
+        (src/fields/fr/u64/wrapper.rs:76-108): inputs reduced mod r, outputs canonical -> (out [n, 32], status [n]);
+        status 1 (and a zero record) only for inverse(0).  numpy arrays or torch CUDA tensors."""
+        code = self.FQ_OPS[op]
+        binary = code <= 2
+        if binary != (b32 is not None):
+            raise ValueError("fr_op %s takes %s" % (op, "two operands" if binary else "one operand"))
+        ins = [a32, b32] if binary else [a32]
+        return self._run("d377_batch_fr_op", ins, [ENC] * len(ins), [ENC, FLAG], outs, pre=(ctypes.c_int(code),), in_slots=2)
+
+    def fr_from_wide_bytes(self, data):
+        """Fr::from_le_bytes_mod_order on [n, 48|64] byte strings -> canonical [n, 32] (src/fields/fr.rs:82-94)."""
+        return self._wide("d377_batch_fr_from_wide_bytes", data)
 
     # -- Fq on in-memory elements (4 Montgomery u64 limbs) ------------------------------------------
     FQ_OPS = {"add": 0, "sub": 1, "mul": 2, "square": 3, "neg": 4, "inverse": 5}
@@ -445,6 +484,39 @@ class Fr(_Bytes32):
     """Batch of scalars given as 32 bytes, interpreted mod r like Fr::from_le_bytes_mod_order
     (src/fields/fr.rs:82-94)."""
 
+    def _op(self, op, other=None):
+        out, st = self._ctx().fr_op(op, self.data, None if other is None else other.data)
+        return Fr(out, self.ctx), st
+
+    def __add__(self, other):
+        return self._op("add", other)[0]
+
+    def __sub__(self, other):
+        return self._op("sub", other)[0]
+
+    def __mul__(self, other):
+        """Fr * Fr, or Fr * Element = Element * Fr (src/min_curve/ops.rs:89-95)."""
+        if isinstance(other, Element):
+            return other * self
+        return self._op("mul", other)[0]
+
+    def __neg__(self):
+        return self._op("neg")[0]
+
+    def square(self):
+        return self._op("square")[0]
+
+    def inverse(self):
+        """Fr::inverse (src/fields/fr/u64/wrapper.rs:80-86) -> (Fr, status[n]); status 1 = None (zero input)."""
+        return self._op("inverse")
+
+    @staticmethod
+    def from_le_bytes_mod_order(data, ctx=None):
+        """Fr::from_le_bytes_mod_order for [n, 32], [n, 48] or [n, 64] byte strings (src/fields/fr.rs:82-94)."""
+        c = ctx or default_context()
+        width = int(data.shape[1])
+        return Fr(c.fr_from_le_bytes_mod_order(data) if width == 32 else c.fr_from_wide_bytes(data), ctx)
+
 
 class Encoding(_Bytes32):
     """Batch of `Encoding([u8; 32])` (src/ark_curve/encoding.rs:14-15)."""
@@ -510,6 +582,29 @@ class Element:
     def vartime_compress(self):
         """Element::vartime_compress (src/ark_curve/encoding.rs:116-128)."""
         return Encoding(self._ctx().compress(self.data), self.ctx)
+
+    def vartime_compress_to_field(self):
+        """Element::vartime_compress_to_field (src/min_curve/element.rs:163-181) -> [n, 4] u64 Montgomery limbs."""
+        return self._ctx().compress_to_field(self.data)
+
+    def __mul__(self, scalars):
+        """Element * Fr -> Element (src/min_curve/ops.rs:89-95)."""
+        return Element(self._ctx().scalar_mul_var_element(self.data, scalars.data), self.ctx)
+
+    @staticmethod
+    def encode_to_curve_element(r):
+        """Element::encode_to_curve (src/min_curve/element.rs:242-244) as an Element."""
+        return Element(r._ctx().encode_to_curve_element(r.data), r.ctx)
+
+    @staticmethod
+    def hash_to_curve_element(r1, r2):
+        """Element::hash_to_curve (src/min_curve/element.rs:235-240) as an Element."""
+        return Element(r1._ctx().hash_to_curve_element(r1.data, r2.data), r1.ctx)
+
+    @staticmethod
+    def generator_mul_element(scalars):
+        """Element::GENERATOR * scalars as Elements."""
+        return Element(scalars._ctx().scalar_mul_base_element(scalars.data), scalars.ctx)
 
     @staticmethod
     def encode_to_curve(r):

@@ -111,6 +111,23 @@ int d377_batch_encode_to_curve(d377_ctx* ctx, const uint8_t* fq32, size_t n, uin
 int d377_batch_hash_to_curve(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t* r2_32, size_t n,
                              uint8_t* enc32_out);
 
+/* The same operations with the reference's own signatures: Elements in, Elements out, no encoding step.
+ *   Element * Fr                                               src/min_curve/ops.rs:89-95, element.rs:138-157
+ *   Element::GENERATOR * Fr
+ *   Element::vartime_compress_to_field -> Fq (4 Montgomery limbs) src/min_curve/element.rs:163-181
+ *   Element::encode_to_curve / hash_to_curve -> Element         src/min_curve/element.rs:190-244
+ * An Element returned by the scalar multiplications is some extended representative of the reference's group
+ * element (same encoding, equal under d377_batch_eq); its X:Y:Z:T are those of the schedule here (signed
+ * windows), not of the reference's double-and-add.  encode_to_curve / hash_to_curve return the coordinates
+ * the reference's formulas give.  scalar32: any 32 bytes, reduced mod r. */
+int d377_batch_scalar_mul_var_element(d377_ctx* ctx, const uint64_t* p_xyzt, const uint8_t* scalar32, size_t n,
+                                      uint64_t* out_xyzt);
+int d377_batch_scalar_mul_base_element(d377_ctx* ctx, const uint8_t* scalar32, size_t n, uint64_t* out_xyzt);
+int d377_batch_compress_to_field(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* fq_out);
+int d377_batch_encode_to_curve_element(d377_ctx* ctx, const uint8_t* fq32, size_t n, uint64_t* out_xyzt);
+int d377_batch_hash_to_curve_element(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t* r2_32, size_t n,
+                                     uint64_t* out_xyzt);
+
 /* Element + Element, Element::double, decaf equality (x1*y2 == x2*y1) on in-memory elements
  *            src/min_curve/element.rs:291-322, 119-136, 334-340; ark: element/projective.rs:65-70
  * Results are the same extended coordinates the reference formulas produce. */
@@ -162,6 +179,17 @@ int d377_batch_fq_to_bytes(d377_ctx* ctx, const uint64_t* a, size_t n, uint8_t* 
 int d377_batch_fr_from_le_bytes_mod_order(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out);
 int d377_batch_fr_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out, uint8_t* status);
 
+/* Fr arithmetic                                                   src/fields/fr/u64/wrapper.rs:76-108
+ * Scalars travel as 32-byte little-endian strings (Fr::to_bytes_le, wrapper.rs:63-70), as in the scalar
+ * multiplications above: inputs are any 32 bytes (reduced mod r first), outputs canonical.  op: the D377_FQ_*
+ * selectors (ADD / SUB / MUL binary, b32 != NULL; SQUARE / NEG / INVERSE unary, b32 NULL).  INVERSE mirrors
+ * `Fr::inverse() -> Option<Fr>`: status[i] = 1 and a zero record for a zero input (status may be NULL for the
+ * other ops).  d377_batch_fr_from_wide_bytes: Fr::from_le_bytes_mod_order on 48- or 64-byte strings (hash
+ * outputs, `Fr::rand`)                                           src/fields/fr.rs:82-94, 118-126 */
+int d377_batch_fr_op(d377_ctx* ctx, int op, const uint8_t* a32, const uint8_t* b32, size_t n, uint8_t* out32,
+                     uint8_t* status);
+int d377_batch_fr_from_wide_bytes(d377_ctx* ctx, const uint8_t* bytes, size_t len, size_t n, uint8_t* fr32_out);
+
 /* -Element (x, t negated), Element::is_identity (x == 0), and the constants Element::IDENTITY /
  * Element::GENERATOR as one 16 x u64 record each      src/min_curve/element.rs:324-332, 113-117, 53-81 */
 int d377_batch_neg(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);
@@ -206,6 +234,20 @@ int d377_batch_fq_from_wide_bytes_dev(d377_ctx* ctx, int dev, void* stream, cons
 int d377_batch_encode_to_curve_wide_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len,
                                         size_t n, uint8_t* enc32_out);
 int d377_batch_to_affine_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t n, uint64_t* xy);
+int d377_batch_scalar_mul_var_element_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt,
+                                          const uint8_t* scalar32, size_t n, uint64_t* out_xyzt);
+int d377_batch_scalar_mul_base_element_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* scalar32, size_t n,
+                                           uint64_t* out_xyzt);
+int d377_batch_compress_to_field_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n,
+                                     uint64_t* fq_out);
+int d377_batch_encode_to_curve_element_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* fq32, size_t n,
+                                           uint64_t* out_xyzt);
+int d377_batch_hash_to_curve_element_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* r1_32,
+                                         const uint8_t* r2_32, size_t n, uint64_t* out_xyzt);
+int d377_batch_fr_op_dev(d377_ctx* ctx, int dev, void* stream, int op, const uint8_t* a32, const uint8_t* b32, size_t n,
+                         uint8_t* out32, uint8_t* status);
+int d377_batch_fr_from_wide_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len,
+                                      size_t n, uint8_t* fr32_out);
 /* MSM on device buffers (the workspace grows inside the context on first use of a larger n). */
 int d377_msm_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, const uint8_t* scalar32, size_t n,
                  uint8_t* enc32_out, uint64_t* xyzt_out);
@@ -229,6 +271,8 @@ int d377_sum_elements_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* 
 #define D377_OP_SCALAR_MUL_VAR 5
 #define D377_OP_ENCODE_TO_CURVE 6
 #define D377_OP_HASH_TO_CURVE 7
+#define D377_OP_SCALAR_MUL_VAR_ELEMENT 8
+#define D377_OP_SCALAR_MUL_BASE_ELEMENT 9
 int d377_batch_sharded_dev(d377_ctx* ctx, int root_dev, void* stream, int op, const void* in0, const void* in1, size_t n,
                            void* out0, void* out1);
 

@@ -158,6 +158,56 @@ class Engine {
     check(d377_batch_scalar_mul_var(ctx_, u8(ps), u8(ks), ps.size(), u8m(out), st.data()));
     return results(out, st);
   }
+  /// Element * Fr, Elements in and out (`impl Mul<Fr> for Element`, src/min_curve/ops.rs:89-95)
+  std::vector<Element> mul(const std::vector<Element>& ps, const std::vector<Fr>& ks) {
+    if (ps.size() != ks.size()) throw std::invalid_argument("length mismatch");
+    std::vector<Element> out(ps.size());
+    check(d377_batch_scalar_mul_var_element(ctx_, u64(ps), u8(ks), ps.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  /// Element::GENERATOR * k as Elements
+  std::vector<Element> mul_generator_element(const std::vector<Fr>& ks) {
+    std::vector<Element> out(ks.size());
+    check(d377_batch_scalar_mul_base_element(ctx_, u8(ks), ks.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  /// Element::encode_to_curve / hash_to_curve as Elements (src/min_curve/element.rs:235-244)
+  std::vector<Element> encode_to_curve_element(const std::vector<Fq>& rs) {
+    std::vector<Element> out(rs.size());
+    check(d377_batch_encode_to_curve_element(ctx_, u8(rs), rs.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  std::vector<Element> hash_to_curve_element(const std::vector<Fq>& r1, const std::vector<Fq>& r2) {
+    if (r1.size() != r2.size()) throw std::invalid_argument("length mismatch");
+    std::vector<Element> out(r1.size());
+    check(d377_batch_hash_to_curve_element(ctx_, u8(r1), u8(r2), r1.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  /// Element::vartime_compress_to_field (src/min_curve/element.rs:163-181): 4 Montgomery limbs per element
+  std::vector<std::array<uint64_t, 4>> vartime_compress_to_field(const std::vector<Element>& els) {
+    std::vector<std::array<uint64_t, 4>> out(els.size());
+    check(d377_batch_compress_to_field(ctx_, u64(els), els.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
+  /// Fr + - * (src/fields/fr/u64/wrapper.rs:88-108); square / neg take b empty; inverse: ok = false for zero (:80-86)
+  std::vector<Result<Fr>> fr_op(int op, const std::vector<Fr>& a, const std::vector<Fr>& b = {}) {
+    const bool binary = op <= D377_FQ_MUL;
+    if (binary && a.size() != b.size()) throw std::invalid_argument("length mismatch");
+    std::vector<Fr> out(a.size());
+    std::vector<uint8_t> st(a.size());
+    check(d377_batch_fr_op(ctx_, op, u8(a), binary ? u8(b) : nullptr, a.size(), u8m(out), st.data()));
+    return results(out, st);
+  }
+  std::vector<Fr> fr_add(const std::vector<Fr>& a, const std::vector<Fr>& b) { return values(fr_op(D377_FQ_ADD, a, b)); }
+  std::vector<Fr> fr_sub(const std::vector<Fr>& a, const std::vector<Fr>& b) { return values(fr_op(D377_FQ_SUB, a, b)); }
+  std::vector<Fr> fr_mul(const std::vector<Fr>& a, const std::vector<Fr>& b) { return values(fr_op(D377_FQ_MUL, a, b)); }
+  /// Fr::from_le_bytes_mod_order on n strings of len = 48 or 64 bytes (src/fields/fr.rs:82-94)
+  std::vector<Fr> fr_from_wide_bytes(const std::vector<uint8_t>& bytes, size_t len) {
+    if (len == 0 || bytes.size() % len) throw std::invalid_argument("length mismatch");
+    std::vector<Fr> out(bytes.size() / len);
+    check(d377_batch_fr_from_wide_bytes(ctx_, bytes.data(), len, out.size(), u8m(out)));
+    return out;
+  }
   /// Fq::sqrt_ratio_zeta (src/ark_curve/invsqrt.rs:75-166; SqrtRoot::MinCurve: src/min_curve/invsqrt.rs:73-95)
   std::vector<std::pair<bool, Fq>> sqrt_ratio_zeta(const std::vector<Fq>& num, const std::vector<Fq>& den,
                                                    SqrtRoot which = SqrtRoot::Ark) {
@@ -243,6 +293,12 @@ class Engine {
   static std::vector<Result<T>> results(const std::vector<T>& v, const std::vector<uint8_t>& st) {
     std::vector<Result<T>> r(v.size());
     for (size_t i = 0; i < v.size(); ++i) r[i] = {st[i] == 0, v[i], EncodingError::InvalidEncoding};
+    return r;
+  }
+  template <class T>
+  static std::vector<T> values(const std::vector<Result<T>>& v) {
+    std::vector<T> r(v.size());
+    for (size_t i = 0; i < v.size(); ++i) r[i] = v[i].value;
     return r;
   }
   d377_ctx* ctx_ = nullptr;

@@ -207,6 +207,74 @@ static void fr_from_le_bytes_mod_order(const uint8_t *b, uint64_t out[4]) {
     }
 }
 
+/* Fr arithmetic on canonical values (src/fields/fr/u64/wrapper.rs:76-108 wraps ark-ff's Fp256; only the values
+ * matter here, so this is schoolbook multiplication and a bit-serial reduction -- nothing shared with the GPU's
+ * word-level Montgomery form). */
+static inline void fr_sub_r(uint64_t a[4]) {
+    u128 br = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)a[i] - R_ORDER[i] - br; a[i] = (uint64_t)d; br = (d >> 64) & 1; }
+}
+static void fr_add(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {   /* a, b < r < 2^251 */
+    u128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (u128)a[i] + b[i]; out[i] = (uint64_t)c; c >>= 64; }
+    if (geq_r(out)) fr_sub_r(out);
+}
+static void fr_neg(const uint64_t a[4], uint64_t out[4]) {
+    if ((a[0] | a[1] | a[2] | a[3]) == 0) { memset(out, 0, 32); return; }
+    u128 br = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)R_ORDER[i] - a[i] - br; out[i] = (uint64_t)d; br = (d >> 64) & 1; }
+}
+static void fr_sub(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    uint64_t nb[4]; fr_neg(b, nb); fr_add(a, nb, out);
+}
+static void fr_reduce_bits(const uint64_t *p, int nlimbs, uint64_t out[4]) {     /* p mod r, one bit at a time */
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (int bit = 64 * nlimbs - 1; bit >= 0; --bit) {
+        acc[3] = (acc[3] << 1) | (acc[2] >> 63); acc[2] = (acc[2] << 1) | (acc[1] >> 63);
+        acc[1] = (acc[1] << 1) | (acc[0] >> 63); acc[0] = (acc[0] << 1) | ((p[bit >> 6] >> (bit & 63)) & 1);
+        if (geq_r(acc)) fr_sub_r(acc);                                        /* 2 acc + 1 <= 2r - 1 */
+    }
+    memcpy(out, acc, 32);
+}
+static void fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    uint64_t p[8] = {0};
+    for (int i = 0; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (u128)a[i] * b[j] + p[i + j]; p[i + j] = (uint64_t)c; c >>= 64; }
+        p[i + 4] = (uint64_t)c;
+    }
+    fr_reduce_bits(p, 8, out);
+}
+static int fr_inverse(const uint64_t a[4], uint64_t out[4]) {                  /* wrapper.rs:80-86: None for zero */
+    if ((a[0] | a[1] | a[2] | a[3]) == 0) { memset(out, 0, 32); return 0; }
+    uint64_t e[4] = {R_ORDER[0] - 2, R_ORDER[1], R_ORDER[2], R_ORDER[3]};      /* r is odd and > 2: no borrow */
+    uint64_t acc[4] = {1, 0, 0, 0};
+    for (int bit = 255; bit >= 0; --bit) {
+        fr_mul(acc, acc, acc);
+        if ((e[bit >> 6] >> (bit & 63)) & 1) fr_mul(acc, a, acc);
+    }
+    memcpy(out, acc, 32);
+    return 1;
+}
+/* Fr::from_le_bytes_mod_order for any length, src/fields/fr.rs:82-94: 32-byte chunks, folded from the most
+ * significant one with acc * FIELD_SIZE_POWER_OF_TWO + chunk (fr.rs:75-80 = 2^256 mod r) */
+static void fr_from_le_bytes_mod_order_any(const uint8_t *b, size_t len, uint64_t out[4]) {
+    static const uint64_t two256[5] = {0, 0, 0, 0, 1};
+    uint64_t pow2[4], acc[4] = {0, 0, 0, 0};
+    fr_reduce_bits(two256, 5, pow2);
+    size_t nchunks = (len + 31) / 32;
+    for (size_t c = nchunks; c-- > 0;) {
+        uint8_t padded[32] = {0};
+        size_t l = (c * 32 + 32 <= len) ? 32 : len - c * 32;
+        memcpy(padded, b + c * 32, l);
+        uint64_t x[4], t[4];
+        fr_from_le_bytes_mod_order(padded, x);
+        fr_mul(acc, pow2, t);
+        fr_add(t, x, acc);
+    }
+    memcpy(out, acc, 32);
+}
+
 /* -------------------------------------------------- sqrt_ratio_zeta --- */
 /* src/ark_curve/constants.rs:30-58 */
 #define SQRT_N 47
@@ -592,6 +660,38 @@ API void d377o_fq_op(int op, const uint64_t *a, const uint64_t *b, size_t n, uin
         memcpy(out + 4 * i, r.l, 32);
         if (status) status[i] = st;
     }
+}
+/* Fr operations on 32-byte little-endian scalars (inputs reduced mod r, outputs canonical), same op codes */
+API void d377o_fr_op(int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out, uint8_t *status) {
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t x[4], y[4] = {0, 0, 0, 0}, r[4];
+        fr_from_le_bytes_mod_order(a + 32 * i, x);
+        if (op <= 2) fr_from_le_bytes_mod_order(b + 32 * i, y);
+        uint8_t st = 0;
+        switch (op) {
+        case 0: fr_add(x, y, r); break;
+        case 1: fr_sub(x, y, r); break;
+        case 2: fr_mul(x, y, r); break;
+        case 3: fr_mul(x, x, r); break;
+        case 4: fr_neg(x, r); break;
+        default: st = (uint8_t)!fr_inverse(x, r); break;
+        }
+        store_le(r, out + 32 * i);
+        if (status) status[i] = st;
+    }
+}
+API void d377o_fr_from_wide_bytes(const uint8_t *in, size_t len, size_t n, uint8_t *out32) {
+    for (size_t i = 0; i < n; ++i) { uint64_t r[4]; fr_from_le_bytes_mod_order_any(in + len * i, len, r); store_le(r, out32 + 32 * i); }
+}
+/* Element::vartime_compress_to_field (src/min_curve/element.rs:163-181) as Montgomery limbs */
+API void d377o_compress_to_field(const uint64_t *xyzt, size_t n, uint64_t *mont) {
+    for (size_t i = 0; i < n; ++i) { fq s = el_compress_to_field(el_load(xyzt + 16 * i)); memcpy(mont + 4 * i, s.l, 32); }
+}
+/* Element::hash_to_curve (src/min_curve/element.rs:235-240) as an Element */
+API void d377o_hash_to_curve_xyzt(const uint8_t *r1, const uint8_t *r2, size_t n, uint64_t *xyzt) {
+    for (size_t i = 0; i < n; ++i)
+        el_store(el_add(el_elligator_map(fq_from_le_bytes_mod_order(r1 + 32 * i)),
+                        el_elligator_map(fq_from_le_bytes_mod_order(r2 + 32 * i))), xyzt + 16 * i);
 }
 /* the min_curve backend's root (src/min_curve/invsqrt.rs:73-95) */
 API void d377o_sqrt_ratio_zeta_min_curve(const uint8_t *num32, const uint8_t *den32, size_t n,

@@ -204,6 +204,46 @@ impl Element {
         })?;
         Ok(results(&st, |i| out[i]))
     }
+    /// `Element * Fr` element-wise, Elements in and out (`impl Mul<Fr> for Element`, src/min_curve/ops.rs:89-95).
+    /// The result is the reference's group element; its projective coordinates are the library's own.
+    pub fn mul_batch(ctx: &GpuContext, ps: &[Element], ks: &[Fr]) -> Result<Vec<Element>, GpuError> {
+        assert_eq!(ps.len(), ks.len());
+        let n = ps.len();
+        let xyzt = elements_to_xyzt(ps);
+        let bytes = pack32(ks, |k| k.to_bytes());
+        let mut out = vec![0u64; 16 * n];
+        check(unsafe { ffi::d377_batch_scalar_mul_var_element(ctx.0, xyzt.as_ptr(), bytes.as_ptr(), n, out.as_mut_ptr()) })?;
+        Ok(elements_from_xyzt(&out))
+    }
+    /// `Element::GENERATOR * k` as Elements.
+    pub fn mul_generator_element_batch(ctx: &GpuContext, ks: &[Fr]) -> Result<Vec<Element>, GpuError> {
+        let bytes = pack32(ks, |k| k.to_bytes());
+        let mut out = vec![0u64; 16 * ks.len()];
+        check(unsafe { ffi::d377_batch_scalar_mul_base_element(ctx.0, bytes.as_ptr(), ks.len(), out.as_mut_ptr()) })?;
+        Ok(elements_from_xyzt(&out))
+    }
+    /// `Element::vartime_compress_to_field` (src/min_curve/element.rs:163-181).
+    pub fn vartime_compress_to_field_batch(ctx: &GpuContext, els: &[Element]) -> Result<Vec<Fq>, GpuError> {
+        let xyzt = elements_to_xyzt(els);
+        let mut out = vec![0u64; 4 * els.len()];
+        check(unsafe { ffi::d377_batch_compress_to_field(ctx.0, xyzt.as_ptr(), els.len(), out.as_mut_ptr()) })?;
+        Ok(out.chunks_exact(4).map(fq_limbs).collect())
+    }
+    /// `Element::encode_to_curve` as Elements (the coordinates the reference's formulas give).
+    pub fn encode_to_curve_element_batch(ctx: &GpuContext, rs: &[Fq]) -> Result<Vec<Element>, GpuError> {
+        let bytes = pack32(rs, |r| r.to_bytes());
+        let mut out = vec![0u64; 16 * rs.len()];
+        check(unsafe { ffi::d377_batch_encode_to_curve_element(ctx.0, bytes.as_ptr(), rs.len(), out.as_mut_ptr()) })?;
+        Ok(elements_from_xyzt(&out))
+    }
+    /// `Element::hash_to_curve` as Elements.
+    pub fn hash_to_curve_element_batch(ctx: &GpuContext, r1: &[Fq], r2: &[Fq]) -> Result<Vec<Element>, GpuError> {
+        assert_eq!(r1.len(), r2.len());
+        let (a, b) = (pack32(r1, |r| r.to_bytes()), pack32(r2, |r| r.to_bytes()));
+        let mut out = vec![0u64; 16 * r1.len()];
+        check(unsafe { ffi::d377_batch_hash_to_curve_element(ctx.0, a.as_ptr(), b.as_ptr(), r1.len(), out.as_mut_ptr()) })?;
+        Ok(elements_from_xyzt(&out))
+    }
     pub fn add_batch(ctx: &GpuContext, ps: &[Element], qs: &[Element]) -> Result<Vec<Element>, GpuError> {
         assert_eq!(ps.len(), qs.len());
         let (a, b) = (elements_to_xyzt(ps), elements_to_xyzt(qs));
@@ -354,6 +394,34 @@ impl Fr {
     }
 }
 
+impl Fr {
+    /// Element-wise `Fr` operator (src/fields/fr/u64/wrapper.rs:76-108); `Inverse` yields `None` for zero like `Fr::inverse`.
+    pub fn op_batch(ctx: &GpuContext, op: FqOp, a: &[Fr], b: Option<&[Fr]>) -> Result<Vec<Option<Fr>>, GpuError> {
+        let n = a.len();
+        let la = pack32(a, |x| x.to_bytes());
+        let lb = b.map(|b| {
+            assert_eq!(b.len(), n);
+            pack32(b, |x| x.to_bytes())
+        });
+        let mut out = vec![0u8; 32 * n];
+        let mut st = vec![0u8; n];
+        check(unsafe {
+            ffi::d377_batch_fr_op(ctx.0, op as i32, la.as_ptr(), lb.as_ref().map_or(core::ptr::null(), |v| v.as_ptr()), n,
+                                  out.as_mut_ptr(), st.as_mut_ptr())
+        })?;
+        Ok((0..n).map(|i| if st[i] == 0 { Some(Fr::from_le_bytes_mod_order(&out[32 * i..32 * i + 32])) } else { None }).collect())
+    }
+    /// `Fr::from_le_bytes_mod_order` on 48- or 64-byte strings (hash outputs; `Fr::rand` draws 48 bytes).
+    pub fn from_wide_bytes_batch(ctx: &GpuContext, bytes: &[u8], len: usize) -> Result<Vec<Fr>, GpuError> {
+        assert!(len == 48 || len == 64);
+        assert_eq!(bytes.len() % len, 0);
+        let n = bytes.len() / len;
+        let mut out = vec![0u8; 32 * n];
+        check(unsafe { ffi::d377_batch_fr_from_wide_bytes(ctx.0, bytes.as_ptr(), len, n, out.as_mut_ptr()) })?;
+        Ok(out.chunks_exact(32).map(Fr::from_le_bytes_mod_order).collect())
+    }
+}
+
 // ---- device-pointer forms -----------------------------------------------------------------------
 /// Batches that already live in HBM (hipMalloc'ed by the caller, 16-byte aligned): no copies, enqueued on
 /// `stream` (a `hipStream_t`), no host synchronisation.  Thin `unsafe` pass-throughs: the caller owns the
@@ -365,6 +433,15 @@ pub mod dev {
     pub unsafe fn scalar_mul_var(ctx: &GpuContext, dev: i32, stream: *mut c_void, enc32: *const u8, scalar32: *const u8, n: usize,
                                  enc32_out: *mut u8, status: *mut u8) -> Result<(), GpuError> {
         check(ffi::d377_batch_scalar_mul_var_dev(ctx.0, dev, stream, enc32, scalar32, n, enc32_out, status))
+    }
+    /// `Element` records (16 x u64) in and out: `Element * Fr` with no encoding step.
+    pub unsafe fn scalar_mul_var_element(ctx: &GpuContext, dev: i32, stream: *mut c_void, xyzt: *const u64, scalar32: *const u8, n: usize,
+                                         xyzt_out: *mut u64) -> Result<(), GpuError> {
+        check(ffi::d377_batch_scalar_mul_var_element_dev(ctx.0, dev, stream, xyzt, scalar32, n, xyzt_out))
+    }
+    pub unsafe fn fr_op(ctx: &GpuContext, dev: i32, stream: *mut c_void, op: FqOp, a32: *const u8, b32: *const u8, n: usize, out32: *mut u8,
+                        status: *mut u8) -> Result<(), GpuError> {
+        check(ffi::d377_batch_fr_op_dev(ctx.0, dev, stream, op as i32, a32, b32, n, out32, status))
     }
     pub unsafe fn scalar_mul_base(ctx: &GpuContext, dev: i32, stream: *mut c_void, scalar32: *const u8, n: usize, enc32_out: *mut u8)
         -> Result<(), GpuError> {

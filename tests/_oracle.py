@@ -180,6 +180,34 @@ class Oracle:
         self.lib.d377o_fq_op(ctypes.c_int(op), _p(a), _p(bb) if bb is not None else None, self._n(a.shape[0]), _p(out), _p(st))
         return out, st
 
+    def fr_op(self, op, a, b=None):
+        """op codes as fq_op, on [n, 32] little-endian scalars (any bytes: reduced mod r) -> (canonical bytes, status)."""
+        a = as_u8(a)
+        bb = as_u8(b) if b is not None else None
+        out = np.zeros_like(a)
+        st = np.zeros(a.shape[0], np.uint8)
+        self.lib.d377o_fr_op(ctypes.c_int(op), _p(a), _p(bb) if bb is not None else None, self._n(a.shape[0]), _p(out), _p(st))
+        return out, st
+
+    def fr_from_wide_bytes(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n, length = data.shape
+        out = np.zeros((n, 32), np.uint8)
+        self.lib.d377o_fr_from_wide_bytes(_p(data), ctypes.c_size_t(length), self._n(n), _p(out))
+        return out
+
+    def compress_to_field(self, p):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 16)
+        out = np.zeros((p.shape[0], 4), np.uint64)
+        self.lib.d377o_compress_to_field(_p(p), self._n(p.shape[0]), _p(out))
+        return out
+
+    def hash_to_curve_xyzt(self, r1, r2):
+        r1, r2 = as_u8(r1), as_u8(r2)
+        out = np.zeros((r1.shape[0], 16), np.uint64)
+        self.lib.d377o_hash_to_curve_xyzt(_p(r1), _p(r2), self._n(r1.shape[0]), _p(out))
+        return out
+
     def msm(self, xyzt, k, threads=8):
         """Reference fold; slices are folded on `threads` python-side chunks and summed (the sum is
         commutative and the encoding canonical, so chunking does not change the result)."""

@@ -168,6 +168,36 @@ static void sqrt_ratio_edge_cases(Engine& e) {
   CHECK(differ > 8 && differ < 56);
 }
 
+// tests/operations.rs:19-43 in their literal form, on Elements and with Fr arithmetic on the device:
+//   (a * P) + (b * P) == (a + b) * P        b * (a * P) == (a * b) * P
+static void operations_proptests_literal(Engine& e) {
+  std::mt19937_64 rng(668);
+  const size_t n = 2048;
+  std::vector<Fq> r(n); std::vector<Fr> a(n), b(n);
+  for (size_t i = 0; i < n; ++i) { for (auto& x : r[i].b) x = (uint8_t)rng(); for (auto& x : a[i].b) x = (uint8_t)rng(); for (auto& x : b[i].b) x = (uint8_t)rng(); }
+  auto P = e.encode_to_curve_element(r);               // element_strategy()
+  auto aP = e.mul(P, a), bP = e.mul(P, b);
+  auto lhs = e.add(aP, bP), rhs = e.mul(P, e.fr_add(a, b));
+  auto same = e.eq(lhs, rhs);
+  for (size_t i = 0; i < n; ++i) CHECK(same[i]);
+  auto same2 = e.eq(e.mul(aP, b), e.mul(P, e.fr_mul(a, b)));
+  for (size_t i = 0; i < n; ++i) CHECK(same2[i]);
+  // Element-form and Encoding-form agree; compress_to_field is the encoding as an Fq; the inverse is an inverse
+  auto enc = e.vartime_compress(aP);
+  auto enc2 = e.scalar_mul(e.vartime_compress(P), a);
+  for (size_t i = 0; i < n; ++i) CHECK(enc2[i].ok && enc2[i].value == enc[i]);
+  CHECK(e.vartime_compress_to_field(aP).size() == n);
+  auto inv = e.fr_op(D377_FQ_INVERSE, a);
+  std::vector<Fr> iv(n); for (size_t i = 0; i < n; ++i) { CHECK(inv[i].ok); iv[i] = inv[i].value; }
+  auto one = e.fr_mul(a, iv);
+  for (size_t i = 0; i < n; ++i) CHECK(one[i] == Fr::from_u64(1));
+  CHECK(!e.fr_op(D377_FQ_INVERSE, {Fr::from_u64(0)})[0].ok);
+  auto g1 = e.vartime_compress(e.mul_generator_element({Fr::from_u64(5)}));
+  CHECK(g1[0] == e.mul_generator({Fr::from_u64(5)})[0]);
+  std::vector<uint8_t> wide(64 * 3, 0xff);
+  CHECK(e.fr_from_wide_bytes(wide, 64).size() == 3);
+}
+
 // CurveGroup::normalize_batch, Encoding round trip, MSM over encodings
 static void widened_entry_points(Engine& e) {
   std::vector<Fr> ks;
@@ -191,6 +221,7 @@ int main() {
   test_encoding_matches_sage_encoding(e);
   round_trips_if_successful(e);
   scalar_mul_properties(e);
+  operations_proptests_literal(e);
   vartime_multiscalar_mul_matches_scalar_mul(e);
   sqrt_ratio_edge_cases(e);
   widened_entry_points(e);

@@ -217,6 +217,32 @@ void sim_op_counts(unsigned long* mul, unsigned long* sqr) {
   op_counts().mul = 0; op_counts().sqr = 0;
 }
 #endif
+// the kernels' Fr arithmetic (k_fr_op / k_fr_from_wide in d377.hip): op codes of include/decaf377_amd.h
+void sim_fr_op(int op, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out, uint8_t* st) {
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t x[8], y[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
+    memcpy(x, a + 8 * i, 32); fr_reduce_words(x);
+    if (op <= 2) { memcpy(y, b + 8 * i, 32); fr_reduce_words(y); }
+    st[i] = 0;
+    switch (op) {
+      case 0: fr_addmod(x, y, r); break;
+      case 1: fr_submod(x, y, r); break;
+      case 2: fr_mulmod(x, y, r); break;
+      case 3: fr_mulmod(x, x, r); break;
+      case 4: fr_submod(y, x, r); break;
+      default: st[i] = fr_invmod(x, r) ? 0 : 1; break;
+    }
+    memcpy(out + 8 * i, r, 32);
+  }
+}
+void sim_fr_from_wide(const uint32_t* in, int len, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t lo[8], hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    memcpy(lo, in + (size_t)(len / 4) * i, 32);
+    memcpy(hi, in + (size_t)(len / 4) * i + 8, (size_t)len - 32);
+    fr_from_wide_words(lo, hi, out + 8 * i);
+  }
+}
 void sim_fr_reduce(const uint32_t* k, size_t n, uint32_t* out) {
   for (size_t i = 0; i < n; ++i) { uint32_t kk[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); memcpy(out + 8 * i, kk, 32); }
 }

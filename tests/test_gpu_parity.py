@@ -648,6 +648,121 @@ def test_min_curve_root_2_16(ctx, oracle):
         ctx.sqrt_ratio_zeta(num[:4], den[:4], root="other")
 
 
+def _fq_ints(oracle, mont):
+    """[n, 4] Montgomery limbs -> python ints"""
+    return [int.from_bytes(bytes(r), "little") for r in oracle.fq_to_bytes(np.ascontiguousarray(mont).reshape(-1, 4))]
+
+
+def test_element_form_operations(ctx, oracle):
+    """The reference's own signatures (Elements in and out): `Element * Fr` (src/min_curve/ops.rs:89-95),
+    `GENERATOR * Fr`, `vartime_compress_to_field` (element.rs:163-181), `encode_to_curve` / `hash_to_curve` as
+    Elements (element.rs:190-244).  Scalar multiples are compared as group elements (encoding, decaf equality) and
+    checked to be valid extended points; the maps and compress_to_field are compared limb for limb."""
+    rng = np.random.default_rng(801)
+    n = 1 << 12
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    r1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i, v in enumerate([0, 1, 2, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1]):
+        k[i] = ibytes(v)
+    P = oracle.elligator_map_xyzt(r0)                               # projective, Z != 1
+    P[40] = oracle.identity_xyzt()
+    P[41] = oracle.add_xyzt(P[42:43], oracle.neg_xyzt(P[42:43]))[0]  # the identity with Z != 1
+    out = ctx.scalar_mul_var_element(P, k)
+    ref = oracle.scalar_mul_xyzt(P, k)
+    assert (ctx.compress(out) == oracle.compress(ref)).all()
+    assert oracle.eq_xyzt(out, ref).all()
+    assert list(np.nonzero(ctx.is_identity(out))[0]) == list(np.nonzero(oracle.is_identity(ref))[0])
+    assert ctx.is_identity(out)[[0, 4, 40, 41]].all()
+    m = 64                                                           # a valid extended point: on the curve, XY = ZT
+    c = _fq_ints(oracle, out[:m].reshape(-1, 4))
+    for i in range(m):
+        X, Y, Z, T = c[4 * i:4 * i + 4]
+        assert (X * Y - Z * T) % Q == 0 and (-X * X + Y * Y - Z * Z - 3021 * T * T) % Q == 0 and Z % Q != 0
+    # in place, and the Encoding-form kernel agrees
+    buf = P.copy()
+    ctx.scalar_mul_var_element(buf, k, outs=[buf])
+    assert (buf == out).all()
+    enc_out, st = ctx.scalar_mul_var(oracle.compress(P), k)
+    assert not st.any() and (enc_out == ctx.compress(out)).all()
+    # fixed base
+    gb = ctx.scalar_mul_base_element(k)
+    assert (ctx.compress(gb) == oracle.scalar_mul_base(k)).all()
+    assert oracle.eq_xyzt(gb, oracle.scalar_mul_xyzt(np.tile(oracle.generator_xyzt(), (n, 1)), k)).all()
+    # compress_to_field: the Fq whose bytes are the encoding
+    f = ctx.compress_to_field(P)
+    assert (f == oracle.compress_to_field(P)).all()
+    assert (ctx.fq_to_bytes(f) == oracle.compress(P)).all()
+    # the maps, as Elements: the coordinates the reference formulas give
+    assert (ctx.encode_to_curve_element(r0) == oracle.elligator_map_xyzt(r0)).all()
+    assert (ctx.hash_to_curve_element(r0, r1) == oracle.hash_to_curve_xyzt(r0, r1)).all()
+
+
+def test_element_scalar_mul_full_size(ctx, oracle, torch_mod):
+    """2^20 Elements x scalars on device tensors: same group elements as the Encoding-form kernel (the one the
+    bench measures and the other tests pin to the oracle), a sample against the oracle, and (a + b) P = aP + bP."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    n = 1 << 20
+    g = torch.Generator(device=dev).manual_seed(802)
+    r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    k2 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    P = ctx.double(ctx.encode_to_curve_element(r0))
+    enc = ctx.compress(P)
+    out = ctx.scalar_mul_var_element(P, k)
+    ref, st = ctx.scalar_mul_var(enc, k)
+    torch.cuda.synchronize()
+    assert int(st.sum().item()) == 0 and torch.equal(ctx.compress(out), ref)
+    idx = np.arange(0, n, n // 128)
+    Ph, kh = P.cpu().numpy().view(np.uint64)[idx], k.cpu().numpy()[idx]
+    assert (ref.cpu().numpy()[idx] == oracle.compress(oracle.scalar_mul_xyzt(Ph, kh))).all()
+    ksum, _ = ctx.fr_op("add", k, k2)
+    lhs = ctx.scalar_mul_var_element(P, ksum)
+    rhs = ctx.add(out, ctx.scalar_mul_var_element(P, k2))
+    torch.cuda.synchronize()
+    assert bool(ctx.eq(lhs, rhs).all().item())
+
+
+def test_fr_arithmetic(ctx, oracle, torch_mod):
+    """Fr add / sub / mul / square / neg / inverse (src/fields/fr/u64/wrapper.rs:76-108) and the wide reduction
+    (src/fields/fr.rs:82-94) on 32-byte scalars: host and device paths against the oracle, edge values included."""
+    torch = torch_mod
+    rng = np.random.default_rng(803)
+    n = 1 << 13
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    edges = [0, 1, 2, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1, 1 << 255]
+    for i, v in enumerate(edges):
+        a[i] = ibytes(v)
+        b[len(edges) - 1 - i] = ibytes(v)
+    t = lambda x: torch.from_numpy(x).to("cuda:0")
+    for code, op in enumerate(["add", "sub", "mul", "square", "neg", "inverse"]):
+        m = n if op != "inverse" else 1 << 10                      # the oracle's inversion is slow
+        args = (a[:m], b[:m]) if code <= 2 else (a[:m],)
+        want, wst = oracle.fr_op(code, *args)
+        got, st = ctx.fr_op(op, *args)
+        assert (got == want).all() and (st == wst).all(), op
+        gd, sd = ctx.fr_op(op, *[t(x) for x in args])
+        assert (gd.cpu().numpy() == want).all() and (sd.cpu().numpy() == wst).all(), op
+    assert wst[0] == 1 and not want[0].any()                        # inverse(0): None
+    ai = [int.from_bytes(bytes(x), "little") % R_ORDER for x in a[:256]]
+    inv, _ = ctx.fr_op("inverse", a[:256])
+    assert all(x == 0 or x * int.from_bytes(bytes(y), "little") % R_ORDER == 1 for x, y in zip(ai, inv))
+    for length in (48, 64):
+        d = rng.integers(0, 256, (n, length), dtype=np.uint8)
+        d[0] = 255
+        d[1] = 0
+        want = oracle.fr_from_wide_bytes(d)
+        assert (ctx.fr_from_wide_bytes(d) == want).all()
+        assert (ctx.fr_from_wide_bytes(t(d)).cpu().numpy() == want).all()
+        assert [int.from_bytes(bytes(x), "little") for x in want[:64]] == [int.from_bytes(bytes(x), "little") % R_ORDER for x in d[:64]]
+    with pytest.raises(ValueError):
+        ctx.fr_op("add", a)
+    with pytest.raises(ValueError):
+        ctx.fr_from_wide_bytes(a)
+
+
 def _dev_cases(ctx, oracle, torch, n):
     """name of the _dev export -> (callable on device tensors, callable on host arrays)."""
     rng = np.random.default_rng(703)
@@ -683,6 +798,13 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_fq_from_wide_bytes_dev": lambda f: f.fq_from_wide_bytes,
         "d377_batch_encode_to_curve_wide_dev": lambda f: f.encode_to_curve_wide,
         "d377_batch_fq_op_dev": lambda f: f.fq_op,
+        "d377_batch_scalar_mul_var_element_dev": lambda f: f.scalar_mul_var_element,
+        "d377_batch_scalar_mul_base_element_dev": lambda f: f.scalar_mul_base_element,
+        "d377_batch_compress_to_field_dev": lambda f: f.compress_to_field,
+        "d377_batch_encode_to_curve_element_dev": lambda f: f.encode_to_curve_element,
+        "d377_batch_hash_to_curve_element_dev": lambda f: f.hash_to_curve_element,
+        "d377_batch_fr_op_dev": lambda f: f.fr_op,
+        "d377_batch_fr_from_wide_bytes_dev": lambda f: f.fr_from_wide_bytes,
         "d377_msm_dev": lambda f: f.msm,
         "d377_msm_encoded_dev": lambda f: f.msm,
         "d377_sum_elements_dev": None,
@@ -699,6 +821,11 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_encode_to_curve_wide_dev": [(w48,), (w64,)],
         "d377_batch_fq_op_dev": [("add", a, b), ("sub", a, b), ("mul", a, b), ("square", a), ("neg", a), ("inverse", a)],
         "d377_msm_dev": [(Qp, k)], "d377_msm_encoded_dev": [(raw, k)],
+        "d377_batch_scalar_mul_var_element_dev": [(Qp, k)], "d377_batch_scalar_mul_base_element_dev": [(k,)],
+        "d377_batch_compress_to_field_dev": [(Qp,)], "d377_batch_encode_to_curve_element_dev": [(r0,)],
+        "d377_batch_hash_to_curve_element_dev": [(r0, r1)],
+        "d377_batch_fr_op_dev": [("add", r0, k), ("sub", r0, k), ("mul", r0, k), ("square", r0), ("neg", r0), ("inverse", r0)],
+        "d377_batch_fr_from_wide_bytes_dev": [(w48,), (w64,)],
     }
     return cases, args, t, (P, Qp, raw, k, r0)
 
@@ -778,6 +905,9 @@ def test_sharded_device_path(oracle, torch_mod):
             root, ws = c.sharded("sqrt_ratio_zeta", t(r0), t(r1))
             h_root, h_ws = c.sqrt_ratio_zeta(r0, r1)
             assert _same(root, h_root) and _same(ws, h_ws)
+            el = c.sharded("scalar_mul_var_element", xyzt, t(k))[0]
+            assert _same(el, c.scalar_mul_var_element(xyzt.cpu().numpy().view(np.uint64), k))
+            assert _same(c.sharded("scalar_mul_base_element", t(k))[0], c.scalar_mul_base_element(k))
         c.close()
 
 

@@ -12,6 +12,8 @@ import subprocess
 import numpy as np
 import pytest
 
+R_ORDER = 2111115437357092606062206234695386632838870926408408195193685246394721360383
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM_DIR = os.path.join(ROOT, "tests", "host_sim")
 CSRC = os.path.join(ROOT, "decaf377_amd", "csrc")
@@ -185,6 +187,31 @@ def test_scalar_mul_matches_oracle(sim, oracle, vectors):
     red = np.zeros((n, 32), np.uint8)
     sim.sim_fr_reduce(_p(k), n_(n), _p(red))
     assert (red == oracle.fr_from_bytes_mod_order(k)).all()
+
+
+def test_fr_arithmetic_matches_oracle(sim, oracle):
+    """The scalar-field arithmetic of curve.hpp (word-level Montgomery, what k_fr_op runs) against the oracle's
+    bit-serial restatement, on random and edge operands (0, 1, r - 1, r, 2^256 - 1)."""
+    rng = np.random.default_rng(15)
+    n = 300
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    edges = [0, 1, 2, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1, 1 << 255]
+    for i, v in enumerate(edges):
+        a[i] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+        b[len(edges) - 1 - i] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    out = np.zeros((n, 32), np.uint8)
+    st = np.zeros(n, np.uint8)
+    for op in range(6):
+        sim.sim_fr_op(ctypes.c_int(op), _p(a), _p(b), n_(n), _p(out), _p(st))
+        oo, so = oracle.fr_op(op, a, b if op <= 2 else None)
+        assert (out == oo).all() and (st == so).all(), op
+    for length in (48, 64):
+        d = rng.integers(0, 256, (n, length), dtype=np.uint8)
+        d[0] = 255
+        d[1] = 0
+        sim.sim_fr_from_wide(_p(d), ctypes.c_int(length), n_(n), _p(out))
+        assert (out == oracle.fr_from_wide_bytes(d)).all()
 
 
 def _val(limbs):

@@ -365,3 +365,45 @@ def test_neg_is_identity_fq_ops(oracle):
             assert mont(out[i]) == f(x, y) % m.Q, (op, i)
             assert int(st[i]) == (1 if op == 5 and x == 0 else 0)
         assert all(int.from_bytes(out[i].tobytes(), "little") < m.Q for i in range(64))     # fully reduced limbs
+
+
+def test_fr_arithmetic_against_integers(oracle):
+    """d377o_fr_op / d377o_fr_from_wide_bytes (src/fields/fr/u64/wrapper.rs:76-108, src/fields/fr.rs:82-94)
+    against Python integers mod r, edge operands included."""
+    R = 2111115437357092606062206234695386632838870926408408195193685246394721360383
+    rng = np.random.default_rng(41)
+    n = 256
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for i, v in enumerate([0, 1, R - 1, R, R + 1, (1 << 256) - 1]):
+        a[i] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+        b[5 - i] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    val = lambda row: int.from_bytes(bytes(row), "little")
+    want = [lambda x, y: (x + y) % R, lambda x, y: (x - y) % R, lambda x, y: x * y % R, lambda x, y: x * x % R,
+            lambda x, y: -x % R, lambda x, y: pow(x, -1, R) if x else 0]
+    for op in range(6):
+        out, st = oracle.fr_op(op, a, b if op <= 2 else None)
+        for i in range(n):
+            x, y = val(a[i]) % R, val(b[i]) % R
+            assert val(out[i]) == want[op](x, y), (op, i)
+            assert st[i] == (1 if op == 5 and x == 0 else 0)
+    for length in (48, 64):
+        d = rng.integers(0, 256, (n, length), dtype=np.uint8)
+        d[0] = 255
+        out = oracle.fr_from_wide_bytes(d)
+        assert [val(r) for r in out] == [val(r) % R for r in d]
+    # fr.rs:75-80: FIELD_SIZE_POWER_OF_TWO is 2^256 mod r in Montgomery form
+    limbs = [3987543627614508126, 17742427666091596403, 14557327917022607905, 322810149704226881]
+    assert sum(v << (64 * i) for i, v in enumerate(limbs)) * pow(1 << 256, -1, R) % R == (1 << 256) % R
+
+
+def test_element_form_oracle_entry_points(oracle):
+    """compress_to_field is the encoding read as an Fq (src/min_curve/element.rs:163-187); hash_to_curve as an
+    Element compresses to hash_to_curve's encoding (element.rs:235-240)."""
+    rng = np.random.default_rng(42)
+    r0 = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    r1 = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    P = oracle.elligator_map_xyzt(r0)
+    assert (oracle.fq_to_bytes(oracle.compress_to_field(P)) == oracle.compress(P)).all()
+    assert (oracle.compress(oracle.hash_to_curve_xyzt(r0, r1)) == oracle.hash_to_curve(r0, r1)).all()
+    assert (oracle.hash_to_curve_xyzt(r0, r1) == oracle.add_xyzt(P, oracle.elligator_map_xyzt(r1))).all()

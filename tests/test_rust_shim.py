@@ -88,7 +88,7 @@ def test_wrappers_call_bound_functions_with_right_arity():
     text = re.sub(r"//[^\n]*", "", text)
     h = header_prototypes()
     calls = [(m.group(1), _call_args(text, m.end() - 1)) for m in re.finditer(r"ffi::(d377_[a-z0-9_]+)\(", text)]
-    assert len(calls) >= 35
+    assert len(calls) >= 44
     for name, nargs in calls:
         assert name in h, name
         assert nargs == len(h[name][1]), (name, nargs, len(h[name][1]))
@@ -100,7 +100,10 @@ def test_wrappers_call_bound_functions_with_right_arity():
                  "d377_msm", "d377_msm_encoded", "d377_batch_sqrt_ratio_zeta_ex", "d377_batch_fq_op",
                  "d377_batch_fq_from_wide_bytes", "d377_batch_encode_to_curve_wide", "d377_batch_fq_from_bytes_checked",
                  "d377_batch_fq_to_bytes", "d377_batch_fr_from_le_bytes_mod_order", "d377_batch_fr_from_bytes_checked",
-                 "d377_batch_scalar_mul_var_dev", "d377_msm_dev", "d377_batch_sharded_dev"):
+                 "d377_batch_scalar_mul_var_dev", "d377_msm_dev", "d377_batch_sharded_dev",
+                 "d377_batch_scalar_mul_var_element", "d377_batch_scalar_mul_base_element", "d377_batch_compress_to_field",
+                 "d377_batch_encode_to_curve_element", "d377_batch_hash_to_curve_element", "d377_batch_fr_op",
+                 "d377_batch_fr_from_wide_bytes", "d377_batch_scalar_mul_var_element_dev", "d377_batch_fr_op_dev"):
         assert must in used, must
     # Projective::new_unchecked takes the crate's Fq (src/ark_curve/edwards.rs:21), never its private inner value
     assert ".0 .0" not in text and "new_unchecked(fq_limbs(" in text
