@@ -15,7 +15,9 @@
 //                   super-bucket (128 consecutive buckets) it belongs to; LDS atomics hand out the positions
 //   k_msm_place2    level 2: workgroup (window, super-bucket) spreads its entries over the 128 bucket runs
 //   k_msm_segments  one lane per 32-point segment of a bucket run: mixed additions (7 M each)
-//   k_msm_buckets   one lane per bucket: sum of its segment partials
+//   k_msm_reduce    the same again on the partial sums (groups of 32, up to two more levels): a bucket that holds
+//                   most of the points (many equal scalars) is cut down by 32 per level, not summed by one lane
+//   k_msm_buckets   one lane per bucket: sum of what is left of it (one partial with random scalars)
 //   k_msm_chunks    one lane per 32 consecutive buckets: running-sum trick inside the chunk,
 //                   plus (lo - 1) * (chunk total) by double-and-add:  sum_b b * B_b
 //   k_msm_fold      32-to-1 folds until one point per window
@@ -221,15 +223,17 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digit
 
 // One workgroup per window.  In: blockhist[w][s][b] = points of slice s in bucket b.  Out: blockhist[w][s][b] =
 // position of the first such point in the window's index array; offs[w][0..nb] = exclusive prefix of the bucket
-// sizes (offs[w][nb] = total); segoff[w][0..nb] = the same for the number of SEG-point segments per bucket.
+// sizes (offs[w][nb] = total); segoff[l][w][0..nb], l = 0..REDUCE_LEVELS-1 = the same for ceil(size / SEG^(l+1)): the
+// number of SEG-point segments per bucket, of SEG-segment groups, ... (the levels of the bucket reduction).
 // Buckets are taken 1024 at a time, thread t on bucket chunk + t, so every slice row is read and written coalesced.
-__global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, int nb, int S) {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t part2[1024];
+constexpr int REDUCE_LEVELS = 3;
+__global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, int nb, int S, int W) {
+  __shared__ uint32_t part[1 + REDUCE_LEVELS][1024];
   const int w = blockIdx.x, t = threadIdx.x;
   const int len = nb + 1;
   uint32_t* bh = blockhist + (size_t)w * S * nb;
-  uint32_t carry = 0, carry2 = 0;                                 // totals of the chunks before this one
+  uint32_t carry[1 + REDUCE_LEVELS];                              // totals of the chunks before this one
+  for (int l = 0; l <= REDUCE_LEVELS; ++l) carry[l] = 0;
   for (int chunk = 0; chunk < len; chunk += 1024) {
     const int j = chunk + t;
     uint32_t c = 0;
@@ -239,23 +243,27 @@ __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* blockhist, uint32_t
         bh[(size_t)sl * nb + j] = c;
         c += v;
       }
-    const uint32_t c2 = (c + SEG - 1) / SEG;
-    part[t] = c; part2[t] = c2;
+    uint32_t own[1 + REDUCE_LEVELS];
+    own[0] = c;
+    for (int l = 1; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + SEG - 1) / SEG;
+    for (int l = 0; l <= REDUCE_LEVELS; ++l) part[l][t] = own[l];
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-      uint32_t v = (t >= off) ? part[t - off] : 0u, v2 = (t >= off) ? part2[t - off] : 0u;
+      uint32_t v[1 + REDUCE_LEVELS];
+      for (int l = 0; l <= REDUCE_LEVELS; ++l) v[l] = (t >= off) ? part[l][t - off] : 0u;
       __syncthreads();
-      part[t] += v; part2[t] += v2;
+      for (int l = 0; l <= REDUCE_LEVELS; ++l) part[l][t] += v[l];
       __syncthreads();
     }
-    const uint32_t run = carry + part[t] - c, run2 = carry2 + part2[t] - c2;   // exclusive
+    const uint32_t run = carry[0] + part[0][t] - c;              // exclusive
     if (j < len) {                                                // slot nb is the sentinel: total
       offs[(size_t)w * len + j] = run;
-      segoff[(size_t)w * len + j] = run2;
+      for (int l = 1; l <= REDUCE_LEVELS; ++l)
+        segoff[((size_t)(l - 1) * W + w) * len + j] = carry[l] + part[l][t] - own[l];
     }
     if (j < nb)
       for (int sl = 0; sl < S; ++sl) bh[(size_t)sl * nb + j] += run;           // slice-relative -> absolute position
-    carry += part[1023]; carry2 += part2[1023];
+    for (int l = 0; l <= REDUCE_LEVELS; ++l) carry[l] += part[l][1023];
     __syncthreads();
   }
 }
@@ -317,34 +325,48 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place2(const uint32_t* tmp
   }
 }
 
+// Lane gi of a reduction level -> (window, bucket, group within the bucket) by a short search in that level's
+// prefix sums so[w][0..nb] (W <= 63 windows; groups of a window are contiguous).  False beyond the last group.
+__device__ __forceinline__ bool msm_locate(size_t gi, const uint32_t* so_all, int W, int nb, int* w_out, int* b_out, uint32_t* k_out,
+                                           size_t* base_out) {
+  const int len = nb + 1;
+  size_t base = 0;
+  int w = 0;
+  for (; w < W; ++w) {
+    const uint32_t tot = so_all[(size_t)w * len + nb];
+    if (gi < base + tot) break;
+    base += tot;
+  }
+  if (w == W) return false;
+  const uint32_t local = (uint32_t)(gi - base);
+  const uint32_t* so = so_all + (size_t)w * len;
+  int lo_b = 0, hi_b = nb;                             // largest b with so[b] <= local
+  while (hi_b - lo_b > 1) {
+    const int mid = (lo_b + hi_b) >> 1;
+    if (so[mid] <= local) lo_b = mid; else hi_b = mid;
+  }
+  *w_out = w; *b_out = lo_b; *k_out = local - so[lo_b]; *base_out = base;
+  return true;
+}
+__device__ __forceinline__ size_t msm_window_base(const uint32_t* so_all, int w, int nb) {   // groups of the windows before w
+  size_t base = 0;
+  for (int k = 0; k < w; ++k) base += so_all[(size_t)k * (nb + 1) + nb];
+  return base;
+}
+
 // One lane per SEG-point segment of a bucket run (runs are Poisson-distributed around n / 2^(c-1);
 // one lane per whole bucket left lanes of a wave waiting for the longest run and quantised the
-// grid to ~1.1 residency rounds).  Lane gi finds its (window, bucket, segment) by a short search
-// in the segment prefix sums, adds its <= SEG cached points (next record in flight while the
-// current one is added) and writes one partial sum.
+// grid to ~1.1 residency rounds).  Lane gi finds its (window, bucket, segment), adds its <= SEG cached points
+// (next record in flight while the current one is added) and writes one partial sum.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, const uint32_t* segoff, size_t n, int W,
                int nb, size_t max_segs, uint32_t* partial) {
   const int len = nb + 1;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_segs; gi += (size_t)gridDim.x * BLOCK) {
-    // window: running total of segments per window (W <= 63)
-    size_t base = 0;
-    int w = 0;
-    for (; w < W; ++w) {
-      const uint32_t tot = segoff[(size_t)w * len + nb];
-      if (gi < base + tot) break;
-      base += tot;
-    }
-    if (w == W) break;                                 // beyond the last real segment
-    const uint32_t local = (uint32_t)(gi - base);
-    const uint32_t* so = segoff + (size_t)w * len;
-    int lo_b = 0, hi_b = nb;                           // largest b with so[b] <= local
-    while (hi_b - lo_b > 1) {
-      const int mid = (lo_b + hi_b) >> 1;
-      if (so[mid] <= local) lo_b = mid; else hi_b = mid;
-    }
-    const int b = lo_b;
-    const uint32_t k = local - so[b];
+    int w, b;
+    uint32_t k;
+    size_t base;
+    if (!msm_locate(gi, segoff, W, nb, &w, &b, &k, &base)) break;   // beyond the last real segment
     const uint32_t run_lo = offs[(size_t)w * len + b], run_hi = offs[(size_t)w * len + b + 1];
     uint32_t lo = run_lo + k * SEG, hi = lo + SEG;
     if (hi > run_hi) hi = run_hi;
@@ -367,15 +389,37 @@ k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, c
   }
 }
 
-// one lane per bucket: sum of its (usually <= 5) segment partials
+// A further level of the same reduction: one lane per group of <= SEG partial sums of one bucket (so_in: prefix of
+// the partials per bucket, so_out: of the groups).  With random scalars a bucket has a handful of partials and one
+// level finishes it; with many equal scalars (all coefficients 1, say) a run holds most of the n points, and every
+// level cuts its partials by SEG instead of leaving them to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
+__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, int W, int nb, size_t max_groups, uint32_t* out) {
+  const int len = nb + 1;
+  for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_groups; gi += (size_t)gridDim.x * BLOCK) {
+    int w, b;
+    uint32_t k;
+    size_t base;
+    if (!msm_locate(gi, so_out, W, nb, &w, &b, &k, &base)) break;
+    const size_t in_base = msm_window_base(so_in, w, nb);
+    const uint32_t s0 = so_in[(size_t)w * len + b], s1 = so_in[(size_t)w * len + b + 1];
+    uint32_t lo = s0 + k * SEG, hi = lo + SEG;
+    if (hi > s1) hi = s1;
+    ge acc = ge_identity();
+#pragma unroll 1
+    for (uint32_t j = lo; j < hi; ++j) acc = ge_add(acc, pt_load_ext(in + (in_base + j) * PT_WORDS));
+    pt_store_ext(out + gi * PT_WORDS, acc);
+  }
+}
+
+// one lane per bucket: sum of what the last level left of it (one partial with random scalars)
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_buckets(const uint32_t* partial, const uint32_t* segoff, int W, int nb, uint32_t* buckets) {
   const int len = nb + 1;
   const size_t total = (size_t)W * nb;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < total; gi += (size_t)gridDim.x * BLOCK) {
     const int w = (int)(gi / nb), b = (int)(gi % nb);
-    size_t base = 0;
-    for (int k = 0; k < w; ++k) base += segoff[(size_t)k * len + nb];
+    const size_t base = msm_window_base(segoff, w, nb);
     const uint32_t s0 = segoff[(size_t)w * len + b], s1 = segoff[(size_t)w * len + b + 1];
     ge acc = ge_identity();
 #pragma unroll 1
@@ -563,13 +607,18 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_dig = carve((size_t)W * n * 2);
   const size_t o_bh = carve((size_t)W * S * nb * 4);
   const size_t o_off = carve((size_t)W * (nb + 1) * 4);
-  const size_t o_seg = carve((size_t)W * (nb + 1) * 4);
+  const size_t o_seg = carve((size_t)REDUCE_LEVELS * W * (nb + 1) * 4);
   const size_t max_segs = ((size_t)n * W) / SEG + (size_t)W * nb;      // sum of ceil(run / SEG) never exceeds this
   const size_t o_par = carve(max_segs * PT_WORDS * 4);
   const size_t o_idx = carve((size_t)W * n * 4);
   const size_t o_sub = carve((size_t)W * n);                            // level-1 placement: bucket index within the super-bucket
   static_assert(PT_WORDS >= SEG, "the level-1 index array borrows the segment partials' area");
   const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
+  // further levels of the bucket reduction: groups of SEG partials, then groups of those (never more than this many)
+  const int levels = n <= ((size_t)1 << 11) ? 1 : n <= ((size_t)1 << 16) ? 2 : REDUCE_LEVELS;
+  const size_t max_g2 = max_segs / SEG + (size_t)W * nb, max_g3 = max_g2 / SEG + (size_t)W * nb;
+  const size_t o_r2 = carve(levels >= 2 ? max_g2 * PT_WORDS * 4 : 0);
+  const size_t o_r3 = carve(levels >= 3 ? max_g3 * PT_WORDS * 4 : 0);
   const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
   // ping-pong buffers of the 32-to-1 folds, sized from the fold sequence itself: the first fold writes
   // ceil(nchunks / FOLD) records per window into f0, the second ceil(that / FOLD) into f1, and so on
@@ -614,12 +663,25 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
     }
   }
   hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
-  hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, bh, offs, segoff, nb, S);
+  hipLaunchKernelGGL(k_msm_scan, dim3(W), dim3(1024), 0, s, bh, offs, segoff, nb, S, W);
   hipLaunchKernelGGL(k_msm_place1, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
   hipLaunchKernelGGL(k_msm_place2, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
   hipLaunchKernelGGL(k_msm_segments, dim3(grid_of(d, max_segs)), dim3(BLOCK), 0, s, pts, idx, offs, segoff, n, W, nb,
                      max_segs, partial);
-  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, partial, segoff, W, nb, bkt);
+  const uint32_t* last = partial;                      // what k_msm_buckets finishes, with its prefix array
+  const uint32_t* last_so = segoff;
+  const size_t so_stride = (size_t)W * (nb + 1);
+  if (levels >= 2) {
+    uint32_t* r2 = (uint32_t*)(m + o_r2);
+    hipLaunchKernelGGL(k_msm_reduce, dim3(grid_of(d, max_g2)), dim3(BLOCK), 0, s, last, last_so, segoff + so_stride, W, nb, max_g2, r2);
+    last = r2; last_so = segoff + so_stride;
+  }
+  if (levels >= 3) {
+    uint32_t* r3 = (uint32_t*)(m + o_r3);
+    hipLaunchKernelGGL(k_msm_reduce, dim3(grid_of(d, max_g3)), dim3(BLOCK), 0, s, last, last_so, segoff + 2 * so_stride, W, nb, max_g3, r3);
+    last = r3; last_so = segoff + 2 * so_stride;
+  }
+  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, last, last_so, W, nb, bkt);
   hipLaunchKernelGGL(k_msm_chunks, dim3(grid_of(d, (size_t)W * nchunks)), dim3(BLOCK), 0, s, bkt, W, nb, nchunks, ch);
   // fold chunk results down to one point per window
   const uint32_t* cur_in = ch;

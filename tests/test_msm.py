@@ -87,6 +87,36 @@ def test_msm_affine_and_projective_inputs_mixed(ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [700, 5000, 70000])
+def test_msm_equal_and_few_distinct_scalars(ctx, oracle, n):
+    """Scalars that are all equal (coefficients 1, a common weight) or take a few values put most points of a window
+    into one bucket: the bucket reduction has to stay a tree (k_msm_reduce levels), and the sum has to stay right.
+    n = 70000 crosses into the third level."""
+    rng = np.random.default_rng(705 + n)
+    P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    one = np.zeros((n, 32), np.uint8)
+    one[:, 0] = 1
+    total = P[0:1]
+    for i in range(1, min(n, 5000)):
+        total = oracle.add_xyzt(total, P[i:i + 1])
+    if n <= 5000:
+        assert bytes(ctx.msm(P, one)[0]) == bytes(oracle.compress(total)[0])                  # the plain sum
+    k1 = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    same = np.repeat(k1, n, axis=0)
+    want = ctx.scalar_mul_var(ctx.msm(P, one)[0].reshape(1, 32), k1)[0][0]                     # k * sum P_i
+    assert bytes(ctx.msm(P, same)[0]) == bytes(want)
+    few = np.repeat(rng.integers(0, 256, (3, 32), dtype=np.uint8), (n + 2) // 3, axis=0)[:n]
+    if n <= 5000:
+        assert bytes(ctx.msm(P, few)[0]) == bytes(oracle.msm(P, few)[0])
+    else:
+        parts = [ctx.msm(P[i:i + 10000], few[i:i + 10000])[1].reshape(1, 16) for i in range(0, n, 10000)]
+        acc = parts[0]
+        for q in parts[1:]:
+            acc = ctx.add(acc, q)
+        assert bytes(ctx.msm(P, few)[0]) == bytes(ctx.compress(acc)[0])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("window", [4, 5, 7, 12, 14, 16])
 def test_msm_every_window_width(oracle, window):
     """Same inputs through different bucket widths (developer override) give the same bytes."""
