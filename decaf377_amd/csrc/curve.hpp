@@ -664,7 +664,7 @@ D377_HD ge ge_add_cached(const ge& p, const gec& q, bool neg, bool with_t) {
 // affine cached entry (Z = 1): fixed-base table, 6 M (+1 for T)
 struct gea { fe ypx, ymx, kt; };
 D377_HD ge ge_add_affine(const ge& p, const gea& q, bool neg, bool with_t) {
-  fe a = fe_mul(fe_sub(p.y, p.x), q.ymx);
+  fe a = fe_mul(fe_sub_nc(p.y, p.x), q.ymx);
   fe b = fe_mul(fe_add(p.y, p.x), q.ypx);
   fe c = fe_mul(p.t, q.kt);
   fe d = fe_dbl(p.z);                     // lazy
