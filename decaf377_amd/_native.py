@@ -35,6 +35,8 @@ EXPORTS = [
     "d377_batch_scalar_mul_var_element_dev", "d377_batch_scalar_mul_base_element_dev", "d377_batch_compress_to_field_dev",
     "d377_batch_encode_to_curve_element_dev", "d377_batch_hash_to_curve_element_dev",
     "d377_batch_fr_op", "d377_batch_fr_op_dev", "d377_batch_fr_from_wide_bytes", "d377_batch_fr_from_wide_bytes_dev",
+    "d377_batch_fq_from_bytes_checked_dev", "d377_batch_fq_to_bytes_dev", "d377_batch_fr_from_le_bytes_mod_order_dev",
+    "d377_batch_fr_from_bytes_checked_dev",
 ]
 
 _lib = None
@@ -92,6 +94,10 @@ def load():
         "d377_batch_compress_to_field": [vp, vp, sz, vp],
         "d377_batch_encode_to_curve_element": [vp, vp, sz, vp],
         "d377_batch_hash_to_curve_element": [vp, vp, vp, sz, vp],
+        "d377_batch_fq_from_bytes_checked": [vp, vp, sz, vp, vp],
+        "d377_batch_fq_to_bytes": [vp, vp, sz, vp],
+        "d377_batch_fr_from_le_bytes_mod_order": [vp, vp, sz, vp],
+        "d377_batch_fr_from_bytes_checked": [vp, vp, sz, vp, vp],
     }
     for name, args in host.items():
         getattr(lib, name).argtypes = args

@@ -281,6 +281,54 @@ D377_HD fe fe_from_mont256_words(const uint32_t w[8]) {
   return fe_mul(fe_from_words(w), fe_const(FE_FROM_MONT256));
 }
 
+// ---- records used without conversion ---------------------------------------------------------
+// The eight words of x * 2^256 (a reference Fq in memory), taken as limbs, are the Montgomery-261 form of x * 2^-5.
+// An Element whose four coordinates are all scaled by one factor is the same projective point, and the addition /
+// doubling formulas are homogeneous (degree 2 in each operand), so the element-wise kernels skip the four (eight)
+// conversion products on the way in and fold the accumulated power of two into the constant of the product that
+// writes the record: the words they store are those of the reference formulas on the unscaled coordinates.
+D377_HD void fe_scaled_to_mont256_words(const fe& a, const uint32_t (&c)[NL], uint32_t w[8]) {
+  fe_to_words(fe_reduce_once(fe_mul_strict(a, fe_const(c))), w);
+}
+// q - x on canonical words (x = 0 stays 0); false if x was not canonical (the caller converts the long way then)
+D377_HD bool fq_neg_words(const uint32_t x[8], uint32_t out[8]) {
+  uint32_t nz = 0;
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    nz |= x[i];
+    const uint64_t t = (uint64_t)FQ_MODULUS_W_LIT[i] - x[i] - borrow;
+    out[i] = (uint32_t)t;
+    borrow = (t >> 63) & 1u;
+  }
+  if (nz == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+  }
+  return borrow == 0 && !(nz != 0 && words_geq(x, FQ_MODULUS_W_LIT));
+}
+// (a + b) mod q and (a - b) mod q on canonical words; false if an operand was not canonical
+D377_HD bool fq_addsub_words(const uint32_t a[8], const uint32_t b[8], bool sub, uint32_t out[8]) {
+  const bool ok = !words_geq(a, FQ_MODULUS_W_LIT) && !words_geq(b, FQ_MODULUS_W_LIT);
+  uint32_t bb[8];
+  if (sub) (void)fq_neg_words(b, bb);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) if (!sub) bb[i] = b[i];
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c += (uint64_t)a[i] + bb[i]; out[i] = (uint32_t)c; c >>= 32; }   // < 2q < 2^254
+  if (words_geq(out, FQ_MODULUS_W_LIT)) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t t = (uint64_t)out[i] - FQ_MODULUS_W_LIT[i] - borrow;
+      out[i] = (uint32_t)t;
+      borrow = (t >> 63) & 1u;
+    }
+  }
+  return ok;
+}
+
 // src/sign.rs:11-17
 D377_HD fe fe_abs(const fe& a) { return fe_select(fe_is_negative(a), fe_neg(a), a); }
 
@@ -328,6 +376,31 @@ D377_HD ge ge_neg(const ge& p) {   // src/min_curve/element.rs:324-332
   ge r = p;
   r.x = fe_neg(p.x); r.t = fe_neg(p.t);
   return r;
+}
+// Elements read without conversion (see "records used without conversion" above): coordinates scaled by 2^-5
+D377_HD ge ge_from_raw_words(const uint32_t w[32]) {
+  ge g;
+  g.x = fe_from_words(w); g.y = fe_from_words(w + 8); g.z = fe_from_words(w + 16); g.t = fe_from_words(w + 24);
+  return g;
+}
+// result of ge_add / ge_double on raw operands (coordinates scaled by 2^-20) -> the reference's words
+D377_HD void ge_raw4_to_words(const ge& g, uint32_t w[32]) {
+  fe_scaled_to_mont256_words(g.x, FE_RAW4_TO_MONT256, w);
+  fe_scaled_to_mont256_words(g.y, FE_RAW4_TO_MONT256, w + 8);
+  fe_scaled_to_mont256_words(g.z, FE_RAW4_TO_MONT256, w + 16);
+  fe_scaled_to_mont256_words(g.t, FE_RAW4_TO_MONT256, w + 24);
+}
+// decaf equality x1 * y2 == x2 * y1 (src/min_curve/element.rs:334-340): both sides carry the same scale
+D377_HD bool ge_eq_raw_words(const uint32_t p[32], const uint32_t q[32]) {
+  return fe_eq(fe_mul(fe_from_words(p), fe_from_words(q + 8)), fe_mul(fe_from_words(q), fe_from_words(p + 8)));
+}
+// -P on the record itself: X and T replaced by q - X, q - T.  False if a word string was not canonical.
+D377_HD bool ge_neg_words(const uint32_t p[32], uint32_t out[32]) {
+  bool ok = fq_neg_words(p, out);
+#pragma unroll
+  for (int i = 8; i < 24; ++i) out[i] = p[i];
+  ok = fq_neg_words(p + 24, out + 24) && ok;
+  return ok && !words_geq(p + 8, FQ_MODULUS_W_LIT) && !words_geq(p + 16, FQ_MODULUS_W_LIT);
 }
 D377_HD ge ge_select(bool c, const ge& a, const ge& b) {
   ge r;

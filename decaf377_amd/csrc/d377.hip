@@ -416,20 +416,33 @@ __global__ void __launch_bounds__(BLOCK) k_fq_op(int op, const uint64_t* a, cons
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t w[8];
     load32(ab, i, w);
-    const fe x = fe_from_mont256_words(w);
-    fe y = fe_zero(), r;
-    if (op <= D377_FQ_MUL) { load32(bb, i, w); y = fe_from_mont256_words(w); }
+    uint32_t v[8], o[8];
+    for (int k = 0; k < 8; ++k) v[k] = 0;
+    if (op <= D377_FQ_MUL) load32(bb, i, v);
     uint32_t st = 0;
-    switch (op) {
-      case D377_FQ_ADD: r = fe_carry(fe_add(x, y)); break;
-      case D377_FQ_SUB: r = fe_sub(x, y); break;
-      case D377_FQ_MUL: r = fe_mul(x, y); break;
-      case D377_FQ_SQUARE: r = fe_sqr(x); break;
-      case D377_FQ_NEG: r = fe_neg(x); break;
-      default: r = fe_invert(x); st = fe_is_zero(x) ? 1u : 0u; break;     // 0^(q-2) = 0: zero record, status 1
+    bool done = false;
+    // products: raw limbs carry 2^-5 each (curve.hpp, "records used without conversion"); sums on the words themselves
+    if (op == D377_FQ_MUL || op == D377_FQ_SQUARE) {
+      const fe x = fe_from_words(w);
+      fe_scaled_to_mont256_words(op == D377_FQ_MUL ? fe_mul(x, fe_from_words(v)) : fe_sqr(x), FE_RAW2_TO_MONT256, o);
+      done = true;
+    } else if (op == D377_FQ_ADD || op == D377_FQ_SUB) {
+      done = fq_addsub_words(w, v, op == D377_FQ_SUB, o);
+    } else if (op == D377_FQ_NEG) {
+      done = fq_neg_words(w, o);
     }
-    fe_to_mont256_words(r, w);
-    store32(reinterpret_cast<uint8_t*>(out), i, w);
+    if (!done) {                                          // inverse, or a non-canonical operand: the long way
+      const fe x = fe_from_mont256_words(w);
+      fe r;
+      switch (op) {
+        case D377_FQ_ADD: r = fe_carry(fe_add(x, fe_from_mont256_words(v))); break;
+        case D377_FQ_SUB: r = fe_sub(x, fe_from_mont256_words(v)); break;
+        case D377_FQ_NEG: r = fe_neg(x); break;
+        default: r = fe_invert(x); st = fe_is_zero(x) ? 1u : 0u; break;   // 0^(q-2) = 0: zero record, status 1
+      }
+      fe_to_mont256_words(r, o);
+    }
+    store32(reinterpret_cast<uint8_t*>(out), i, o);
     if (status) status[i] = (uint8_t)st;
   }
 }
@@ -500,27 +513,46 @@ __global__ void __launch_bounds__(BLOCK) k_fr_from_wide(const uint8_t* in, int l
   }
 }
 __global__ void __launch_bounds__(BLOCK) k_neg(const uint64_t* p, size_t n, uint64_t* out) {
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
-    store_ge_mont256(out, i, ge_neg(load_ge_mont256(p, i)));
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t a[32], r[32];
+    load_record128(p, i, a);
+    if (ge_neg_words(a, r)) store_record128(out, i, r);
+    else store_ge_mont256(out, i, ge_neg(load_ge_mont256(p, i)));     // a non-canonical record: reduce it the long way
+  }
 }
 // Element::is_identity: x == 0 (src/min_curve/element.rs:113-117)
 __global__ void __launch_bounds__(BLOCK) k_is_identity(const uint64_t* p, size_t n, uint8_t* out) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
     out[i] = fe_is_zero(load_ge_mont256(p, i).x) ? 1 : 0;
 }
+// add / double / eq / neg read the records without converting them (curve.hpp, "records used without conversion"):
+// these kernels move 256-384 bytes per element and the eight conversion products were most of their time.
 __global__ void __launch_bounds__(BLOCK) k_add(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
-    store_ge_mont256(out, i, ge_add(load_ge_mont256(p, i), load_ge_mont256(q, i)));
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t a[32], b[32];
+    load_record128(p, i, a);
+    load_record128(q, i, b);
+    ge_raw4_to_words(ge_add(ge_from_raw_words(a), ge_from_raw_words(b)), a);
+    store_record128(out, i, a);
+  }
 }
 __global__ void __launch_bounds__(BLOCK) k_double(const uint64_t* p, size_t n, uint64_t* out) {
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
-    store_ge_mont256(out, i, ge_double(load_ge_mont256(p, i)));
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t a[32];
+    load_record128(p, i, a);
+    ge_raw4_to_words(ge_double(ge_from_raw_words(a)), a);
+    store_record128(out, i, a);
+  }
 }
 // decaf equality: x1 * y2 == x2 * y1  (src/min_curve/element.rs:334-340)
 __global__ void __launch_bounds__(BLOCK) k_eq(const uint64_t* p, const uint64_t* q, size_t n, uint8_t* eq) {
+  const uint8_t* pb = reinterpret_cast<const uint8_t*>(p);
+  const uint8_t* qb = reinterpret_cast<const uint8_t*>(q);
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    const ge a = load_ge_mont256(p, i), b = load_ge_mont256(q, i);
-    eq[i] = fe_eq(fe_mul(a.x, b.y), fe_mul(b.x, a.y)) ? 1 : 0;
+    uint32_t a[32], b[32];                               // only X and Y are read
+    load32(pb, 4 * i + 0, a); load32(pb, 4 * i + 1, a + 8);
+    load32(qb, 4 * i + 0, b); load32(qb, 4 * i + 1, b + 8);
+    eq[i] = ge_eq_raw_words(a, b) ? 1 : 0;
   }
 }
 
@@ -1130,6 +1162,21 @@ int d377_batch_fr_from_le_bytes_mod_order(d377_ctx* ctx, const uint8_t* bytes32,
 }
 int d377_batch_fr_from_bytes_checked(d377_ctx* ctx, const uint8_t* bytes32, size_t n, uint8_t* fr32_out, uint8_t* status) {
   return run_host(ctx, OP_FR_CHECKED, 0, bytes32, nullptr, n, fr32_out, status);
+}
+int d377_batch_fq_from_bytes_checked_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes32, size_t n, uint64_t* out,
+                                         uint8_t* status) {
+  return run_dev(ctx, dev, stream, OP_FQ_CHECKED, 0, bytes32, nullptr, n, out, status);
+}
+int d377_batch_fq_to_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* a, size_t n, uint8_t* bytes32) {
+  return run_dev(ctx, dev, stream, OP_FQ_TO_BYTES, 0, a, nullptr, n, bytes32, nullptr);
+}
+int d377_batch_fr_from_le_bytes_mod_order_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes32, size_t n,
+                                              uint8_t* fr32_out) {
+  return run_dev(ctx, dev, stream, OP_FR_MOD, 0, bytes32, nullptr, n, fr32_out, nullptr);
+}
+int d377_batch_fr_from_bytes_checked_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes32, size_t n, uint8_t* fr32_out,
+                                         uint8_t* status) {
+  return run_dev(ctx, dev, stream, OP_FR_CHECKED, 0, bytes32, nullptr, n, fr32_out, status);
 }
 int d377_batch_fr_op(d377_ctx* ctx, int op, const uint8_t* a32, const uint8_t* b32, size_t n, uint8_t* out32, uint8_t* status) {
   if (op < D377_FQ_ADD || op > D377_FQ_INVERSE) return fail(D377_ERR_ARG, "%s", "unknown Fr operation");

@@ -52,6 +52,15 @@ __device__ __forceinline__ ge load_ge_mont256(const uint64_t* xyzt, size_t i) {
   return g;
 }
 
+__device__ __forceinline__ void load_record128(const uint64_t* xyzt, size_t i, uint32_t w[32]) {
+  const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
+  load32(b, 4 * i + 0, w); load32(b, 4 * i + 1, w + 8); load32(b, 4 * i + 2, w + 16); load32(b, 4 * i + 3, w + 24);
+}
+__device__ __forceinline__ void store_record128(uint64_t* xyzt, size_t i, const uint32_t w[32]) {
+  uint8_t* b = reinterpret_cast<uint8_t*>(xyzt);
+  store32(b, 4 * i + 0, w); store32(b, 4 * i + 1, w + 8); store32(b, 4 * i + 2, w + 16); store32(b, 4 * i + 3, w + 24);
+}
+
 __device__ __forceinline__ void slot_store(uint32_t* p, const fe& v) {
   uint4* q = reinterpret_cast<uint4*>(p);
   q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);

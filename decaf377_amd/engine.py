@@ -258,25 +258,13 @@ class Context:
 
 
     # -- Fr byte handling ---------------------------------------------------------------------------
-    def fr_from_le_bytes_mod_order(self, bytes32):
+    def fr_from_le_bytes_mod_order(self, bytes32, outs=None):
         """Fr::from_le_bytes_mod_order on [n, 32] byte strings -> canonical [n, 32] (src/fields/fr.rs:82-94)."""
-        b = np.ascontiguousarray(bytes32, dtype=np.uint8)
-        _check(b, ENC, _rows(b), "fr_from_le_bytes_mod_order input")
-        out = np.empty_like(b)
-        _native.check(self._lib.d377_batch_fr_from_le_bytes_mod_order(
-            self._h, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b.shape[0]), out.ctypes.data_as(ctypes.c_void_p)))
-        return out
+        return self._run("d377_batch_fr_from_le_bytes_mod_order", [bytes32], [ENC], [ENC], outs)[0]
 
-    def fr_from_bytes_checked(self, bytes32):
-        """Fr::from_bytes_checked (src/fields/fr.rs:100-107) -> ([n, 32], status[n])."""
-        b = np.ascontiguousarray(bytes32, dtype=np.uint8)
-        _check(b, ENC, _rows(b), "fr_from_bytes_checked input")
-        out = np.empty_like(b)
-        st = np.zeros(max(b.shape[0], 1), np.uint8)
-        _native.check(self._lib.d377_batch_fr_from_bytes_checked(
-            self._h, b.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(b.shape[0]),
-            out.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p)))
-        return out, st[:b.shape[0]]
+    def fr_from_bytes_checked(self, bytes32, outs=None):
+        """Fr::from_bytes_checked (src/fields/fr.rs:100-107) -> ([n, 32], status[n]); a rejected record is all-zero."""
+        return self._run("d377_batch_fr_from_bytes_checked", [bytes32], [ENC], [ENC, FLAG], outs)
 
     def fr_op(self, op, a32, b32=None, outs=None):
         """Fr add/sub/mul (binary) and square/neg/inverse (unary) on [n, 32] little-endian scalars

@@ -244,6 +244,13 @@ int d377_batch_encode_to_curve_element_dev(d377_ctx* ctx, int dev, void* stream,
                                            uint64_t* out_xyzt);
 int d377_batch_hash_to_curve_element_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* r1_32,
                                          const uint8_t* r2_32, size_t n, uint64_t* out_xyzt);
+int d377_batch_fq_from_bytes_checked_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes32, size_t n,
+                                         uint64_t* out, uint8_t* status);
+int d377_batch_fq_to_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* a, size_t n, uint8_t* bytes32);
+int d377_batch_fr_from_le_bytes_mod_order_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes32, size_t n,
+                                              uint8_t* fr32_out);
+int d377_batch_fr_from_bytes_checked_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes32, size_t n,
+                                         uint8_t* fr32_out, uint8_t* status);
 int d377_batch_fr_op_dev(d377_ctx* ctx, int dev, void* stream, int op, const uint8_t* a32, const uint8_t* b32, size_t n,
                          uint8_t* out32, uint8_t* status);
 int d377_batch_fr_from_wide_bytes_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* bytes, size_t len,

@@ -167,6 +167,25 @@ void sim_group_misc(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* su
     (void)fe_invert(a.z);
   }
 }
+// the element-wise kernels' conversion-free forms (k_add, k_double, k_eq, k_neg, k_fq_op in d377.hip)
+void sim_raw_forms(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* sum, uint32_t* dbl, uint32_t* neg, uint8_t* eq,
+                   uint8_t* neg_ok, uint32_t* fmul, uint32_t* fsqr, uint32_t* fadd, uint32_t* fsub, uint32_t* fneg, uint8_t* f_ok) {
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t* a = p + 32 * i;
+    const uint32_t* b = q + 32 * i;
+    ge_raw4_to_words(ge_add(ge_from_raw_words(a), ge_from_raw_words(b)), sum + 32 * i);
+    ge_raw4_to_words(ge_double(ge_from_raw_words(a)), dbl + 32 * i);
+    neg_ok[i] = ge_neg_words(a, neg + 32 * i) ? 1 : 0;
+    eq[i] = ge_eq_raw_words(a, b) ? 1 : 0;
+    // field ops on the X words of the two records
+    fe_scaled_to_mont256_words(fe_mul(fe_from_words(a), fe_from_words(b)), FE_RAW2_TO_MONT256, fmul + 8 * i);
+    fe_scaled_to_mont256_words(fe_sqr(fe_from_words(a)), FE_RAW2_TO_MONT256, fsqr + 8 * i);
+    bool ok = fq_addsub_words(a, b, false, fadd + 8 * i);
+    ok = fq_addsub_words(a, b, true, fsub + 8 * i) && ok;
+    ok = fq_neg_words(a, fneg + 8 * i) && ok;
+    f_ok[i] = ok ? 1 : 0;
+  }
+}
 void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
     RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);

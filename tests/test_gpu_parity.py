@@ -805,6 +805,10 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_hash_to_curve_element_dev": lambda f: f.hash_to_curve_element,
         "d377_batch_fr_op_dev": lambda f: f.fr_op,
         "d377_batch_fr_from_wide_bytes_dev": lambda f: f.fr_from_wide_bytes,
+        "d377_batch_fq_from_bytes_checked_dev": lambda f: f.fq_from_bytes_checked,
+        "d377_batch_fq_to_bytes_dev": lambda f: f.fq_to_bytes,
+        "d377_batch_fr_from_le_bytes_mod_order_dev": lambda f: f.fr_from_le_bytes_mod_order,
+        "d377_batch_fr_from_bytes_checked_dev": lambda f: f.fr_from_bytes_checked,
         "d377_msm_dev": lambda f: f.msm,
         "d377_msm_encoded_dev": lambda f: f.msm,
         "d377_sum_elements_dev": None,
@@ -826,6 +830,8 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_hash_to_curve_element_dev": [(r0, r1)],
         "d377_batch_fr_op_dev": [("add", r0, k), ("sub", r0, k), ("mul", r0, k), ("square", r0), ("neg", r0), ("inverse", r0)],
         "d377_batch_fr_from_wide_bytes_dev": [(w48,), (w64,)],
+        "d377_batch_fq_from_bytes_checked_dev": [(k,)], "d377_batch_fq_to_bytes_dev": [(a,)],
+        "d377_batch_fr_from_le_bytes_mod_order_dev": [(k,)], "d377_batch_fr_from_bytes_checked_dev": [(k,)],
     }
     return cases, args, t, (P, Qp, raw, k, r0)
 

@@ -214,6 +214,41 @@ def test_fr_arithmetic_matches_oracle(sim, oracle):
         assert (out == oracle.fr_from_wide_bytes(d)).all()
 
 
+def test_conversion_free_forms_match_oracle(sim, oracle):
+    """k_add / k_double / k_eq / k_neg / k_fq_op read Montgomery-256 records without converting them (the words,
+    taken as limbs, are the value scaled by 2^-5) and fold the scale into the product that writes the result:
+    the words they store must still be the reference formulas' (oracle add / double / neg / eq, Fq ops), identity
+    and zero coordinates included; a non-canonical word string is reported, not mis-negated."""
+    rng = np.random.default_rng(16)
+    n = 64
+    P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    Q2 = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    P[0] = oracle.identity_xyzt()
+    Q2[1] = oracle.identity_xyzt()
+    Q2[2] = P[2]
+    Q2[3] = oracle.add_xyzt(P[3:4], P[3:4])[0]
+    Q2[4] = oracle.neg_xyzt(P[4:5])[0]
+    z = lambda *shape: np.zeros(shape, np.uint64)
+    s_, d_, ng = z(n, 16), z(n, 16), z(n, 16)
+    fm, fs, fa, fb, fn = z(n, 4), z(n, 4), z(n, 4), z(n, 4), z(n, 4)
+    eq, nok, fok = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    sim.sim_raw_forms(_p(P), _p(Q2), n_(n), _p(s_), _p(d_), _p(ng), _p(eq), _p(nok), _p(fm), _p(fs), _p(fa), _p(fb), _p(fn), _p(fok))
+    assert (s_ == oracle.add_xyzt(P, Q2)).all()
+    assert (d_ == oracle.double_xyzt(P)).all()
+    assert (ng == oracle.neg_xyzt(P)).all() and nok.all() and fok.all()
+    assert (eq == oracle.eq_xyzt(P, Q2)).all() and eq[2] == 1 and eq[0] == 0
+    # the field ops take the X words of the two records (rows of 16 u64: X is the first four)
+    a, b = np.ascontiguousarray(P[:, :4]), np.ascontiguousarray(Q2[:, :4])
+    for got, op in ((fa, 0), (fb, 1), (fm, 2), (fs, 3), (fn, 4)):
+        assert (got == oracle.fq_op(op, a, b if op <= 2 else None)[0]).all(), op
+    # a non-canonical X (q + 5 as words): the word-level forms decline
+    bad = P.copy()
+    q = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+    bad[0, :4] = np.frombuffer(int(q + 5).to_bytes(32, "little"), np.uint64)
+    sim.sim_raw_forms(_p(bad), _p(Q2), n_(1), _p(s_), _p(d_), _p(ng), _p(eq), _p(nok), _p(fm), _p(fs), _p(fa), _p(fb), _p(fn), _p(fok))
+    assert nok[0] == 0 and fok[0] == 0
+
+
 def _val(limbs):
     return sum(int(v) << (29 * i) for i, v in enumerate(limbs))
 
@@ -324,6 +359,11 @@ L.sim_scalar_mul_var(p(enc), p(k), n_(n), p(out), p(st))
 L.sim_scalar_mul_base(p(k), n_(n), p(out))
 L.sim_double_variants(p(xyzt), n_(n), p(x2), p(a), p(b))
 L.sim_group_misc(p(xyzt), p(x2), n_(n), p(a), p(b))
+f = [np.zeros((n, 4), np.uint64) for _ in range(5)]
+fl = [np.zeros(n, np.uint8) for _ in range(3)]
+full = np.full((n, 16), 0xFFFFFFFFFFFFFFFF, np.uint64)      # every word string the conversion-free forms may be handed
+for u, v in ((xyzt, x2), (full, full)):
+    L.sim_raw_forms(p(u), p(v), n_(n), p(a), p(b), p(np.zeros((n, 16), np.uint64)), p(fl[0]), p(fl[1]), p(f[0]), p(f[1]), p(f[2]), p(f[3]), p(f[4]), p(fl[2]))
 w = np.zeros((n, 4), np.uint64)
 L.sim_fq_mul(p(xyzt), p(x2), n_(n), p(w)); L.sim_fq_sub(p(xyzt), p(x2), n_(n), p(w)); L.sim_fq_add(p(xyzt), p(x2), n_(n), p(w))
 print("BOUNDS_OK")
