@@ -477,8 +477,9 @@ D377_HD void ge_compress(const SqrtTables& T, PT& pt, const ge& p, uint32_t w[8]
 }
 
 // Element::elligator_map, src/ark_curve/elligator.rs:15-62.  r0 in Montgomery-261.
+// First half: the point (s, t) of the Jacobi quartic t^2 = (1 + a s^2)^2 - 4 d s^2 (elligator.rs:20-45).
 template <class PT>
-D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0) {
+D377_HD void ge_elligator_st(const SqrtTables& T, PT& pt, const fe& r0, fe* s_out, fe* t_out) {
   const fe one = fe_const(FE_ONE), dma = fe_const(FE_D_MINUS_A), dd = fe_const(FE_D);
   fe r = fe_mul(fe_const(FE_ZETA), fe_sqr(r0));                                   // :20
   fe den = fe_mul(fe_sub(fe_mul(dd, r), dma), fe_sub(fe_mul(dma, r), dd));        // :22
@@ -488,14 +489,26 @@ D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0) {
   isri = fe_select(iss, isri, fe_mul(isri, r0));                                  // twiddle, :28-38
   fe s = fe_mul(isri, num);                                                       // :40
   fe p = fe_mul(fe_mul(fe_mul(isri, s), fe_sub(r, one)), fe_const(FE_A_MINUS_2D_SQ));
-  fe t = fe_sub(fe_select(iss, fe_neg(p), p), one);                               // :41  (-sgn * ... - 1)
+  *t_out = fe_sub(fe_select(iss, fe_neg(p), p), one);                             // :41  (-sgn * ... - 1)
   if (fe_is_negative(s) == iss) s = fe_neg(s);                                    // :43-45
+  *s_out = s;
+}
+// Second half: the isogeny to the Edwards curve (elligator.rs:48-59)
+D377_HD ge ge_from_jacobi_st(const fe& s, const fe& t) {
+  const fe one = fe_const(FE_ONE);
   fe e = fe_dbl(s);                                                               // :48
   fe ss = fe_sqr(s);
   fe f = fe_sub(one, ss);                                                         // 1 + a s^2, a = -1
   fe g = fe_add(one, ss);                                                         // 1 - a s^2
   ge o;
   o.x = fe_mul(e, t); o.y = fe_mul(f, g); o.z = fe_mul(f, t); o.t = fe_mul(e, g); // :52-54
+  return o;
+}
+template <class PT>
+D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0) {
+  fe s, t;
+  ge_elligator_st(T, pt, r0, &s, &t);
+  ge o = ge_from_jacobi_st(s, t);
   D377_INVARIANT(T, o, true);                                                     // :56-59
   return o;
 }
@@ -755,8 +768,9 @@ D377_HD ge ge_add_affine(const ge& p, const gea& q, bool neg, bool with_t) {
 // [k]P with signed 4-bit windows, MSB first: 63 x (4 doublings + 1 cached addition).
 // `Tab` holds the per-lane table of cached 0..8 * P (global scratch on the GPU): it provides
 // store(j, gec) and load(j, swap) -> gec, where swap exchanges ypx / ymx (negative digit).
+// want_t: whether the caller uses T of the result (the square-root-free compressor does not).
 template <class Tab>
-D377_HD ge ge_scalar_mul_w4(const ge& p, const uint32_t digits[8], Tab& tab) {
+D377_HD ge ge_scalar_mul_w4(const ge& p, const uint32_t digits[8], Tab& tab, bool want_t = true) {
   {
     gec id;
     id.ypx = fe_const(FE_ONE); id.ymx = fe_const(FE_ONE); id.z2 = fe_dbl(fe_const(FE_ONE)); id.kt = fe_zero();
@@ -782,7 +796,7 @@ D377_HD ge ge_scalar_mul_w4(const ge& p, const uint32_t digits[8], Tab& tab) {
     const gec e = tab.load(neg ? -d : d, neg);
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) r = ge_double_neg(r, j == 3);   // (-2)^4 = 16
-    r = ge_add_cached(r, e, neg, i == 0);       // only the compressor needs the last T
+    r = ge_add_cached(r, e, neg, want_t && i == 0);   // only the last T can have a reader
   }
   return r;
 }
@@ -810,21 +824,34 @@ constexpr int FB_BITS = D377_FB_BITS;
 constexpr int FB_WINDOWS = (FB_BITS == 8) ? 32 : 252 / FB_BITS;
 constexpr int FB_ENTRIES = (1 << (FB_BITS - 1)) + 1;
 static_assert(FB_BITS == 8 || 252 % FB_BITS == 0, "window width must tile the 252 scalar bits");
+// signed digit i of k (FB_BITS wide), with the running carry of the recoding
+D377_HD int fb_digit(const uint32_t k[8], int i, uint32_t& carry) {
+  const int bit = FB_BITS * i, wi = bit >> 5, sh = bit & 31;
+  uint32_t v = k[wi] >> sh;
+  if (sh + FB_BITS > 32 && wi + 1 < 8) v |= k[wi + 1] << (32 - sh);
+  const uint32_t dd = (v & ((1u << FB_BITS) - 1u)) + carry;
+  carry = (dd >= (1u << (FB_BITS - 1))) ? 1u : 0u;        // k < r < 2^251: the top digit never carries out
+  return (int)dd - (int)(carry << FB_BITS);
+}
+// want_t: whether the caller reads T of the result.  The entry of window i + 1 is fetched before the addition of
+// window i: the table (6.2 MB) lives in L2 / Infinity Cache, and one mixed addition is only ~1 500 instructions.
 template <class FTab>
-D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab) {
+D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab, bool want_t = true) {
   ge r = ge_identity();
   uint32_t carry = 0;
+  int d = fb_digit(k, 0, carry);
+  bool neg = d < 0;
+  gea e = ftab.load(0, neg ? -d : d, neg);
 #pragma unroll 1
   for (int i = 0; i < FB_WINDOWS; ++i) {
-    const int bit = FB_BITS * i, wi = bit >> 5, sh = bit & 31;
-    uint32_t v = k[wi] >> sh;
-    if (sh + FB_BITS > 32 && wi + 1 < 8) v |= k[wi + 1] << (32 - sh);
-    uint32_t dd = (v & ((1u << FB_BITS) - 1u)) + carry;
-    carry = (dd >= (1u << (FB_BITS - 1))) ? 1u : 0u;      // k < r < 2^251: the top digit never carries out
-    const int d = (int)dd - (int)(carry << FB_BITS);
-    const bool neg = d < 0;
-    const gea e = ftab.load(i, neg ? -d : d, neg);
-    r = ge_add_affine(r, e, neg, true);
+    const gea cur = e;
+    const bool neg_cur = neg;
+    if (i + 1 < FB_WINDOWS) {
+      d = fb_digit(k, i + 1, carry);
+      neg = d < 0;
+      e = ftab.load(i + 1, neg ? -d : d, neg);
+    }
+    r = ge_add_affine(r, cur, neg_cur, want_t || i + 1 < FB_WINDOWS);
   }
   return r;
 }
@@ -844,6 +871,122 @@ D377_HD fe fe_invert(const fe& x) {
   const uint32_t ee[8] = {0xFFFFFFFFu, FQ_MODULUS_W_LIT[1] - 1u, FQ_MODULUS_W_LIT[2], FQ_MODULUS_W_LIT[3],
                           FQ_MODULUS_W_LIT[4], FQ_MODULUS_W_LIT[5], FQ_MODULUS_W_LIT[6], FQ_MODULUS_W_LIT[7]};
   return fe_pow_words(x, ee);
+}
+
+// x^(q-2) from the two fixed exponentiations of the square root: q - 2 = 2^47 (m - 1) + (2^47 - 1), so
+// 1/x = (x^((m-1)/2))^(2^48) * x^(2^47 - 1): 296 S + 53 M against 256 S + ~128 M for the plain ladder.
+template <class PT>
+D377_HD fe fe_invert_chain(const fe& x, PT& pt) {
+  return fe_mul(fe_sqr_n(fe_pow_m12(x, pt), 48), fe_pow_2_47_m1(x));
+}
+
+// k / 2 mod r for canonical k < r (r odd): (k + r) / 2 when k is odd
+D377_HD void fr_half_words(uint32_t k[8]) {
+  const uint32_t odd = k[0] & 1u;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c += (uint64_t)k[i] + (odd ? FR_ORDER_W_LIT[i] : 0u); k[i] = (uint32_t)c; c >>= 32; }   // < 2r < 2^252
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = (k[i] >> 1) | (i < 7 ? (k[i + 1] << 31) : 0u);
+}
+
+// ---- compression without a square root, batched ------------------------------------------------
+// Element::vartime_compress (src/ark_curve/encoding.rs:91-128) takes v = 1/sqrt(u1 (a-d) X^2), u1 = X^2 - T^2.
+// When the point is known as an image of the decaf isogeny,
+//     P = (E F : G H : F G : E H)   with   F^2 - H^2 = -(1 + d) E^2,
+// that argument is the perfect square ((1 + d) E^3 F)^2 and the steps of encoding.rs:97-110 collapse to
+//     s = | (sigma G - H) / E |,   sigma = +1 if E / F is non-negative, -1 otherwise
+// (u2 = |v u1| = |E / F|, u3 = u2 Z - T = E (sigma G - H), s = |(a-d) v u3 X|; the two |.| absorb the sign of
+// the root, so either root gives the reference's bytes).  Both producers on the hot path have that shape:
+//   * a doubling P = [2]R, R = (X0 : Y0 : Z0):  E = 2 X0 Y0, G = Y0^2 - X0^2, H = -(X0^2 + Y0^2), F = G - 2 Z0^2,
+//     so s = |Y0 / X0| or |X0 / Y0| -- a scalar multiplication [k]P is computed as [2]([k/2 mod r]P);
+//   * the Elligator map (elligator.rs:48-54): (E, F, G, H) = (2s, t, 1 - s^2, 1 + s^2), so s_out = |s| or |1/s|.
+// What is left is ONE inversion per element, and inversions batch (Montgomery's trick) where square roots do
+// not: a lane collects the states of its next DCB_K elements and inverts once for all of them.
+// State of one element: enc = | (is_negative(w / p) ? n1 : n0) / p |; p = 0 (the identity's X = 0, where the
+// reference's sqrt_ratio_zeta(1, 0) returns 0 and the encoding is 0) and failed lanes are stored as
+// p = 1, n0 = n1 = 0.  All four values are strict products (tight limbs, < 2q) and travel as 32-byte records.
+constexpr int DCB_K = 32;               // elements per lane per inversion
+#if defined(D377_CHECK_INVARIANTS)
+constexpr bool DCB_WANT_T = true;       // the debug assertions re-check T Z = X Y on the half point
+#else
+constexpr bool DCB_WANT_T = false;      // the state of a doubling does not read T
+#endif
+struct dcb_state { fe p, w, n0, n1; };
+
+D377_HD dcb_state dcb_neutral() {
+  dcb_state st;
+  st.p = fe_const(FE_ONE); st.w = fe_zero(); st.n0 = fe_zero(); st.n1 = fe_zero();
+  return st;
+}
+D377_HD dcb_state dcb_guard_zero(dcb_state st, bool dead) {
+  const bool z = dead || fe_strict_is_zero(st.p);
+  const dcb_state nt = dcb_neutral();
+  st.p = fe_select(z, nt.p, st.p); st.w = fe_select(z, nt.w, st.w);
+  st.n0 = fe_select(z, nt.n0, st.n0); st.n1 = fe_select(z, nt.n1, st.n1);
+  return st;
+}
+// state of [2]R (T of R is not used)
+D377_HD dcb_state ge_dcb_from_half(const ge& r, bool dead) {
+  const fe a = fe_sqr(r.x), b = fe_sqr(r.y), c = fe_sqr2x(r.z);
+  const fe f = fe_sub(b, fe_add(a, c));                 // F = Y0^2 - X0^2 - 2 Z0^2
+  const fe q = fe_mul(r.x, r.y);                        // E / 2
+  dcb_state st;
+  st.p = fe_mul_strict(q, f);                           // E F / 2
+  st.w = fe_mul_strict(q, fe_dbl(q));                   // w / p = 2 q / F = E / F
+  st.n0 = fe_mul_strict(b, f);                          // n0 / p = Y0^2 / (X0 Y0)
+  st.n1 = fe_mul_strict(a, f);                          // n1 / p = X0^2 / (X0 Y0)
+  return dcb_guard_zero(st, dead);
+}
+// state of the Elligator point of (s, t)
+D377_HD dcb_state ge_dcb_from_jacobi_st(const fe& s_in, const fe& t) {
+  const fe s = fe_mul_strict(s_in, fe_const(FE_ONE));   // same value below 1.1 q: keeps p below 2q for the zero test
+  dcb_state st;
+  st.p = fe_mul_strict(s, t);                           // E F / 2
+  st.w = fe_mul_strict(s, fe_dbl(s));                   // w / p = 2 s / t
+  st.n0 = fe_mul_strict(s, st.p);                       // n0 / p = s
+  st.n1 = fe_mul_strict(t, fe_const(FE_ONE));           // n1 / p = 1 / s
+  return dcb_guard_zero(st, false);
+}
+// IO: where a lane keeps the states of its current round and where results go --
+//   get(slot, j, w) / put(slot, j, w): 32-byte record `slot` (0 p, 1 w, 2 n0, 3 n1) of the round's j-th element;
+//   park(j, w) / parked(j, w): a 32-byte place per element that is free until its result is written (the output
+//   record itself); emit(j, w): the element's encoding.
+template <class IO>
+D377_HD void dcb_put(IO& io, int j, const dcb_state& st) {
+  uint32_t w[8];
+  fe_to_words(st.p, w); io.put(0, j, w);
+  fe_to_words(st.w, w); io.put(1, j, w);
+  fe_to_words(st.n0, w); io.put(2, j, w);
+  fe_to_words(st.n1, w); io.put(3, j, w);
+}
+template <class PT, class IO>
+D377_HD void dcb_finish(PT& pt, IO& io, int cnt) {
+  if (cnt <= 0) return;
+  uint32_t w[8];
+  fe c = fe_const(FE_ONE);
+#pragma unroll 1
+  for (int j = 0; j < cnt; ++j) {                       // prefix products, parked in the output records
+    fe_to_words(c, w);
+    io.park(j, w);
+    io.get(0, j, w);
+    c = fe_mul_strict(c, fe_from_words(w));
+  }
+  fe inv = fe_invert_chain(c, pt);
+#pragma unroll 1
+  for (int j = cnt - 1; j >= 0; --j) {
+    io.parked(j, w);
+    const fe inv_j = fe_mul(inv, fe_from_words(w));     // 1 / p_j
+    io.get(0, j, w);
+    inv = fe_mul(inv, fe_from_words(w));
+    io.get(1, j, w);
+    const bool neg = fe_is_negative(fe_mul(fe_from_words(w), inv_j));     // sign of E / F (encoding.rs:104)
+    io.get(neg ? 3 : 2, j, w);
+    fe s = fe_canon(fe_mul(fe_from_words(w), inv_j));
+    s = fe_select((s.l[0] & 1u) != 0, fe_canon_negate(s), s);             // .abs(), encoding.rs:110
+    fe_to_words(s, w);
+    io.emit(j, w);
+  }
 }
 
 }  // namespace d377

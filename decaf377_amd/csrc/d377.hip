@@ -62,6 +62,21 @@ struct FixedTab {
   }
 };
 
+// Round storage of the square-root-free compressor (curve.hpp, dcb_finish): [4 slots][DCB_K][lanes] 32-byte
+// records in global scratch, so that a wave reads and writes 2 KiB contiguous; the prefix products of the
+// batched inversion are parked in the output records of the elements they belong to.
+struct DcbIO {
+  uint8_t* scratch;
+  uint8_t* out32;
+  size_t nthreads, tid, base;           // the round's j-th element is record base + j * nthreads
+  __device__ __forceinline__ size_t rec(int slot, int j) const { return (size_t)(slot * DCB_K + j) * nthreads + tid; }
+  __device__ __forceinline__ void put(int slot, int j, const uint32_t w[8]) { store32(scratch, rec(slot, j), w); }
+  __device__ __forceinline__ void get(int slot, int j, uint32_t w[8]) const { load32(scratch, rec(slot, j), w); }
+  __device__ __forceinline__ void park(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * nthreads, w); }
+  __device__ __forceinline__ void parked(int j, uint32_t w[8]) const { load32(out32, base + (size_t)j * nthreads, w); }
+  __device__ __forceinline__ void emit(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * nthreads, w); }
+};
+
 // ------------------------------------------------------------------------- init kernels ---
 __device__ fe fe_pow_u32(const fe& x, uint32_t e) {   // e >= 1
   int top = 31 - __clz((int)e);
@@ -210,15 +225,29 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_roundtrip(SqrtTables 
   }
 }
 
+// The kernels below end in an encoding of a point whose isogeny preimage they know (a doubling, or the Elligator
+// map's (s, t)): they run on the persistent grid (<= 2 blocks per CU), each lane takes its elements in rounds of
+// DCB_K, leaves the four 32-byte state records of each in `dcb`, and finishes the round with one inversion.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtTables T, const uint8_t* fq32, size_t n,
-                                                           uint8_t* out32) {
+                                                           uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t w[8];
-    load32(fq32, i, w);
-    ge g = ge_elligator_map(T, pt, fe_from_words_mod_order(w));
-    ge_compress(T, pt, g, w);
-    store32(out32, i, w);
+  DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
+  for (size_t base = io.tid; base < n; base += (size_t)DCB_K * io.nthreads) {
+    io.base = base;
+    int cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < DCB_K; ++j) {
+      const size_t i = base + (size_t)j * io.nthreads;
+      if (i >= n) break;
+      uint32_t w[8];
+      load32(fq32, i, w);
+      fe s, t;
+      ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s, &t);
+      D377_INVARIANT(T, ge_from_jacobi_st(s, t), true);
+      dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
+      cnt = j + 1;
+    }
+    dcb_finish(pt, io, cnt);
   }
 }
 
@@ -236,40 +265,63 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTab
   }
 }
 
+// [k]P = [2]([k/2 mod r]P): the window loop runs on k/2 and the encoding is that of the double (no square root)
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTables T, const uint8_t* enc32,
                                                           const uint8_t* scalar32, size_t n, uint8_t* out32,
-                                                          uint8_t* status, uint32_t* scratch) {
+                                                          uint8_t* status, uint32_t* scratch, uint8_t* dcb) {
   D377_POW_LDS();
   GlobalTab tab;
   tab.base = scratch;
   tab.nthreads = (size_t)gridDim.x * BLOCK;
   tab.tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  for (size_t i = tab.tid; i < n; i += tab.nthreads) {
-    uint32_t w[8], k[8], dg[8];
-    load32(enc32, i, w);
-    load32(scalar32, i, k);
-    ge g;
-    const uint32_t bad = ge_decompress(T, pt, w, &g);
-    fr_reduce_words(k);
-    fr_recode_signed16(k, dg);
-    ge r = ge_scalar_mul_w4(g, dg, tab);
-    ge_compress(T, pt, r, w, bad == 0);
-    status[i] = (uint8_t)bad;
-    if (bad) store32_zero(out32, i); else store32(out32, i, w);
+  DcbIO io{dcb, out32, tab.nthreads, tab.tid, 0};
+  for (size_t base = tab.tid; base < n; base += (size_t)DCB_K * tab.nthreads) {
+    io.base = base;
+    int cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < DCB_K; ++j) {
+      const size_t i = base + (size_t)j * tab.nthreads;
+      if (i >= n) break;
+      uint32_t w[8], k[8], dg[8];
+      load32(enc32, i, w);
+      load32(scalar32, i, k);
+      ge g;
+      const uint32_t bad = ge_decompress(T, pt, w, &g);
+      fr_reduce_words(k);
+      fr_half_words(k);
+      fr_recode_signed16(k, dg);
+      const ge r = ge_scalar_mul_w4(g, dg, tab, DCB_WANT_T);
+      D377_INVARIANT(T, r, bad == 0);
+      dcb_put(io, j, ge_dcb_from_half(r, bad != 0));      // failed lanes: neutral state, all-zero output
+      status[i] = (uint8_t)bad;
+      cnt = j + 1;
+    }
+    dcb_finish(pt, io, cnt);
   }
 }
 
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
-                                                           const uint8_t* scalar32, size_t n, uint8_t* out32) {
+                                                           const uint8_t* scalar32, size_t n, uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
   FixedTab ft{fbase};
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t k[8], w[8];
-    load32(scalar32, i, k);
-    fr_reduce_words(k);
-    ge r = ge_scalar_mul_base_w8(k, ft);
-    ge_compress(T, pt, r, w);
-    store32(out32, i, w);
+  DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
+  for (size_t base = io.tid; base < n; base += (size_t)DCB_K * io.nthreads) {
+    io.base = base;
+    int cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < DCB_K; ++j) {
+      const size_t i = base + (size_t)j * io.nthreads;
+      if (i >= n) break;
+      uint32_t k[8];
+      load32(scalar32, i, k);
+      fr_reduce_words(k);
+      fr_half_words(k);
+      const ge r = ge_scalar_mul_base_w8(k, ft, DCB_WANT_T);
+      D377_INVARIANT(T, r, true);
+      dcb_put(io, j, ge_dcb_from_half(r, false));
+      cnt = j + 1;
+    }
+    dcb_finish(pt, io, cnt);
   }
 }
 
@@ -350,13 +402,23 @@ __global__ void __launch_bounds__(BLOCK) k_fq_from_wide(const uint8_t* in, int l
   }
 }
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(SqrtTables T, const uint8_t* in, int len,
-                                                                                size_t n, uint8_t* out32) {
+                                                                                size_t n, uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t w[8];
-    ge g = ge_elligator_map(T, pt, fe_carry(load_wide(in, i, len)));
-    ge_compress(T, pt, g, w);
-    store32(out32, i, w);
+  DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
+  for (size_t base = io.tid; base < n; base += (size_t)DCB_K * io.nthreads) {
+    io.base = base;
+    int cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < DCB_K; ++j) {
+      const size_t i = base + (size_t)j * io.nthreads;
+      if (i >= n) break;
+      fe s, t;
+      ge_elligator_st(T, pt, fe_carry(load_wide(in, i, len)), &s, &t);
+      D377_INVARIANT(T, ge_from_jacobi_st(s, t), true);
+      dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
+      cnt = j + 1;
+    }
+    dcb_finish(pt, io, cnt);
   }
 }
 // (x/z, y/z) as Montgomery-256 limbs: CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81), with
@@ -611,6 +673,8 @@ int init_device(DeviceState& d) {
   // variable-base window tables: one per resident lane, fixed grid, grid-stride over the batch
   d.vb_blocks = d.cus * WAVES_PER_SIMD;        // exactly the resident blocks: 2 per CU
   HIP_TRY(hipMalloc(&d.vb_scratch, (size_t)d.vb_blocks * BLOCK * VB_ENTRIES * VB_ENTRY_WORDS * sizeof(uint32_t)));
+  // round records of the square-root-free compressor: 4 x DCB_K 32-byte records per resident lane (512 MiB)
+  HIP_TRY(hipMalloc(&d.dcb_scratch, (size_t)d.vb_blocks * BLOCK * 4 * DCB_K * 32));
   uint32_t* keys = nullptr;
   int* coll = nullptr;
   HIP_TRY(hipMalloc(&keys, 512 * sizeof(uint32_t)));
@@ -628,7 +692,7 @@ void free_device(DeviceState& d) {
   if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
   (void)d.vb_guard.drain();
   (void)d.msm.guard.drain();
-  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.inv_fail);
+  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.inv_fail);
   for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); (void)hipFree(d.shard[i]); }
   for (int i = 0; i < 2; ++i) {
     if (d.ev_in[i]) (void)hipEventDestroy(d.ev_in[i]);
@@ -649,6 +713,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
   if (n == 0) return D377_OK;
   const SqrtTables T = d.tables();
   const int g = grid_for(d, n);
+  const int gv = g < d.vb_blocks ? g : d.vb_blocks;   // the persistent grid: exactly the resident blocks
   int rc;
   switch (op) {
     case OP_SQRT:
@@ -664,19 +729,25 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     case OP_ROUNDTRIP:
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
       break;
+    // The next four keep per-lane state in scratch areas that exist once per device (window tables, round records of
+    // the square-root-free compressor): never more lanes than those areas have, and each launch queues behind the
+    // areas' last user.
     case OP_MUL_BASE:
-      hipLaunchKernelGGL(k_scalar_mul_base, dim3(g), dim3(BLOCK), 0, s, T, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
-      break;
-    case OP_MUL_VAR: {
-      int gv = g < d.vb_blocks ? g : d.vb_blocks;    // never more lanes than scratch tables
-      if ((rc = d.vb_guard.acquire(s))) return rc;   // the window tables are one per device: queue behind their last user
-      hipLaunchKernelGGL(k_scalar_mul_var, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
-                         (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch);
+      if ((rc = d.vb_guard.acquire(s))) return rc;
+      hipLaunchKernelGGL(k_scalar_mul_base, dim3(gv), dim3(BLOCK), 0, s, T, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0,
+                         d.dcb_scratch);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
-    }
+    case OP_MUL_VAR:
+      if ((rc = d.vb_guard.acquire(s))) return rc;
+      hipLaunchKernelGGL(k_scalar_mul_var, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                         (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch, d.dcb_scratch);
+      if ((rc = d.vb_guard.release(s))) return rc;
+      break;
     case OP_ENCODE:
-      hipLaunchKernelGGL(k_encode_to_curve, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0);
+      if ((rc = d.vb_guard.acquire(s))) return rc;
+      hipLaunchKernelGGL(k_encode_to_curve, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, d.dcb_scratch);
+      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_HASH:
       hipLaunchKernelGGL(k_hash_to_curve, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
@@ -698,8 +769,10 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     case OP_ENCODE_WIDE48:
     case OP_ENCODE_WIDE64:
-      hipLaunchKernelGGL(k_encode_to_curve_wide, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
-                         op == OP_ENCODE_WIDE48 ? 48 : 64, n, (uint8_t*)out0);
+      if ((rc = d.vb_guard.acquire(s))) return rc;
+      hipLaunchKernelGGL(k_encode_to_curve_wide, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
+                         op == OP_ENCODE_WIDE48 ? 48 : 64, n, (uint8_t*)out0, d.dcb_scratch);
+      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_AFFINE: {
       // ~AFFINE_PER_LANE elements per lane so that one inversion serves many, but never fewer lanes than one
@@ -735,7 +808,6 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_MUL_VAR_EL: {
-      int gv = g < d.vb_blocks ? g : d.vb_blocks;
       if ((rc = d.vb_guard.acquire(s))) return rc;
       hipLaunchKernelGGL(k_scalar_mul_var_el, dim3(gv), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
                          (uint64_t*)out0, d.vb_scratch);

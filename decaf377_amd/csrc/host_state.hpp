@@ -60,6 +60,7 @@ struct DeviceState {
   uint8_t* s_lookup = nullptr;
   uint32_t* fbase = nullptr;
   uint32_t* vb_scratch = nullptr;
+  uint8_t* dcb_scratch = nullptr;        // round records of the square-root-free compressor (curve.hpp, dcb_finish)
   int vb_blocks = 0;
   uint32_t* inv_fail = nullptr;          // device counter of the -DD377_CHECK_INVARIANTS build (always allocated)
   ScratchGuard vb_guard;

@@ -39,6 +39,29 @@ struct HostFTab {
   }
 };
 
+// the square-root-free compression of the scalar-multiplication and Elligator kernels (curve.hpp, "compression
+// without a square root"): one host "lane" walks the batch in rounds of DCB_K elements, as a device lane does
+struct HostDcbIO {
+  uint32_t st[4][DCB_K][8];
+  uint32_t* out;
+  size_t base;
+  void put(int s, int j, const uint32_t* w) { memcpy(st[s][j], w, 32); }
+  void get(int s, int j, uint32_t* w) const { memcpy(w, st[s][j], 32); }
+  void park(int j, const uint32_t* w) { memcpy(out + 8 * (base + j), w, 32); }
+  void parked(int j, uint32_t* w) const { memcpy(w, out + 8 * (base + j), 32); }
+  void emit(int j, const uint32_t* w) { memcpy(out + 8 * (base + j), w, 32); }
+};
+template <class F>
+static void dcb_rounds(size_t n, uint32_t* out, F state_of) {
+  for (size_t base = 0; base < n; base += DCB_K) {
+    HostDcbIO io; io.out = out; io.base = base;
+    const int cnt = (int)((n - base) < (size_t)DCB_K ? (n - base) : (size_t)DCB_K);
+    for (int j = 0; j < cnt; ++j) dcb_put(io, j, state_of(base + j));
+    RegPowTab pt;
+    dcb_finish(pt, io, cnt);
+  }
+}
+
 extern "C" {
 int sim_init() {
   // same construction the init kernels perform on the device
@@ -204,14 +227,30 @@ void sim_roundtrip(const uint32_t* enc, size_t n, uint32_t* out, uint8_t* st) {
   }
 }
 void sim_encode_to_curve(const uint32_t* r0, size_t n, uint32_t* enc, uint32_t* xyzt) {
+  dcb_rounds(n, enc, [&](size_t i) {
+    RegPowTab pt; fe s, t;
+    ge_elligator_st(g_T, pt, fe_from_words_mod_order(r0 + 8 * i), &s, &t);
+    if (xyzt) ge_store256(ge_from_jacobi_st(s, t), xyzt + 32 * i);
+    return ge_dcb_from_jacobi_st(s, t);
+  });
+}
+// the same through the generic compressor (one square root more per element): what hash_to_curve and compress use
+void sim_encode_to_curve_sqrt(const uint32_t* r0, size_t n, uint32_t* enc) {
   for (size_t i = 0; i < n; ++i) {
     RegPowTab pt;
-    ge g = ge_elligator_map(g_T, pt, fe_from_words_mod_order(r0 + 8 * i));
-    ge_compress(g_T, pt, g, enc + 8 * i);
-    if (xyzt) ge_store256(g, xyzt + 32 * i);
+    ge_compress(g_T, pt, ge_elligator_map(g_T, pt, fe_from_words_mod_order(r0 + 8 * i)), enc + 8 * i);
   }
 }
 void sim_scalar_mul_var(const uint32_t* enc, const uint32_t* k, size_t n, uint32_t* out, uint8_t* st) {
+  dcb_rounds(n, out, [&](size_t i) {
+    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
+    st[i] = (uint8_t)bad;
+    uint32_t kk[8], dg[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_half_words(kk); fr_recode_signed16(kk, dg);
+    HostTab tab; ge r = ge_scalar_mul_w4(g, dg, tab, DCB_WANT_T);  // [k/2]P; the state is that of its double
+    return ge_dcb_from_half(r, bad != 0);
+  });
+}
+void sim_scalar_mul_var_sqrt(const uint32_t* enc, const uint32_t* k, size_t n, uint32_t* out, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
     RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
     st[i] = (uint8_t)bad;
@@ -223,11 +262,13 @@ void sim_scalar_mul_var(const uint32_t* enc, const uint32_t* k, size_t n, uint32
 }
 void sim_scalar_mul_base(const uint32_t* k, size_t n, uint32_t* out) {
   HostFTab ft{g_fbase.data()};
-  for (size_t i = 0; i < n; ++i) {
-    uint32_t kk[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk);
-    RegPowTab pt;
-    ge_compress(g_T, pt, ge_scalar_mul_base_w8(kk, ft), out + 8 * i);
-  }
+  dcb_rounds(n, out, [&](size_t i) {
+    uint32_t kk[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_half_words(kk);
+    return ge_dcb_from_half(ge_scalar_mul_base_w8(kk, ft, DCB_WANT_T), false);
+  });
+}
+void sim_fr_half(const uint32_t* k, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) { memcpy(out + 8 * i, k + 8 * i, 32); fr_reduce_words(out + 8 * i); fr_half_words(out + 8 * i); }
 }
 #if defined(D377_BOUNDS)
 // products / squarings executed since the last call (bounds build only): bench.py's per-element MAC counts
