@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarises a tools/collect_pmc.sh output directory: per-kernel averages of every counter, the kernel
 stats table, and the JSON record bench.py reads for roofline.traffic / valu_insts_per_element.
-usage: tools/pmc_summarize.py <dir> [label]   -> <dir>/pmc_summary.csv, <dir>/pmc_traffic.json, <dir>/kernel_stats.csv"""
+usage: tools/pmc_summarize.py <dir> [label [elements]]   -> <dir>/pmc_summary.csv, <dir>/pmc_traffic.json, <dir>/kernel_stats.csv
+`elements`: records per k_scalar_mul_var launch of the profiled command (default 2^22, bench.py's workload); with it the
+record carries valu_insts_per_element = SQ_INSTS_VALU (wave-instructions) / (elements / 64)."""
 import csv
 import glob
 import json
@@ -18,6 +20,7 @@ def short(name):
 def main():
     d = sys.argv[1]
     label = sys.argv[2] if len(sys.argv) > 2 else d
+    elements = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 22
     agg = {}          # (kernel, grid, counter) -> [sum, launches]
     for f in sorted(glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
@@ -64,6 +67,9 @@ def main():
                 rec[k] = c[k]
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             rec["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        if kern == "k_scalar_mul_var" and "SQ_INSTS_VALU" in c:
+            rec["elements"] = elements
+            rec["valu_insts_per_element"] = c["SQ_INSTS_VALU"] / (elements / 64.0)
         out[kern] = rec
     json.dump(out, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
     for k, v in out.items():
