@@ -16,8 +16,8 @@ EXPORTS = [
     "d377_ctx_create", "d377_ctx_destroy", "d377_ctx_num_devices", "d377_ctx_device_id",
     "d377_batch_sqrt_ratio_zeta", "d377_batch_decompress", "d377_batch_compress", "d377_batch_roundtrip",
     "d377_batch_scalar_mul_base", "d377_batch_scalar_mul_var", "d377_batch_encode_to_curve",
-    "d377_batch_hash_to_curve", "d377_batch_add", "d377_batch_double", "d377_batch_eq",
-    "d377_batch_add_dev", "d377_batch_double_dev", "d377_batch_eq_dev",
+    "d377_batch_hash_to_curve", "d377_batch_add", "d377_batch_sub", "d377_batch_double", "d377_batch_eq",
+    "d377_batch_add_dev", "d377_batch_sub_dev", "d377_batch_double_dev", "d377_batch_eq_dev",
     "d377_batch_fr_from_le_bytes_mod_order", "d377_batch_fr_from_bytes_checked",
     "d377_batch_fq_op", "d377_batch_fq_op_dev", "d377_batch_fq_from_bytes_checked", "d377_batch_fq_to_bytes",
     "d377_batch_neg", "d377_batch_is_identity", "d377_batch_neg_dev", "d377_batch_is_identity_dev",
@@ -85,6 +85,7 @@ def load():
         "d377_batch_encode_to_curve": [vp, vp, sz, vp],
         "d377_batch_hash_to_curve": [vp, vp, vp, sz, vp],
         "d377_batch_add": [vp, vp, vp, sz, vp],
+        "d377_batch_sub": [vp, vp, vp, sz, vp],
         "d377_batch_double": [vp, vp, sz, vp],
         "d377_batch_eq": [vp, vp, vp, sz, vp],
         "d377_batch_neg": [vp, vp, sz, vp],

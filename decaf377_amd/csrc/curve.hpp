@@ -358,6 +358,19 @@ D377_HD ge ge_add(const ge& p, const ge& q) {
   return r;
 }
 
+// p - q = p + (-q), -q = (-x, y, z, -t) (src/min_curve/ops.rs:43-49, element.rs:324-332): the addition above with
+// y2 -+ x2 exchanged and the sign of C folded into F and G -- the same field values, no negation computed
+D377_HD ge ge_sub_pts(const ge& p, const ge& q) {
+  fe a = fe_mul(fe_sub(p.y, p.x), fe_add(q.y, q.x));
+  fe b = fe_mul(fe_add(p.y, p.x), fe_sub(q.y, q.x));
+  fe c = fe_mul(fe_mul(fe_const(FE_K), p.t), q.t);
+  fe d = fe_mul(fe_dbl(p.z), q.z);
+  fe e = fe_sub(b, a), f = fe_add(d, c), g = fe_sub(d, c), h = fe_add(b, a);
+  ge r;
+  r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g); r.t = fe_mul(e, h);
+  return r;
+}
+
 // src/min_curve/element.rs:119-136
 D377_HD ge ge_double(const ge& p) {
   fe a = fe_sqr(p.x), b = fe_sqr(p.y);

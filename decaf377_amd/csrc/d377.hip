@@ -589,12 +589,14 @@ __global__ void __launch_bounds__(BLOCK) k_is_identity(const uint64_t* p, size_t
 }
 // add / double / eq / neg read the records without converting them (curve.hpp, "records used without conversion"):
 // these kernels move 256-384 bytes per element and the eight conversion products were most of their time.
-__global__ void __launch_bounds__(BLOCK) k_add(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out) {
+// negate != 0: Element - Element = self + other.neg() (src/min_curve/ops.rs:43-49)
+__global__ void __launch_bounds__(BLOCK) k_add(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out, int negate) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t a[32], b[32];
     load_record128(p, i, a);
     load_record128(q, i, b);
-    ge_raw4_to_words(ge_add(ge_from_raw_words(a), ge_from_raw_words(b)), a);
+    const ge gp = ge_from_raw_words(a), gq = ge_from_raw_words(b);
+    ge_raw4_to_words(negate ? ge_sub_pts(gp, gq) : ge_add(gp, gq), a);
     store_record128(out, i, a);
   }
 }
@@ -754,7 +756,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
                          (uint8_t*)out0);
       break;
     case OP_ADD:
-      hipLaunchKernelGGL(k_add, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint64_t*)in1, n, (uint64_t*)out0);
+      hipLaunchKernelGGL(k_add, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint64_t*)in1, n, (uint64_t*)out0, aux);
       break;
     case OP_DOUBLE:
       hipLaunchKernelGGL(k_double, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
@@ -1191,6 +1193,9 @@ int d377_batch_hash_to_curve(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t*
 int d377_batch_add(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint64_t* out_xyzt) {
   return run_host(ctx, OP_ADD, 0, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
 }
+int d377_batch_sub(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint64_t* out_xyzt) {
+  return run_host(ctx, OP_ADD, 1, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
+}
 int d377_batch_double(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
   return run_host(ctx, OP_DOUBLE, 0, p_xyzt, nullptr, n, out_xyzt, nullptr);
 }
@@ -1200,6 +1205,10 @@ int d377_batch_eq(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt,
 int d377_batch_add_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n,
                        uint64_t* out_xyzt) {
   return run_dev(ctx, dev, stream, OP_ADD, 0, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
+}
+int d377_batch_sub_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n,
+                       uint64_t* out_xyzt) {
+  return run_dev(ctx, dev, stream, OP_ADD, 1, p_xyzt, q_xyzt, n, out_xyzt, nullptr);
 }
 int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt) {
   return run_dev(ctx, dev, stream, OP_DOUBLE, 0, p_xyzt, nullptr, n, out_xyzt, nullptr);

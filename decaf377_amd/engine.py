@@ -218,6 +218,10 @@ class Context:
     def add(self, p_xyzt, q_xyzt, outs=None):
         return self._run("d377_batch_add", [p_xyzt, q_xyzt], [ELEM, ELEM], [ELEM], outs)[0]
 
+    def sub(self, p_xyzt, q_xyzt, outs=None):
+        """Element - Element = self + other.neg() (src/min_curve/ops.rs:43-87)."""
+        return self._run("d377_batch_sub", [p_xyzt, q_xyzt], [ELEM, ELEM], [ELEM], outs)[0]
+
     def double(self, p_xyzt, outs=None):
         return self._run("d377_batch_double", [p_xyzt], [ELEM], [ELEM], outs)[0]
 

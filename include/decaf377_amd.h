@@ -128,10 +128,13 @@ int d377_batch_encode_to_curve_element(d377_ctx* ctx, const uint8_t* fq32, size_
 int d377_batch_hash_to_curve_element(d377_ctx* ctx, const uint8_t* r1_32, const uint8_t* r2_32, size_t n,
                                      uint64_t* out_xyzt);
 
-/* Element + Element, Element::double, decaf equality (x1*y2 == x2*y1) on in-memory elements
- *            src/min_curve/element.rs:291-322, 119-136, 334-340; ark: element/projective.rs:65-70
+/* Element + Element, Element - Element (= self + other.neg()), Element::double, decaf equality
+ * (x1*y2 == x2*y1) on in-memory elements
+ *            src/min_curve/element.rs:291-322, 119-136, 334-340; src/min_curve/ops.rs:15-87;
+ *            ark: element/projective.rs:65-70
  * Results are the same extended coordinates the reference formulas produce. */
 int d377_batch_add(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint64_t* out_xyzt);
+int d377_batch_sub(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint64_t* out_xyzt);
 int d377_batch_double(d377_ctx* ctx, const uint64_t* p_xyzt, size_t n, uint64_t* out_xyzt);
 int d377_batch_eq(d377_ctx* ctx, const uint64_t* p_xyzt, const uint64_t* q_xyzt, size_t n, uint8_t* equal);
 
@@ -218,6 +221,8 @@ int d377_batch_hash_to_curve_dev(d377_ctx* ctx, int dev, void* stream, const uin
                                  const uint8_t* r2_32, size_t n, uint8_t* enc32_out);
 
 int d377_batch_add_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt,
+                       size_t n, uint64_t* out_xyzt);
+int d377_batch_sub_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, const uint64_t* q_xyzt,
                        size_t n, uint64_t* out_xyzt);
 int d377_batch_double_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* p_xyzt, size_t n,
                           uint64_t* out_xyzt);

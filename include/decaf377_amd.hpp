@@ -226,6 +226,13 @@ class Engine {
     check(d377_batch_add(ctx_, u64(p), u64(q), p.size(), reinterpret_cast<uint64_t*>(out.data())));
     return out;
   }
+  /// Element - Element (src/min_curve/ops.rs:43-87)
+  std::vector<Element> sub(const std::vector<Element>& p, const std::vector<Element>& q) {
+    if (p.size() != q.size()) throw std::invalid_argument("length mismatch");
+    std::vector<Element> out(p.size());
+    check(d377_batch_sub(ctx_, u64(p), u64(q), p.size(), reinterpret_cast<uint64_t*>(out.data())));
+    return out;
+  }
   std::vector<Element> double_(const std::vector<Element>& p) {
     std::vector<Element> out(p.size());
     check(d377_batch_double(ctx_, u64(p), p.size(), reinterpret_cast<uint64_t*>(out.data())));

@@ -251,6 +251,14 @@ impl Element {
         check(unsafe { ffi::d377_batch_add(ctx.0, a.as_ptr(), b.as_ptr(), ps.len(), out.as_mut_ptr()) })?;
         Ok(elements_from_xyzt(&out))
     }
+    /// `Element - Element` (src/min_curve/ops.rs:43-87)
+    pub fn sub_batch(ctx: &GpuContext, ps: &[Element], qs: &[Element]) -> Result<Vec<Element>, GpuError> {
+        assert_eq!(ps.len(), qs.len());
+        let (a, b) = (elements_to_xyzt(ps), elements_to_xyzt(qs));
+        let mut out = vec![0u64; 16 * ps.len()];
+        check(unsafe { ffi::d377_batch_sub(ctx.0, a.as_ptr(), b.as_ptr(), ps.len(), out.as_mut_ptr()) })?;
+        Ok(elements_from_xyzt(&out))
+    }
     pub fn double_batch(ctx: &GpuContext, ps: &[Element]) -> Result<Vec<Element>, GpuError> {
         let a = elements_to_xyzt(ps);
         let mut out = vec![0u64; 16 * ps.len()];

@@ -134,6 +134,10 @@ class Oracle:
         self.lib.d377o_add_xyzt(_p(p), _p(q), self._n(p.shape[0]), _p(out))
         return out
 
+    def sub_xyzt(self, p, q):
+        """Element - Element = self + other.neg() (src/min_curve/ops.rs:43-49)."""
+        return self.add_xyzt(p, self.neg_xyzt(q))
+
     def double_xyzt(self, p):
         p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 16)
         out = np.zeros_like(p)

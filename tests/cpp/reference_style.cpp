@@ -145,6 +145,7 @@ static void vartime_multiscalar_mul_matches_scalar_mul(Engine& e) {
   // P + (-P) is the identity; GENERATOR is the decoding of [8, 0, ...]
   auto g = Engine::generator();
   CHECK(e.is_identity(e.add({g}, e.neg({g})))[0]);
+  CHECK(e.is_identity(e.sub({g}, {g}))[0]);                // Element - Element, src/min_curve/ops.rs:43-49
   CHECK(e.is_identity({Engine::identity()})[0] && !e.is_identity({g})[0]);
   std::array<uint8_t, 32> eight{}; eight[0] = 8;
   CHECK(e.vartime_compress({g})[0] == Encoding(eight));

@@ -209,6 +209,12 @@ void sim_raw_forms(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* sum
     f_ok[i] = ok ? 1 : 0;
   }
 }
+// Element - Element as k_add does it with negate = 1
+void sim_raw_ge_sub(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* out) {
+  for (size_t i = 0; i < n; ++i) {
+    ge_raw4_to_words(ge_sub_pts(ge_from_raw_words(p + 32 * i), ge_from_raw_words(q + 32 * i)), out + 32 * i);
+  }
+}
 void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
     RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);

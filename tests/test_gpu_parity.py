@@ -307,6 +307,12 @@ def test_add_double_eq(ctx, oracle, kats):
     assert ctx.eq(d2, ctx.add(P, P)).all()
     assert not ctx.eq(P, Qp).any()
     assert (ctx.eq(s, ctx.add(Qp, P)) == 1).all()
+    # Element - Element = self + other.neg() (src/min_curve/ops.rs:43-87): the reference's coordinates, and (P + Q) - Q = P
+    df = ctx.sub(P, Qp)
+    assert (df == oracle.sub_xyzt(P, Qp)).all()
+    assert ctx.eq(ctx.sub(s, Qp), P).all() and ctx.is_identity(ctx.sub(P, P)).all()
+    ident = np.tile(oracle.identity_xyzt(), (4, 1))
+    assert (ctx.sub(ident, P[:4]) == oracle.sub_xyzt(ident, P[:4])).all() and ctx.eq(ctx.sub(P[:4], ident), P[:4]).all()
 
 
 def test_full_size_fixed_base_2_20(ctx, torch_mod, oracle):
@@ -790,6 +796,7 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_encode_to_curve_dev": lambda f: f.encode_to_curve,
         "d377_batch_hash_to_curve_dev": lambda f: f.hash_to_curve,
         "d377_batch_add_dev": lambda f: f.add,
+        "d377_batch_sub_dev": lambda f: f.sub,
         "d377_batch_double_dev": lambda f: f.double,
         "d377_batch_eq_dev": lambda f: f.eq,
         "d377_batch_neg_dev": lambda f: f.neg,
@@ -819,7 +826,7 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_decompress_dev": [(raw,)], "d377_batch_compress_dev": [(Qp,)], "d377_batch_roundtrip_dev": [(raw,)],
         "d377_batch_scalar_mul_base_dev": [(k,)], "d377_batch_scalar_mul_var_dev": [(raw, k)],
         "d377_batch_encode_to_curve_dev": [(r0,)], "d377_batch_hash_to_curve_dev": [(r0, r1)],
-        "d377_batch_add_dev": [(P, Qp)], "d377_batch_double_dev": [(Qp,)], "d377_batch_eq_dev": [(P, Qp), (Qp, Qp)],
+        "d377_batch_add_dev": [(P, Qp)], "d377_batch_sub_dev": [(P, Qp), (Qp, Qp)], "d377_batch_double_dev": [(Qp,)], "d377_batch_eq_dev": [(P, Qp), (Qp, Qp)],
         "d377_batch_neg_dev": [(Qp,)], "d377_batch_is_identity_dev": [(oracle.add_xyzt(P, oracle.neg_xyzt(P)),), (P,)],
         "d377_batch_to_affine_dev": [(Qp,)], "d377_batch_fq_from_wide_bytes_dev": [(w48,), (w64,)],
         "d377_batch_encode_to_curve_wide_dev": [(w48,), (w64,)],

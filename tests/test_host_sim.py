@@ -281,6 +281,9 @@ def test_conversion_free_forms_match_oracle(sim, oracle):
     eq, nok, fok = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
     sim.sim_raw_forms(_p(P), _p(Q2), n_(n), _p(s_), _p(d_), _p(ng), _p(eq), _p(nok), _p(fm), _p(fs), _p(fa), _p(fb), _p(fn), _p(fok))
     assert (s_ == oracle.add_xyzt(P, Q2)).all()
+    df = z(n, 16)
+    sim.sim_raw_ge_sub(_p(P), _p(Q2), n_(n), _p(df))              # Element - Element = self + other.neg(), ops.rs:43-49
+    assert (df == oracle.add_xyzt(P, oracle.neg_xyzt(Q2))).all()
     assert (d_ == oracle.double_xyzt(P)).all()
     assert (ng == oracle.neg_xyzt(P)).all() and nok.all() and fok.all()
     assert (eq == oracle.eq_xyzt(P, Q2)).all() and eq[2] == 1 and eq[0] == 0
@@ -411,6 +414,7 @@ fl = [np.zeros(n, np.uint8) for _ in range(3)]
 full = np.full((n, 16), 0xFFFFFFFFFFFFFFFF, np.uint64)      # every word string the conversion-free forms may be handed
 for u, v in ((xyzt, x2), (full, full)):
     L.sim_raw_forms(p(u), p(v), n_(n), p(a), p(b), p(np.zeros((n, 16), np.uint64)), p(fl[0]), p(fl[1]), p(f[0]), p(f[1]), p(f[2]), p(f[3]), p(f[4]), p(fl[2]))
+L.sim_raw_ge_sub(p(xyzt), p(x2), n_(n), p(a)); L.sim_raw_ge_sub(p(full), p(full), n_(n), p(a))
 w = np.zeros((n, 4), np.uint64)
 L.sim_fq_mul(p(xyzt), p(x2), n_(n), p(w)); L.sim_fq_sub(p(xyzt), p(x2), n_(n), p(w)); L.sim_fq_add(p(xyzt), p(x2), n_(n), p(w))
 print("BOUNDS_OK")
