@@ -40,7 +40,7 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
 # (4 S + 6 M) + the square-root-free compression: 7 M and 1/32 of a 296 S + 53 M inversion per element
 # (a lane inverts once per round of 32 elements, which is what every lane has at 2^22 elements).  Fixed base
 # is counted at the 8 elements per lane of the 2^20 extra.
-KERNEL_OPS = {"scalar_mul_var": (1674.65625, 1063.25), "roundtrip": (177, 580), "scalar_mul_base": (164.625, 40.0),
+KERNEL_OPS = {"scalar_mul_var": (1674.65625, 1063.25), "roundtrip": (177, 580), "scalar_mul_base": (143.625, 40.0),
               "sqrt_ratio_zeta": (83, 288)}
 MACS_PER_MUL, MACS_PER_SQR = 153, 117
 KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR for k, (m, s) in KERNEL_OPS.items()}   # scalar_mul_var: 380623

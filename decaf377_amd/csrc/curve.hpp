@@ -828,10 +828,11 @@ D377_HD void fr_recode_signed256(const uint32_t k[8], int digits[32]) {
 
 // [k]B from the shared table FB[i][j] = affine cached j * 2^(FB_BITS i) * B (i < FB_WINDOWS, j <= 2^(FB_BITS-1)):
 // FB_WINDOWS mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.  FB_BITS must divide the 252
-// significant scalar bits evenly so that the top digit needs no carry-out: 12 (21 windows x 2049 entries,
-// 6.2 MB, resident in L2 / Infinity Cache) or, as before, 8 with FB_WINDOWS = 32 (594 KB).
+// significant scalar bits evenly so that the top digit needs no carry-out: 14 (18 windows x 8193 entries, 21 MB,
+// resident in the Infinity Cache), 12 (21 x 2049, 6.2 MB) or, as at first, 8 with FB_WINDOWS = 32 (594 KB).
+// Measured at 2^20 scalars with the square-root-free compressor: 7.8e8/s with 12 bits, 8.6e8/s with 14.
 #ifndef D377_FB_BITS
-#define D377_FB_BITS 12
+#define D377_FB_BITS 14
 #endif
 constexpr int FB_BITS = D377_FB_BITS;
 constexpr int FB_WINDOWS = (FB_BITS == 8) ? 32 : 252 / FB_BITS;
@@ -847,7 +848,7 @@ D377_HD int fb_digit(const uint32_t k[8], int i, uint32_t& carry) {
   return (int)dd - (int)(carry << FB_BITS);
 }
 // want_t: whether the caller reads T of the result.  The entry of window i + 1 is fetched before the addition of
-// window i: the table (6.2 MB) lives in L2 / Infinity Cache, and one mixed addition is only ~1 500 instructions.
+// window i: the table lives in L2 / Infinity Cache, and one mixed addition is only ~1 500 instructions.
 template <class FTab>
 D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab, bool want_t = true) {
   ge r = ge_identity();
@@ -919,7 +920,10 @@ D377_HD void fr_half_words(uint32_t k[8]) {
 // State of one element: enc = | (is_negative(w / p) ? n1 : n0) / p |; p = 0 (the identity's X = 0, where the
 // reference's sqrt_ratio_zeta(1, 0) returns 0 and the encoding is 0) and failed lanes are stored as
 // p = 1, n0 = n1 = 0.  All four values are strict products (tight limbs, < 2q) and travel as 32-byte records.
-constexpr int DCB_K = 32;               // elements per lane per inversion
+#ifndef D377_DCB_K
+#define D377_DCB_K 32
+#endif
+constexpr int DCB_K = D377_DCB_K;       // elements per lane per inversion
 #if defined(D377_CHECK_INVARIANTS)
 constexpr bool DCB_WANT_T = true;       // the debug assertions re-check T Z = X Y on the half point
 #else

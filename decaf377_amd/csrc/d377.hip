@@ -49,7 +49,7 @@ struct GlobalTab {
     return c;
   }
 };
-// shared fixed-base comb FB[i][j] = affine cached j * 256^i * B, [32][129][3 slots]
+// shared fixed-base comb FB[i][j] = affine cached j * 2^(FB_BITS i) * B, [FB_WINDOWS][FB_ENTRIES][3 slots]
 struct FixedTab {
   const uint32_t* base;
   __device__ __forceinline__ gea load(int i, int j, bool swap) const {
