@@ -232,7 +232,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtT
                                                            uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
   DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
-  for (size_t base = io.tid; base < n; base += (size_t)DCB_K * io.nthreads) {
+  const size_t per_round = (size_t)DCB_K * io.nthreads;
+  for (size_t round = 0; round * per_round < n; ++round) {          // wave-uniform: only the lane index lives in a VGPR
+    const size_t base = round * per_round + io.tid;
     io.base = base;
     int cnt = 0;
 #pragma unroll 1
@@ -275,7 +277,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
   tab.nthreads = (size_t)gridDim.x * BLOCK;
   tab.tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   DcbIO io{dcb, out32, tab.nthreads, tab.tid, 0};
-  for (size_t base = tab.tid; base < n; base += (size_t)DCB_K * tab.nthreads) {
+  const size_t per_round = (size_t)DCB_K * tab.nthreads;
+  for (size_t round = 0; round * per_round < n; ++round) {          // wave-uniform: only the lane index lives in a VGPR
+    const size_t base = round * per_round + tab.tid;
     io.base = base;
     int cnt = 0;
 #pragma unroll 1
@@ -287,13 +291,13 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
       load32(scalar32, i, k);
       ge g;
       const uint32_t bad = ge_decompress(T, pt, w, &g);
+      status[i] = (uint8_t)bad;
       fr_reduce_words(k);
       fr_half_words(k);
       fr_recode_signed16(k, dg);
       const ge r = ge_scalar_mul_w4(g, dg, tab, DCB_WANT_T);
       D377_INVARIANT(T, r, bad == 0);
       dcb_put(io, j, ge_dcb_from_half(r, bad != 0));      // failed lanes: neutral state, all-zero output
-      status[i] = (uint8_t)bad;
       cnt = j + 1;
     }
     dcb_finish(pt, io, cnt);
@@ -305,7 +309,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
   D377_POW_LDS();
   FixedTab ft{fbase};
   DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
-  for (size_t base = io.tid; base < n; base += (size_t)DCB_K * io.nthreads) {
+  const size_t per_round = (size_t)DCB_K * io.nthreads;
+  for (size_t round = 0; round * per_round < n; ++round) {          // wave-uniform: only the lane index lives in a VGPR
+    const size_t base = round * per_round + io.tid;
     io.base = base;
     int cnt = 0;
 #pragma unroll 1
@@ -405,7 +411,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(
                                                                                 size_t n, uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
   DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
-  for (size_t base = io.tid; base < n; base += (size_t)DCB_K * io.nthreads) {
+  const size_t per_round = (size_t)DCB_K * io.nthreads;
+  for (size_t round = 0; round * per_round < n; ++round) {          // wave-uniform: only the lane index lives in a VGPR
+    const size_t base = round * per_round + io.tid;
     io.base = base;
     int cnt = 0;
 #pragma unroll 1

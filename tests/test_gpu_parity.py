@@ -337,6 +337,38 @@ def test_full_size_fixed_base_2_20(ctx, torch_mod, oracle):
     assert (fb[idx].cpu().numpy() == oracle.scalar_mul_base(k.numpy()[idx])).all()
 
 
+def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
+    """The square-root-free compressor (curve.hpp `dcb_finish`; reference: src/ark_curve/encoding.rs:91-128) works in
+    rounds of 32 elements per lane on the persistent grid (2 blocks x 256 lanes per CU).  Batch sizes that leave lanes
+    with 0, 1, 31, 32 and 33 elements, and one that needs a second round for some lanes only, must give the oracle's
+    bytes on the first, the last (second-round) and a spread of the records -- for the variable-base, the fixed-base
+    and the Elligator kernels, with invalid encodings and identity results sprinkled in."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    lanes = torch.cuda.get_device_properties(0).multi_processor_count * 2 * 256
+    g = torch.Generator(device=dev).manual_seed(9077)
+    for n in (lanes - 5, lanes + 7, 31 * lanes + 3, 32 * lanes, 32 * lanes + 4099):
+        r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+        k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+        enc = ctx.encode_to_curve(r0)
+        idx = np.unique(np.concatenate([np.arange(40), np.arange(n - 300, n), np.arange(17, n, max(1, n // 97))]))
+        ti = torch.from_numpy(idx).to(dev)
+        assert (enc[ti].cpu().numpy() == oracle.encode_to_curve(r0[ti].cpu().numpy())).all(), n
+        raw = enc.clone()
+        raw[ti[::7]] = 0xFF                             # invalid encodings (top bits set) inside the checked set
+        k[ti[3::11]] = 0                                # [0]P = identity: the all-zero encoding
+        out, st = ctx.scalar_mul_var(raw, k)
+        o_out, o_st = oracle.scalar_mul_var(raw[ti].cpu().numpy(), k[ti].cpu().numpy())
+        assert (out[ti].cpu().numpy() == o_out).all() and (st[ti].cpu().numpy() == o_st).all(), n
+        assert o_st.any() and not o_st.all()
+        fb = ctx.scalar_mul_base(k)
+        assert (fb[ti].cpu().numpy() == oracle.scalar_mul_base(k[ti].cpu().numpy())).all(), n
+        # in place: the output records double as the parking places of the prefix products
+        k2 = k.clone()
+        ctx.scalar_mul_base(k2, outs=[k2])
+        assert torch.equal(k2, fb), n
+
+
 def test_full_size_var_base_2_22(ctx, torch_mod, oracle):
     """BASELINE config 4 size on one GPU: 2^22 (point, scalar) pairs.  Property at full size:
     [k]P computed with scalars k and k + r (same class mod r, different bytes) must give identical
