@@ -215,6 +215,21 @@ void sim_raw_ge_sub(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* ou
     ge_raw4_to_words(ge_sub_pts(ge_from_raw_words(p + 32 * i), ge_from_raw_words(q + 32 * i)), out + 32 * i);
   }
 }
+// Fq inverse three ways on Montgomery-256 words: divsteps (fe_invert, what the kernels use), the x^(q-2) ladder and the
+// chain built from the square root's exponentiations
+void sim_invert(const uint32_t* a, size_t n, uint32_t* gcd, uint32_t* ladder, uint32_t* chain) {
+  for (size_t i = 0; i < n; ++i) {
+    const fe x = fe_from_mont256_words(a + 8 * i);
+    RegPowTab pt;
+    fe_to_mont256_words(fe_invert(x), gcd + 8 * i);
+    fe_to_mont256_words(fe_invert_pow(x), ladder + 8 * i);
+    fe_to_mont256_words(fe_invert_chain(x, pt), chain + 8 * i);
+  }
+}
+// the plain modular inverse on 29-bit limbs (integers in [0, q))
+void sim_modinv_limbs29(const uint32_t* x, size_t n, uint32_t* y) {
+  for (size_t i = 0; i < n; ++i) modinv_limbs29(x + 9 * i, y + 9 * i);
+}
 void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
     RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
