@@ -35,17 +35,18 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
               "sqrt_ratio_zeta": 97}
 # Field products (M, 153 v_mad_u64_u32 each) and squarings (S, 117) one element executes, counted by the
 # instrumented host build of the same headers (tests/test_host_sim.py::test_bench_mac_counts):
-# variable base = 1 square root (decompression: 288 S + 83 M with its extras) + the 9-entry table + 63 windows x
-# (4 doublings of 3 S + 4 M, + 1 M for T, + a 7 M cached addition) on k/2, + the state of the final doubling
-# (3 S + 5 M) + the square-root-free compression: 7 M per element and 1/32 of a divsteps inversion (inv30.hpp:
-# 20 rounds x 90 signed 64-bit MACs on 30-bit limbs, + 2 M) -- a lane inverts once per round of 32 elements, which is
-# what every lane has at 2^22 elements.  Fixed base is counted at the 8 elements per lane of the 2^20 extra.
-KERNEL_OPS = {"scalar_mul_var": (1673.0625, 1054.0), "roundtrip": (177, 580), "scalar_mul_base": (137.25, 3.0),
-              "sqrt_ratio_zeta": (83, 288)}
+# variable base = 1 square root (decompression, handed the inverse of its denominator: 242 S + 75 M with its extras)
+# + the 9-entry table + 63 windows x (4 doublings of 3 S + 4 M, + 1 M for T, + a 7 M cached addition) on k/2,
+# + the state of the final doubling (3 S + 5 M) + the square-root-free compression (7 M) + the two batched inversions
+# of a round (denominators, compressor: 3-4 M per element each, and one divsteps inversion per lane per 16 elements
+# each: inv30.hpp, 20 rounds x 90 signed 64-bit MACs on 30-bit limbs, + 2 M).  The 2^20 extras are counted at the
+# 8 elements per lane they have.
+KERNEL_OPS = {"scalar_mul_var": (1668.25, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (137.25, 3.0),
+              "sqrt_ratio_zeta": (75.25, 241.0)}
 MACS_PER_MUL, MACS_PER_SQR = 153, 117
 DIVSTEP_MACS_PER_INVERSION = 20 * 90                       # v_mad_i64_i32: update_fg_30 (36) + update_de_30 (54) per round
 KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR for k, (m, s) in KERNEL_OPS.items()}
-KERNEL_MACS["scalar_mul_var"] += DIVSTEP_MACS_PER_INVERSION / 32.0                            # 379351
+KERNEL_MACS["scalar_mul_var"] += 2 * DIVSTEP_MACS_PER_INVERSION / 16.0                        # 373520
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 # v_mad_u64_u32 issues one wave-instruction per 4 cycles per SIMD (16 lanes / cycle): 256 CUs x 4 SIMDs x 16
 # lanes x 2.4 GHz.  Measured on this chip: 3.74-3.80e13/s = 95-97 % of it, because the sustained clock under this
@@ -231,7 +232,7 @@ def main():
         "traffic": traffic,
         "traffic_source": traffic_source,
         "kernel_ms": kernel_ms,
-        "note": "integer-ALU-bound kernel: 3.8e5 32-bit MACs per 97 algorithmic bytes; see roofline_valu",
+        "note": "integer-ALU-bound kernel: 3.7e5 32-bit MACs per 97 algorithmic bytes; see roofline_valu",
     }
     macs = KERNEL_MACS["scalar_mul_var"] * n / (kernel_ms * 1e-3)
     line["roofline_valu"] = {

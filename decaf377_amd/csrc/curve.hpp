@@ -153,19 +153,31 @@ D377_HD bool fe_strict_is_zero(const fe& a) {
 // (src/min_curve/invsqrt.rs:11-95, seed 11^m) instead of the arkworks backend's Sarkar root: the two
 // differ by a sign that is a function of the discrete log t the table phase has already found
 // (constants.inc, D377_TS_U), so no second square root is computed.
+// inv_den: 1/den when the caller has it (the kernels invert the denominators of a lane's whole round at once,
+// dcb_invert_slot below); den = 0 may come with any inv_den.  invsqrt.rs:88-94 builds v = z^((m-1)/2) and
+// uv = z^((m+1)/2), z = num/den, WITHOUT an inversion -- s = den^(2^47-1), t = s^2 den, w = (num t)^((m-1)/2) s,
+// whose exponent of den is -(m+1)/2 modulo q - 1 -- at the price of the 46 S + 9 M chain for s; with 1/den at hand
+// the same two field values are z^((m-1)/2) and its product with z, and everything after them is unchanged.
 template <bool NUM_IS_ONE, class PT>
 D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, const fe& den, fe* res,
-                                bool min_curve_root = false) {
+                                bool min_curve_root = false, const fe* inv_den = nullptr) {
   const bool den_zero = fe_strict_is_zero(den);
   bool num_zero = false;
   if (!NUM_IS_ONE) num_zero = fe_strict_is_zero(num);
 
-  fe s = fe_pow_2_47_m1(den);                       // invsqrt.rs:88-89
-  fe t_ = fe_mul(fe_sqr(s), den);                   // :90
-  fe w = NUM_IS_ONE ? fe_mul(fe_pow_m12(t_, pt), s)     // :91
-                    : fe_mul(fe_pow_m12(fe_mul(num, t_), pt), s);
-  fe v = fe_mul(w, den);                            // :93
-  fe uv = NUM_IS_ONE ? w : fe_mul(w, num);          // :94
+  fe v, uv;
+  if (inv_den != nullptr) {
+    const fe z = NUM_IS_ONE ? *inv_den : fe_mul(num, *inv_den);
+    v = fe_pow_m12(z, pt);
+    uv = fe_mul(v, z);
+  } else {
+    fe s = fe_pow_2_47_m1(den);                       // invsqrt.rs:88-89
+    fe t_ = fe_mul(fe_sqr(s), den);                   // :90
+    fe w = NUM_IS_ONE ? fe_mul(fe_pow_m12(t_, pt), s)     // :91
+                      : fe_mul(fe_pow_m12(fe_mul(num, t_), pt), s);
+    v = fe_mul(w, den);                               // :93
+    uv = NUM_IS_ONE ? w : fe_mul(w, num);             // :94
+  }
   fe x5 = fe_mul(uv, v);                            // :97
   fe x4 = fe_sqr_n(x5, 8);                          // :101-107
   fe x3 = fe_sqr_n(x4, 8);
@@ -465,8 +477,15 @@ D377_HD bool ge_invariants_hold(const ge& p) {
 // ---- encoding ------------------------------------------------------------------------------
 // Encoding::vartime_decompress, src/ark_curve/encoding.rs:32-83.  Returns status
 // (0 ok, 1 InvalidEncoding); on failure *out is unspecified (callers write zeros).
+// the argument of decompression's square root, u2 u1^2 (encoding.rs:50-57), as a strict product
+D377_HD fe ge_decompress_den(const uint32_t w[8]) {
+  fe s = fe_mul(fe_from_words(w), fe_const(FE_R2));
+  fe ss = fe_sqr(s);
+  fe u1sq = fe_sqr_strict(fe_sub(fe_const(FE_ONE), ss));
+  return fe_mul_strict(fe_sub(u1sq, fe_mul(fe_const(FE_4D), ss)), u1sq);
+}
 template <class PT>
-D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8], ge* out) {
+D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8], ge* out, const fe* inv_den = nullptr) {
   uint32_t bad = (w[7] >> 29) != 0;                       // top three bits, encoding.rs:34
   bad |= (uint32_t)words_geq(w, FQ_MODULUS_W_LIT);        // canonical, :43-44
   bad |= (w[0] & 1u);                                     // s negative, :45
@@ -476,7 +495,7 @@ D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8],
   fe u1sq = fe_sqr_strict(u1);                            // strict: keeps den below 2q for the zero test
   fe u2 = fe_sub(u1sq, fe_mul(fe_const(FE_4D), ss));      // :54
   fe v;
-  const bool was_square = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(u2, u1sq), &v);   // :57
+  const bool was_square = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(u2, u1sq), &v, false, inv_den);   // :57
   bad |= (uint32_t)!was_square;                           // :58-60
   fe two_s_u1 = fe_mul(fe_dbl(s), u1);                    // :63
   if (fe_is_negative(fe_mul(two_s_u1, v))) v = fe_neg(v); // :64-67
@@ -489,15 +508,21 @@ D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8],
 }
 
 // Element::vartime_compress, src/ark_curve/encoding.rs:91-128 -> canonical words of s
+// the argument of compression's square root, u1 (a - d) X^2 (encoding.rs:97-101), as a strict product
+D377_HD fe ge_compress_den(const ge& p) {
+  fe u1 = fe_mul(fe_add(p.x, p.t), fe_sub(p.x, p.t));
+  return fe_mul_strict(fe_mul(u1, fe_const(FE_A_MINUS_D)), fe_sqr(p.x));
+}
 template <class PT>
-D377_HD void ge_compress(const SqrtTables& T, PT& pt, const ge& p, uint32_t w[8], bool is_element = true) {
+D377_HD void ge_compress(const SqrtTables& T, PT& pt, const ge& p, uint32_t w[8], bool is_element = true,
+                         const fe* inv_den = nullptr) {
   // every Element the reference can hold satisfies the invariants (Element::new); lanes that carry the
   // leftovers of a failed decompression pass is_element = false
   D377_INVARIANT(T, p, is_element);
   const fe a_minus_d = fe_const(FE_A_MINUS_D);
   fe u1 = fe_mul(fe_add(p.x, p.t), fe_sub(p.x, p.t));                       // :97
   fe v;
-  (void)fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(fe_mul(u1, a_minus_d), fe_sqr(p.x)), &v);  // :101
+  (void)fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(fe_mul(u1, a_minus_d), fe_sqr(p.x)), &v, false, inv_den);  // :101
   fe u2 = fe_abs(fe_mul(v, u1));                                            // :104
   fe u3 = fe_sub(fe_mul(u2, p.z), p.t);                                     // :107
   fe s = fe_mul(fe_mul(fe_mul(a_minus_d, v), u3), p.x);                     // :110
@@ -509,14 +534,21 @@ D377_HD void ge_compress(const SqrtTables& T, PT& pt, const ge& p, uint32_t w[8]
 
 // Element::elligator_map, src/ark_curve/elligator.rs:15-62.  r0 in Montgomery-261.
 // First half: the point (s, t) of the Jacobi quartic t^2 = (1 + a s^2)^2 - 4 d s^2 (elligator.rs:20-45).
+// the argument of the Elligator map's square root, num * den (elligator.rs:20-26), as a strict product
+D377_HD fe ge_elligator_den(const fe& r0) {
+  const fe one = fe_const(FE_ONE), dma = fe_const(FE_D_MINUS_A), dd = fe_const(FE_D);
+  fe r = fe_mul(fe_const(FE_ZETA), fe_sqr(r0));
+  fe den = fe_mul(fe_sub(fe_mul(dd, r), dma), fe_sub(fe_mul(dma, r), dd));
+  return fe_mul_strict(fe_mul(fe_add(r, one), fe_const(FE_A_MINUS_2D)), den);
+}
 template <class PT>
-D377_HD void ge_elligator_st(const SqrtTables& T, PT& pt, const fe& r0, fe* s_out, fe* t_out) {
+D377_HD void ge_elligator_st(const SqrtTables& T, PT& pt, const fe& r0, fe* s_out, fe* t_out, const fe* inv_den = nullptr) {
   const fe one = fe_const(FE_ONE), dma = fe_const(FE_D_MINUS_A), dd = fe_const(FE_D);
   fe r = fe_mul(fe_const(FE_ZETA), fe_sqr(r0));                                   // :20
   fe den = fe_mul(fe_sub(fe_mul(dd, r), dma), fe_sub(fe_mul(dma, r), dd));        // :22
   fe num = fe_mul(fe_add(r, one), fe_const(FE_A_MINUS_2D));                       // :23
   fe isri;
-  const bool iss = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(num, den), &isri);   // :25-26
+  const bool iss = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(num, den), &isri, false, inv_den);   // :25-26
   isri = fe_select(iss, isri, fe_mul(isri, r0));                                  // twiddle, :28-38
   fe s = fe_mul(isri, num);                                                       // :40
   fe p = fe_mul(fe_mul(fe_mul(isri, s), fe_sub(r, one)), fe_const(FE_A_MINUS_2D_SQ));
@@ -536,9 +568,9 @@ D377_HD ge ge_from_jacobi_st(const fe& s, const fe& t) {
   return o;
 }
 template <class PT>
-D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0) {
+D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0, const fe* inv_den = nullptr) {
   fe s, t;
-  ge_elligator_st(T, pt, r0, &s, &t);
+  ge_elligator_st(T, pt, r0, &s, &t, inv_den);
   ge o = ge_from_jacobi_st(s, t);
   D377_INVARIANT(T, o, true);                                                     // :56-59
   return o;
@@ -941,7 +973,7 @@ D377_HD void fr_half_words(uint32_t k[8]) {
 // reference's sqrt_ratio_zeta(1, 0) returns 0 and the encoding is 0) and failed lanes are stored as
 // p = 1, n0 = n1 = 0.  All four values are strict products (tight limbs, < 2q) and travel as 32-byte records.
 #ifndef D377_DCB_K
-#define D377_DCB_K 32
+#define D377_DCB_K 16
 #endif
 constexpr int DCB_K = D377_DCB_K;       // elements per lane per inversion
 #if defined(D377_CHECK_INVARIANTS)
@@ -997,6 +1029,49 @@ D377_HD void dcb_put(IO& io, int j, const dcb_state& st) {
   fe_to_words(st.n0, w); io.put(2, j, w);
   fe_to_words(st.n1, w); io.put(3, j, w);
 }
+// The denominators of a round's square roots, inverted together (see fe_sqrt_ratio_zeta, inv_den): records `slot`
+// hold strict products x_j (a zero is stored as 1: its lane takes the den = 0 exit of the square root whatever the
+// inverse says) and are replaced by 1 / x_j; records `tmp` hold the exclusive prefix products meanwhile -- not the
+// output records, which an in-place caller still needs as inputs at this point.
+constexpr int DCB_TMP_SLOT = 4;
+template <class IO>
+D377_HD void dcb_put_den(IO& io, int slot, int j, const fe& den) {
+  uint32_t w[8];
+  fe_to_words(fe_select(fe_strict_is_zero(den), fe_const(FE_ONE), den), w);
+  io.put(slot, j, w);
+}
+template <class IO>
+D377_HD fe dcb_get_inv(const IO& io, int slot, int j) {
+  uint32_t w[8];
+  io.get(slot, j, w);
+  return fe_from_words(w);
+}
+template <class IO>
+D377_HD void dcb_invert_slot(IO& io, int slot, int cnt) {
+  if (cnt <= 0) return;
+  uint32_t w[8];
+  fe c = fe_const(FE_ONE);
+#pragma unroll 1
+  for (int j = 0; j < cnt; ++j) {
+    fe_to_words(c, w);
+    io.put(DCB_TMP_SLOT, j, w);
+    io.get(slot, j, w);
+    c = fe_mul_strict(c, fe_from_words(w));
+  }
+  fe inv = fe_invert(c);
+#pragma unroll 1
+  for (int j = cnt - 1; j >= 0; --j) {
+    io.get(DCB_TMP_SLOT, j, w);
+    const fe inv_j = fe_mul_strict(inv, fe_from_words(w));
+    io.get(slot, j, w);
+    inv = fe_mul(inv, fe_from_words(w));
+    fe_to_words(inv_j, w);
+    io.put(slot, j, w);
+  }
+}
+
+// (Fetching the next element's records ahead of the current one's work, here and in the round driver, was measured
+// and bought nothing: the waits are already covered.)
 template <class PT, class IO>
 D377_HD void dcb_finish(PT& pt, IO& io, int cnt) {
   (void)pt;

@@ -62,9 +62,10 @@ struct FixedTab {
   }
 };
 
-// Round storage of the square-root-free compressor (curve.hpp, dcb_finish): [4 slots][DCB_K][lanes] 32-byte
-// records in global scratch, so that a wave reads and writes 2 KiB contiguous; the prefix products of the
-// batched inversion are parked in the output records of the elements they belong to.
+// Round storage of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish): [5 slots][DCB_K][lanes] 32-byte
+// records in global scratch, so that a wave reads and writes 2 KiB contiguous.  Slots 0..3: the denominators of the
+// round's square roots / their inverses, later the compressor's state; slot 4: prefix products.  The compressor
+// parks its prefix products in the output records of the elements they belong to.
 struct DcbIO {
   uint8_t* scratch;
   uint8_t* out32;
@@ -76,6 +77,41 @@ struct DcbIO {
   __device__ __forceinline__ void parked(int j, uint32_t w[8]) const { load32(out32, base + (size_t)j * nthreads, w); }
   __device__ __forceinline__ void emit(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * nthreads, w); }
 };
+constexpr int DCB_SLOTS = 5;
+
+// A lane's walk through the batch, on the persistent grid (<= 2 blocks per CU, so that every lane has its own round
+// records): rounds of DCB_K elements; phase 0 leaves the denominators of the round's square roots in records
+// 0 .. NINV-1, they are inverted together (one divsteps inversion per lane), phase 1 does the element's work with
+// those inverses, and when the operation ends in an encoding of a point whose isogeny preimage it knows (FINISH) the
+// square-root-free compressor closes the round.  The round counter is wave-uniform; only the lane index is per lane.
+// phase1(i, j, inv): inv[s] = the eight words of 1 / (denominator s of element j) (fe_from_words makes them a field element)
+template <int NINV, bool FINISH, class PT, class P0, class P1>
+__device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1) {
+  constexpr int NW = NINV > 0 ? NINV : 1;
+  const size_t per_round = (size_t)DCB_K * io.nthreads;
+  for (size_t round = 0; round * per_round < n; ++round) {
+    io.base = round * per_round + io.tid;
+    int cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < DCB_K; ++j) {
+      const size_t i = io.base + (size_t)j * io.nthreads;
+      if (i >= n) break;
+      if (NINV > 0) phase0(i, j);
+      cnt = j + 1;
+    }
+#pragma unroll 1
+    for (int sl = 0; sl < NINV; ++sl) dcb_invert_slot(io, sl, cnt);
+#pragma unroll 1
+    for (int j = 0; j < cnt; ++j) {
+      uint32_t cur[NW][8];
+#pragma unroll
+      for (int sl = 0; sl < NINV; ++sl) io.get(sl, j, cur[sl]);
+      phase1(io.base + (size_t)j * io.nthreads, j, cur);
+    }
+    if (FINISH) dcb_finish(pt, io, cnt);
+  }
+}
+#define D377_DCB_IO(out_ptr) DcbIO io{dcb, reinterpret_cast<uint8_t*>(out_ptr), (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0}
 
 // ------------------------------------------------------------------------- init kernels ---
 __device__ fe fe_pow_u32(const fe& x, uint32_t e) {   // e >= 1
@@ -166,23 +202,36 @@ __global__ void __launch_bounds__(BLOCK) k_init_fbase(uint32_t* fb) {
 }
 
 // --------------------------------------------------------------------------- batch kernels ---
+// Every kernel with a square root runs on the persistent grid and hands its square roots the inverses of their
+// denominators (dcb_rounds above).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtTables T, const uint8_t* num32,
                                                            const uint8_t* den32, size_t n,
-                                                           uint8_t* root32, uint8_t* was_square, int min_curve_root) {
+                                                           uint8_t* root32, uint8_t* was_square, int min_curve_root, uint8_t* dcb) {
   D377_POW_LDS();
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t wn[8], wd[8], wr[8];
-    load32(num32, i, wn);
-    load32(den32, i, wd);
-    fe r;
-    const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, fe_from_words_mod_order_strict(wn), fe_from_words_mod_order_strict(wd), &r,
-                                              min_curve_root != 0);
-    fe_to_bytes_words(r, wr);
-    store32(root32, i, wr);
-    was_square[i] = ws ? 1 : 0;
-  }
+  D377_DCB_IO(root32);
+  dcb_rounds<1, false>(n, io, pt,
+    [&](size_t i, int j) {
+      uint32_t wd[8];
+      load32(den32, i, wd);
+      dcb_put_den(io, 0, j, fe_from_words_mod_order_strict(wd));
+    },
+    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+      uint32_t wn[8], wd[8], wr[8];
+      load32(num32, i, wn);
+      load32(den32, i, wd);
+      const fe inv = fe_from_words(invw[0]);
+      fe r;
+      const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, fe_from_words_mod_order_strict(wn), fe_from_words_mod_order_strict(wd), &r,
+                                                min_curve_root != 0, &inv);
+      fe_to_bytes_words(r, wr);
+      store32(root32, i, wr);
+      was_square[i] = ws ? 1 : 0;
+    });
 }
 
+// decompress, compress and the round trip stay one element per lane on the wide grid, each square root in the
+// reference's inversion-free form: on the persistent grid with batched inverses they execute 4-8 % fewer instructions
+// but finish no sooner (measured, profiles/README.md) -- the oversubscribed grid keeps the issue port fuller.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
                                                       uint64_t* xyzt, uint8_t* status) {
   D377_POW_LDS();
@@ -211,6 +260,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_compress(SqrtTables T
   }
 }
 
+// decompress -> compress.  The compressor here is the generic one (its own square root, from the coordinates alone):
+// a round trip that used the encoding it was given as the point's known preimage would not compress anything.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_roundtrip(SqrtTables T, const uint8_t* enc32, size_t n,
                                                      uint8_t* out32, uint8_t* status) {
   D377_POW_LDS();
@@ -225,46 +276,55 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_roundtrip(SqrtTables 
   }
 }
 
-// The kernels below end in an encoding of a point whose isogeny preimage they know (a doubling, or the Elligator
-// map's (s, t)): they run on the persistent grid (<= 2 blocks per CU), each lane takes its elements in rounds of
-// DCB_K, leaves the four 32-byte state records of each in `dcb`, and finishes the round with one inversion.
+// The next kernels end in an encoding of a point whose isogeny preimage they know (a doubling, or the Elligator
+// map's (s, t)): each lane leaves the four 32-byte state records of its elements in `dcb` and the square-root-free
+// compressor finishes the round with one inversion.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtTables T, const uint8_t* fq32, size_t n,
                                                            uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
-  DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
-  const size_t per_round = (size_t)DCB_K * io.nthreads;
-  for (size_t round = 0; round * per_round < n; ++round) {          // wave-uniform: only the lane index lives in a VGPR
-    const size_t base = round * per_round + io.tid;
-    io.base = base;
-    int cnt = 0;
-#pragma unroll 1
-    for (int j = 0; j < DCB_K; ++j) {
-      const size_t i = base + (size_t)j * io.nthreads;
-      if (i >= n) break;
+  D377_DCB_IO(out32);
+  dcb_rounds<1, true>(n, io, pt,
+    [&](size_t i, int j) {
       uint32_t w[8];
       load32(fq32, i, w);
+      dcb_put_den(io, 0, j, ge_elligator_den(fe_from_words_mod_order(w)));
+    },
+    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+      uint32_t w[8];
+      load32(fq32, i, w);
+      const fe inv = fe_from_words(invw[0]);
       fe s, t;
-      ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s, &t);
+      ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s, &t, &inv);
       D377_INVARIANT(T, ge_from_jacobi_st(s, t), true);
       dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
-      cnt = j + 1;
-    }
-    dcb_finish(pt, io, cnt);
-  }
+    });
 }
 
+// two maps (their square roots take batched inverses), an addition, and the generic compressor: a sum of two points
+// has no known preimage
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTables T, const uint8_t* r1, const uint8_t* r2,
-                                                         size_t n, uint8_t* out32) {
+                                                         size_t n, uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t w[8];
-    load32(r1, i, w);
-    ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w));
-    load32(r2, i, w);
-    ge b = ge_elligator_map(T, pt, fe_from_words_mod_order(w));
-    ge_compress(T, pt, ge_add(a, b), w);
-    store32(out32, i, w);
-  }
+  D377_DCB_IO(out32);
+  dcb_rounds<2, false>(n, io, pt,
+    [&](size_t i, int j) {
+      uint32_t w[8];
+      load32(r1, i, w);
+      dcb_put_den(io, 0, j, ge_elligator_den(fe_from_words_mod_order(w)));
+      load32(r2, i, w);
+      dcb_put_den(io, 1, j, ge_elligator_den(fe_from_words_mod_order(w)));
+    },
+    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+      uint32_t w[8];
+      load32(r1, i, w);
+      fe inv = fe_from_words(invw[0]);
+      const ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv);
+      load32(r2, i, w);
+      inv = fe_from_words(invw[1]);
+      const ge b = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv);
+      ge_compress(T, pt, ge_add(a, b), w);
+      store32(out32, i, w);
+    });
 }
 
 // [k]P = [2]([k/2 mod r]P): the window loop runs on k/2 and the encoding is that of the double (no square root)
@@ -272,25 +332,24 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
                                                           const uint8_t* scalar32, size_t n, uint8_t* out32,
                                                           uint8_t* status, uint32_t* scratch, uint8_t* dcb) {
   D377_POW_LDS();
+  D377_DCB_IO(out32);
   GlobalTab tab;
   tab.base = scratch;
-  tab.nthreads = (size_t)gridDim.x * BLOCK;
-  tab.tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  DcbIO io{dcb, out32, tab.nthreads, tab.tid, 0};
-  const size_t per_round = (size_t)DCB_K * tab.nthreads;
-  for (size_t round = 0; round * per_round < n; ++round) {          // wave-uniform: only the lane index lives in a VGPR
-    const size_t base = round * per_round + tab.tid;
-    io.base = base;
-    int cnt = 0;
-#pragma unroll 1
-    for (int j = 0; j < DCB_K; ++j) {
-      const size_t i = base + (size_t)j * tab.nthreads;
-      if (i >= n) break;
+  tab.nthreads = io.nthreads;
+  tab.tid = io.tid;
+  dcb_rounds<1, true>(n, io, pt,
+    [&](size_t i, int j) {
+      uint32_t w[8];
+      load32(enc32, i, w);
+      dcb_put_den(io, 0, j, ge_decompress_den(w));
+    },
+    [&](size_t i, int j, const uint32_t (*invw)[8]) {
       uint32_t w[8], k[8], dg[8];
       load32(enc32, i, w);
       load32(scalar32, i, k);
+      const fe inv = fe_from_words(invw[0]);
       ge g;
-      const uint32_t bad = ge_decompress(T, pt, w, &g);
+      const uint32_t bad = ge_decompress(T, pt, w, &g, &inv);
       status[i] = (uint8_t)bad;
       fr_reduce_words(k);
       fr_half_words(k);
@@ -298,26 +357,17 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
       const ge r = ge_scalar_mul_w4(g, dg, tab, DCB_WANT_T);
       D377_INVARIANT(T, r, bad == 0);
       dcb_put(io, j, ge_dcb_from_half(r, bad != 0));      // failed lanes: neutral state, all-zero output
-      cnt = j + 1;
-    }
-    dcb_finish(pt, io, cnt);
-  }
+    });
 }
 
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
                                                            const uint8_t* scalar32, size_t n, uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
+  D377_DCB_IO(out32);
   FixedTab ft{fbase};
-  DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
-  const size_t per_round = (size_t)DCB_K * io.nthreads;
-  for (size_t round = 0; round * per_round < n; ++round) {          // wave-uniform: only the lane index lives in a VGPR
-    const size_t base = round * per_round + io.tid;
-    io.base = base;
-    int cnt = 0;
-#pragma unroll 1
-    for (int j = 0; j < DCB_K; ++j) {
-      const size_t i = base + (size_t)j * io.nthreads;
-      if (i >= n) break;
+  dcb_rounds<0, true>(n, io, pt,
+    [&](size_t, int) {},
+    [&](size_t i, int j, const uint32_t (*)[8]) {
       uint32_t k[8];
       load32(scalar32, i, k);
       fr_reduce_words(k);
@@ -325,10 +375,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
       const ge r = ge_scalar_mul_base_w8(k, ft, DCB_WANT_T);
       D377_INVARIANT(T, r, true);
       dcb_put(io, j, ge_dcb_from_half(r, false));
-      cnt = j + 1;
-    }
-    dcb_finish(pt, io, cnt);
-  }
+    });
 }
 
 // The reference's own signatures for these operations take and return Elements (`Element * Fr`,
@@ -372,18 +419,29 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_compress_to_field(Sqr
 }
 // second input null: encode_to_curve; otherwise hash_to_curve (two maps and an addition)
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_map_to_element(SqrtTables T, const uint8_t* r1, const uint8_t* r2, size_t n,
-                                                                          uint64_t* out) {
+                                                                          uint64_t* out, uint8_t* dcb) {
   D377_POW_LDS();
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t w[8];
-    load32(r1, i, w);
-    ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w));
-    if (r2) {
-      load32(r2, i, w);
-      a = ge_add(a, ge_elligator_map(T, pt, fe_from_words_mod_order(w)));
-    }
-    store_ge_mont256(out, i, a);
-  }
+  D377_DCB_IO(out);
+  dcb_rounds<2, false>(n, io, pt,
+    [&](size_t i, int j) {
+      uint32_t w[8];
+      load32(r1, i, w);
+      dcb_put_den(io, 0, j, ge_elligator_den(fe_from_words_mod_order(w)));
+      if (r2) load32(r2, i, w);                            // without a second input slot 1 repeats slot 0 (unused)
+      dcb_put_den(io, 1, j, ge_elligator_den(fe_from_words_mod_order(w)));
+    },
+    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+      uint32_t w[8];
+      load32(r1, i, w);
+      fe inv = fe_from_words(invw[0]);
+      ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv);
+      if (r2) {
+        load32(r2, i, w);
+        inv = fe_from_words(invw[1]);
+        a = ge_add(a, ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv));
+      }
+      store_ge_mont256(out, i, a);
+    });
 }
 
 // wide byte strings (48 or 64 bytes per record) -> Fq, optionally straight into the Elligator map
@@ -410,24 +468,16 @@ __global__ void __launch_bounds__(BLOCK) k_fq_from_wide(const uint8_t* in, int l
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(SqrtTables T, const uint8_t* in, int len,
                                                                                 size_t n, uint8_t* out32, uint8_t* dcb) {
   D377_POW_LDS();
-  DcbIO io{dcb, out32, (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0};
-  const size_t per_round = (size_t)DCB_K * io.nthreads;
-  for (size_t round = 0; round * per_round < n; ++round) {          // wave-uniform: only the lane index lives in a VGPR
-    const size_t base = round * per_round + io.tid;
-    io.base = base;
-    int cnt = 0;
-#pragma unroll 1
-    for (int j = 0; j < DCB_K; ++j) {
-      const size_t i = base + (size_t)j * io.nthreads;
-      if (i >= n) break;
+  D377_DCB_IO(out32);
+  dcb_rounds<1, true>(n, io, pt,
+    [&](size_t i, int j) { dcb_put_den(io, 0, j, ge_elligator_den(fe_carry(load_wide(in, i, len)))); },
+    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+      const fe inv = fe_from_words(invw[0]);
       fe s, t;
-      ge_elligator_st(T, pt, fe_carry(load_wide(in, i, len)), &s, &t);
+      ge_elligator_st(T, pt, fe_carry(load_wide(in, i, len)), &s, &t, &inv);
       D377_INVARIANT(T, ge_from_jacobi_st(s, t), true);
       dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
-      cnt = j + 1;
-    }
-    dcb_finish(pt, io, cnt);
-  }
+    });
 }
 // (x/z, y/z) as Montgomery-256 limbs: CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81), with
 // the batched inversion that name implies (Montgomery's trick).  A lane walks its grid-stride elements
@@ -683,8 +733,8 @@ int init_device(DeviceState& d) {
   // variable-base window tables: one per resident lane, fixed grid, grid-stride over the batch
   d.vb_blocks = d.cus * WAVES_PER_SIMD;        // exactly the resident blocks: 2 per CU
   HIP_TRY(hipMalloc(&d.vb_scratch, (size_t)d.vb_blocks * BLOCK * VB_ENTRIES * VB_ENTRY_WORDS * sizeof(uint32_t)));
-  // round records of the square-root-free compressor: 4 x DCB_K 32-byte records per resident lane (512 MiB)
-  HIP_TRY(hipMalloc(&d.dcb_scratch, (size_t)d.vb_blocks * BLOCK * 4 * DCB_K * 32));
+  // round records of the batched inversions: DCB_SLOTS x DCB_K 32-byte records per resident lane (320 MiB)
+  HIP_TRY(hipMalloc(&d.dcb_scratch, (size_t)d.vb_blocks * BLOCK * DCB_SLOTS * DCB_K * 32));
   uint32_t* keys = nullptr;
   int* coll = nullptr;
   HIP_TRY(hipMalloc(&keys, 512 * sizeof(uint32_t)));
@@ -726,9 +776,14 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
   const int gv = g < d.vb_blocks ? g : d.vb_blocks;   // the persistent grid: exactly the resident blocks
   int rc;
   switch (op) {
+    // Every kernel with a square root or an encoding keeps per-lane state in scratch areas that exist once per device
+    // (round records of the batched inversions, window tables): never more lanes than those areas have (gv), and each
+    // launch queues behind the areas' last user.
     case OP_SQRT:
-      hipLaunchKernelGGL(k_sqrt_ratio_zeta, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
-                         (uint8_t*)out0, (uint8_t*)out1, aux);
+      if ((rc = d.vb_guard.acquire(s))) return rc;
+      hipLaunchKernelGGL(k_sqrt_ratio_zeta, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                         (uint8_t*)out0, (uint8_t*)out1, aux, d.dcb_scratch);
+      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_DECOMPRESS:
       hipLaunchKernelGGL(k_decompress, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint64_t*)out0, (uint8_t*)out1);
@@ -739,9 +794,6 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     case OP_ROUNDTRIP:
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
       break;
-    // The next four keep per-lane state in scratch areas that exist once per device (window tables, round records of
-    // the square-root-free compressor): never more lanes than those areas have, and each launch queues behind the
-    // areas' last user.
     case OP_MUL_BASE:
       if ((rc = d.vb_guard.acquire(s))) return rc;
       hipLaunchKernelGGL(k_scalar_mul_base, dim3(gv), dim3(BLOCK), 0, s, T, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0,
@@ -760,8 +812,10 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_HASH:
-      hipLaunchKernelGGL(k_hash_to_curve, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
-                         (uint8_t*)out0);
+      if ((rc = d.vb_guard.acquire(s))) return rc;
+      hipLaunchKernelGGL(k_hash_to_curve, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                         (uint8_t*)out0, d.dcb_scratch);
+      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_ADD:
       hipLaunchKernelGGL(k_add, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint64_t*)in1, n, (uint64_t*)out0, aux);
@@ -831,10 +885,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_compress_to_field, dim3(g), dim3(BLOCK), 0, s, T, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_ENCODE_EL:
-      hipLaunchKernelGGL(k_map_to_element, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)nullptr, n, (uint64_t*)out0);
-      break;
     case OP_HASH_EL:
-      hipLaunchKernelGGL(k_map_to_element, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n, (uint64_t*)out0);
+      if ((rc = d.vb_guard.acquire(s))) return rc;
+      hipLaunchKernelGGL(k_map_to_element, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
+                         op == OP_HASH_EL ? (const uint8_t*)in1 : (const uint8_t*)nullptr, n, (uint64_t*)out0, d.dcb_scratch);
+      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_FR_BIN:
     case OP_FR_UN:

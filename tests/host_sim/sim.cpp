@@ -42,7 +42,7 @@ struct HostFTab {
 // the square-root-free compression of the scalar-multiplication and Elligator kernels (curve.hpp, "compression
 // without a square root"): one host "lane" walks the batch in rounds of DCB_K elements, as a device lane does
 struct HostDcbIO {
-  uint32_t st[4][DCB_K][8];
+  uint32_t st[5][DCB_K][8];
   uint32_t* out;
   size_t base;
   void put(int s, int j, const uint32_t* w) { memcpy(st[s][j], w, 32); }
@@ -51,14 +51,18 @@ struct HostDcbIO {
   void parked(int j, uint32_t* w) const { memcpy(w, out + 8 * (base + j), 32); }
   void emit(int j, const uint32_t* w) { memcpy(out + 8 * (base + j), w, 32); }
 };
-template <class F>
-static void dcb_rounds(size_t n, uint32_t* out, F state_of) {
+// the kernels' round structure (d377.hip, dcb_rounds): phase 0 leaves the denominators of the round's square roots in
+// records 0 .. NINV-1, they are inverted together, phase 1 does the element's work with the inverses at hand, and the
+// square-root-free compressor finishes the round when the operation ends in an encoding it can produce
+template <int NINV, class P0, class P1>
+static void dcb_rounds(size_t n, uint32_t* out, bool finish, P0 phase0, P1 phase1) {
   for (size_t base = 0; base < n; base += DCB_K) {
     HostDcbIO io; io.out = out; io.base = base;
     const int cnt = (int)((n - base) < (size_t)DCB_K ? (n - base) : (size_t)DCB_K);
-    for (int j = 0; j < cnt; ++j) dcb_put(io, j, state_of(base + j));
-    RegPowTab pt;
-    dcb_finish(pt, io, cnt);
+    for (int j = 0; j < cnt; ++j) phase0(io, base + j, j);
+    for (int sl = 0; sl < NINV; ++sl) dcb_invert_slot(io, sl, cnt);
+    for (int j = 0; j < cnt; ++j) phase1(io, base + j, j);
+    if (finish) { RegPowTab pt; dcb_finish(pt, io, cnt); }
   }
 }
 
@@ -159,6 +163,16 @@ void sim_raw_canon(const uint32_t* a, size_t n, uint32_t* out) {
 void sim_consts(uint32_t* sub16q, uint32_t* sub16q_nc, uint32_t* ql) { for (int i = 0; i < NL; ++i) { sub16q[i] = SUB32Q[i]; sub16q_nc[i] = SUB16Q_NC[i]; ql[i] = QL[i]; } }
 
 void sim_sqrt_ratio_zeta(const uint32_t* num, const uint32_t* den, size_t n, uint32_t* root, uint8_t* ws) {
+  dcb_rounds<1>(n, root, false,
+    [&](HostDcbIO& io, size_t i, int j) { dcb_put_den(io, 0, j, fe_from_words_mod_order_strict(den + 8 * i)); },
+    [&](HostDcbIO& io, size_t i, int j) {
+      const fe inv = dcb_get_inv(io, 0, j);
+      RegPowTab pt; fe r; bool w = fe_sqrt_ratio_zeta<false>(g_T, pt, fe_from_words_mod_order_strict(num + 8 * i), fe_from_words_mod_order_strict(den + 8 * i), &r, false, &inv);
+      fe_to_bytes_words(r, root + 8 * i); ws[i] = w;
+    });
+}
+// the reference's own inversion-free form (invsqrt.rs:88-94), element by element
+void sim_sqrt_ratio_zeta_plain(const uint32_t* num, const uint32_t* den, size_t n, uint32_t* root, uint8_t* ws) {
   for (size_t i = 0; i < n; ++i) {
     RegPowTab pt; fe r; bool w = fe_sqrt_ratio_zeta<false>(g_T, pt, fe_from_words_mod_order_strict(num + 8 * i), fe_from_words_mod_order_strict(den + 8 * i), &r);
     fe_to_bytes_words(r, root + 8 * i); ws[i] = w;
@@ -230,32 +244,53 @@ void sim_invert(const uint32_t* a, size_t n, uint32_t* gcd, uint32_t* ladder, ui
 void sim_modinv_limbs29(const uint32_t* x, size_t n, uint32_t* y) {
   for (size_t i = 0; i < n; ++i) modinv_limbs29(x + 9 * i, y + 9 * i);
 }
-void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
-  for (size_t i = 0; i < n; ++i) {
-    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
-    st[i] = (uint8_t)bad;
-    if (bad) memset(xyzt + 32 * i, 0, 128); else ge_store256(g, xyzt + 32 * i);
-  }
+// decompression / compression / round trip with batched inverses for their square roots (the form the variable-base
+// kernel uses for its decompression; the stand-alone kernels keep the inversion-free form, see d377.hip)
+void sim_decompress_assisted(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
+  std::vector<uint32_t> dummy(8 * (n + 1));
+  dcb_rounds<1>(n, dummy.data(), false,
+    [&](HostDcbIO& io, size_t i, int j) { dcb_put_den(io, 0, j, ge_decompress_den(enc + 8 * i)); },
+    [&](HostDcbIO& io, size_t i, int j) {
+      const fe inv = dcb_get_inv(io, 0, j);
+      RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g, &inv);
+      st[i] = (uint8_t)bad;
+      if (bad) memset(xyzt + 32 * i, 0, 128); else ge_store256(g, xyzt + 32 * i);
+    });
 }
+void sim_compress_assisted(const uint32_t* xyzt, size_t n, uint32_t* enc) {
+  dcb_rounds<1>(n, enc, false,
+    [&](HostDcbIO& io, size_t i, int j) { dcb_put_den(io, 0, j, ge_compress_den(ge_load256(xyzt + 32 * i))); },
+    [&](HostDcbIO& io, size_t i, int j) {
+      const fe inv = dcb_get_inv(io, 0, j);
+      RegPowTab pt; ge_compress(g_T, pt, ge_load256(xyzt + 32 * i), enc + 8 * i, true, &inv);
+    });
+}
+// the kernels' form: one element at a time, inversion-free square roots
 void sim_compress(const uint32_t* xyzt, size_t n, uint32_t* enc) {
   for (size_t i = 0; i < n; ++i) { RegPowTab pt; ge_compress(g_T, pt, ge_load256(xyzt + 32 * i), enc + 8 * i); }
 }
-void sim_roundtrip(const uint32_t* enc, size_t n, uint32_t* out, uint8_t* st) {
-  for (size_t i = 0; i < n; ++i) {
-    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
-    st[i] = (uint8_t)bad;
-    if (bad) memset(out + 8 * i, 0, 32); else ge_compress(g_T, pt, g, out + 8 * i);
-  }
+void sim_roundtrip_assisted(const uint32_t* enc, size_t n, uint32_t* out, uint8_t* st) {
+  dcb_rounds<1>(n, out, false,
+    [&](HostDcbIO& io, size_t i, int j) { dcb_put_den(io, 0, j, ge_decompress_den(enc + 8 * i)); },
+    [&](HostDcbIO& io, size_t i, int j) {
+      const fe inv = dcb_get_inv(io, 0, j);
+      RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g, &inv);
+      st[i] = (uint8_t)bad;
+      if (bad) memset(out + 8 * i, 0, 32); else ge_compress(g_T, pt, g, out + 8 * i);
+    });
 }
 void sim_encode_to_curve(const uint32_t* r0, size_t n, uint32_t* enc, uint32_t* xyzt) {
-  dcb_rounds(n, enc, [&](size_t i) {
-    RegPowTab pt; fe s, t;
-    ge_elligator_st(g_T, pt, fe_from_words_mod_order(r0 + 8 * i), &s, &t);
-    if (xyzt) ge_store256(ge_from_jacobi_st(s, t), xyzt + 32 * i);
-    return ge_dcb_from_jacobi_st(s, t);
-  });
+  dcb_rounds<1>(n, enc, true,
+    [&](HostDcbIO& io, size_t i, int j) { dcb_put_den(io, 0, j, ge_elligator_den(fe_from_words_mod_order(r0 + 8 * i))); },
+    [&](HostDcbIO& io, size_t i, int j) {
+      const fe inv = dcb_get_inv(io, 0, j);
+      RegPowTab pt; fe s, t;
+      ge_elligator_st(g_T, pt, fe_from_words_mod_order(r0 + 8 * i), &s, &t, &inv);
+      if (xyzt) ge_store256(ge_from_jacobi_st(s, t), xyzt + 32 * i);
+      dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
+    });
 }
-// the same through the generic compressor (one square root more per element): what hash_to_curve and compress use
+// the same through the generic compressor and the inversion-free square roots
 void sim_encode_to_curve_sqrt(const uint32_t* r0, size_t n, uint32_t* enc) {
   for (size_t i = 0; i < n; ++i) {
     RegPowTab pt;
@@ -263,13 +298,16 @@ void sim_encode_to_curve_sqrt(const uint32_t* r0, size_t n, uint32_t* enc) {
   }
 }
 void sim_scalar_mul_var(const uint32_t* enc, const uint32_t* k, size_t n, uint32_t* out, uint8_t* st) {
-  dcb_rounds(n, out, [&](size_t i) {
-    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
-    st[i] = (uint8_t)bad;
-    uint32_t kk[8], dg[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_half_words(kk); fr_recode_signed16(kk, dg);
-    HostTab tab; ge r = ge_scalar_mul_w4(g, dg, tab, DCB_WANT_T);  // [k/2]P; the state is that of its double
-    return ge_dcb_from_half(r, bad != 0);
-  });
+  dcb_rounds<1>(n, out, true,
+    [&](HostDcbIO& io, size_t i, int j) { dcb_put_den(io, 0, j, ge_decompress_den(enc + 8 * i)); },
+    [&](HostDcbIO& io, size_t i, int j) {
+      const fe inv = dcb_get_inv(io, 0, j);
+      RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g, &inv);
+      st[i] = (uint8_t)bad;
+      uint32_t kk[8], dg[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_half_words(kk); fr_recode_signed16(kk, dg);
+      HostTab tab; ge r = ge_scalar_mul_w4(g, dg, tab, DCB_WANT_T);  // [k/2]P; the state is that of its double
+      dcb_put(io, j, ge_dcb_from_half(r, bad != 0));
+    });
 }
 void sim_scalar_mul_var_sqrt(const uint32_t* enc, const uint32_t* k, size_t n, uint32_t* out, uint8_t* st) {
   for (size_t i = 0; i < n; ++i) {
@@ -283,10 +321,41 @@ void sim_scalar_mul_var_sqrt(const uint32_t* enc, const uint32_t* k, size_t n, u
 }
 void sim_scalar_mul_base(const uint32_t* k, size_t n, uint32_t* out) {
   HostFTab ft{g_fbase.data()};
-  dcb_rounds(n, out, [&](size_t i) {
-    uint32_t kk[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_half_words(kk);
-    return ge_dcb_from_half(ge_scalar_mul_base_w8(kk, ft, DCB_WANT_T), false);
-  });
+  dcb_rounds<0>(n, out, true,
+    [&](HostDcbIO&, size_t, int) {},
+    [&](HostDcbIO& io, size_t i, int j) {
+      uint32_t kk[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_half_words(kk);
+      dcb_put(io, j, ge_dcb_from_half(ge_scalar_mul_base_w8(kk, ft, DCB_WANT_T), false));
+    });
+}
+void sim_decompress(const uint32_t* enc, size_t n, uint32_t* xyzt, uint8_t* st) {
+  for (size_t i = 0; i < n; ++i) {
+    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
+    st[i] = (uint8_t)bad;
+    if (bad) memset(xyzt + 32 * i, 0, 128); else ge_store256(g, xyzt + 32 * i);
+  }
+}
+void sim_roundtrip(const uint32_t* enc, size_t n, uint32_t* out, uint8_t* st) {
+  for (size_t i = 0; i < n; ++i) {
+    RegPowTab pt; ge g; uint32_t bad = ge_decompress(g_T, pt, enc + 8 * i, &g);
+    st[i] = (uint8_t)bad;
+    if (bad) memset(out + 8 * i, 0, 32); else ge_compress(g_T, pt, g, out + 8 * i);
+  }
+}
+// hash_to_curve: two Elligator maps (their two square roots take batched inverses), an addition, the generic compressor
+void sim_hash_to_curve(const uint32_t* r1, const uint32_t* r2, size_t n, uint32_t* enc) {
+  dcb_rounds<2>(n, enc, false,
+    [&](HostDcbIO& io, size_t i, int j) {
+      dcb_put_den(io, 0, j, ge_elligator_den(fe_from_words_mod_order(r1 + 8 * i)));
+      dcb_put_den(io, 1, j, ge_elligator_den(fe_from_words_mod_order(r2 + 8 * i)));
+    },
+    [&](HostDcbIO& io, size_t i, int j) {
+      const fe i1 = dcb_get_inv(io, 0, j), i2 = dcb_get_inv(io, 1, j);
+      RegPowTab pt;
+      ge a = ge_elligator_map(g_T, pt, fe_from_words_mod_order(r1 + 8 * i), &i1);
+      ge b = ge_elligator_map(g_T, pt, fe_from_words_mod_order(r2 + 8 * i), &i2);
+      ge_compress(g_T, pt, ge_add(a, b), enc + 8 * i);
+    });
 }
 void sim_fr_half(const uint32_t* k, size_t n, uint32_t* out) {
   for (size_t i = 0; i < n; ++i) { memcpy(out + 8 * i, k + 8 * i, 32); fr_reduce_words(out + 8 * i); fr_half_words(out + 8 * i); }
