@@ -38,15 +38,15 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
 # variable base = 1 square root (decompression, handed the inverse of its denominator: 242 S + 75 M with its extras)
 # + the 9-entry table + 63 windows x (4 doublings of 3 S + 4 M, + 1 M for T, + a 7 M cached addition) on k/2,
 # + the state of the final doubling (3 S + 5 M) + the square-root-free compression (7 M) + the two batched inversions
-# of a round (denominators, compressor: 3-4 M per element each, and one divsteps inversion per lane per 16 elements
+# of a chunk (denominators, compressor: 3-4 M per element each, and one divsteps inversion per lane per 8 elements
 # each: inv30.hpp, 20 rounds x 90 signed 64-bit MACs on 30-bit limbs, + 2 M).  The 2^20 extras are counted at the
 # 8 elements per lane they have.
-KERNEL_OPS = {"scalar_mul_var": (1668.25, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (137.25, 3.0),
+KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (137.25, 3.0),
               "sqrt_ratio_zeta": (75.25, 241.0)}
 MACS_PER_MUL, MACS_PER_SQR = 153, 117
 DIVSTEP_MACS_PER_INVERSION = 20 * 90                       # v_mad_i64_i32: update_fg_30 (36) + update_de_30 (54) per round
 KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR for k, (m, s) in KERNEL_OPS.items()}
-KERNEL_MACS["scalar_mul_var"] += 2 * DIVSTEP_MACS_PER_INVERSION / 16.0                        # 373520
+KERNEL_MACS["scalar_mul_var"] += 2 * DIVSTEP_MACS_PER_INVERSION / 8.0                         # 373784
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 # v_mad_u64_u32 issues one wave-instruction per 4 cycles per SIMD (16 lanes / cycle): 256 CUs x 4 SIMDs x 16
 # lanes x 2.4 GHz.  Measured on this chip: 3.74-3.80e13/s = 95-97 % of it, because the sustained clock under this

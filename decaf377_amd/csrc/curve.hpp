@@ -973,7 +973,7 @@ D377_HD void fr_half_words(uint32_t k[8]) {
 // reference's sqrt_ratio_zeta(1, 0) returns 0 and the encoding is 0) and failed lanes are stored as
 // p = 1, n0 = n1 = 0.  All four values are strict products (tight limbs, < 2q) and travel as 32-byte records.
 #ifndef D377_DCB_K
-#define D377_DCB_K 16
+#define D377_DCB_K 8
 #endif
 constexpr int DCB_K = D377_DCB_K;       // elements per lane per inversion
 #if defined(D377_CHECK_INVARIANTS)

@@ -66,35 +66,66 @@ struct FixedTab {
 // records in global scratch, so that a wave reads and writes 2 KiB contiguous.  Slots 0..3: the denominators of the
 // round's square roots / their inverses, later the compressor's state; slot 4: prefix products.  The compressor
 // parks its prefix products in the output records of the elements they belong to.
+//
+// The areas (these records, the variable-base window tables) exist once per RESIDENT lane -- 2 workgroups per CU --
+// but the grid is oversubscribed: a workgroup takes one chunk of DCB_K x 256 consecutive elements (DCB_K per lane)
+// and there are as many workgroups as chunks.  Measured at 2^22 variable-base elements: 64.2 ms with exactly the
+// resident workgroups walking 32 elements per lane each, 61.4 ms with four generations of workgroups of 8 per lane,
+// although the latter pays four times as many inversions (profiles/README.md).  A workgroup therefore claims one of
+// the area's `nslots` lane sets when it starts (an atomic on a small pool) and frees it when it is done; LDS keeps
+// at most `nslots` workgroups resident, so a free set always exists.
+struct DcbScratch {
+  uint8_t* rec;        // [DCB_SLOTS][DCB_K][nslots * BLOCK] 32-byte records
+  int* pool;           // nslots flags, 0 = free (cleared by the host before every launch)
+  int nslots;
+};
 struct DcbIO {
   uint8_t* scratch;
   uint8_t* out32;
-  size_t nthreads, tid, base;           // the round's j-th element is record base + j * nthreads
-  __device__ __forceinline__ size_t rec(int slot, int j) const { return (size_t)(slot * DCB_K + j) * nthreads + tid; }
-  __device__ __forceinline__ void put(int slot, int j, const uint32_t w[8]) { store32(scratch, rec(slot, j), w); }
-  __device__ __forceinline__ void get(int slot, int j, uint32_t w[8]) const { load32(scratch, rec(slot, j), w); }
-  __device__ __forceinline__ void park(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * nthreads, w); }
-  __device__ __forceinline__ void parked(int j, uint32_t w[8]) const { load32(out32, base + (size_t)j * nthreads, w); }
-  __device__ __forceinline__ void emit(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * nthreads, w); }
+  size_t nlanes, lane, base;            // lane of the claimed set; the chunk's j-th element of this lane is record base + j * BLOCK
+  int slot;
+  __device__ __forceinline__ size_t rec(int sl, int j) const { return (size_t)(sl * DCB_K + j) * nlanes + lane; }
+  __device__ __forceinline__ void put(int sl, int j, const uint32_t w[8]) { store32(scratch, rec(sl, j), w); }
+  __device__ __forceinline__ void get(int sl, int j, uint32_t w[8]) const { load32(scratch, rec(sl, j), w); }
+  __device__ __forceinline__ void park(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * BLOCK, w); }
+  __device__ __forceinline__ void parked(int j, uint32_t w[8]) const { load32(out32, base + (size_t)j * BLOCK, w); }
+  __device__ __forceinline__ void emit(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * BLOCK, w); }
 };
 constexpr int DCB_SLOTS = 5;
 
-// A lane's walk through the batch, on the persistent grid (<= 2 blocks per CU, so that every lane has its own round
-// records): rounds of DCB_K elements; phase 0 leaves the denominators of the round's square roots in records
-// 0 .. NINV-1, they are inverted together (one divsteps inversion per lane), phase 1 does the element's work with
-// those inverses, and when the operation ends in an encoding of a point whose isogeny preimage it knows (FINISH) the
-// square-root-free compressor closes the round.  The round counter is wave-uniform; only the lane index is per lane.
+__device__ __forceinline__ int dcb_claim(const DcbScratch& sc) {
+  __shared__ int s_slot;
+  if (threadIdx.x == 0) {
+    int s = (int)(blockIdx.x % (unsigned)sc.nslots);
+    while (atomicCAS(&sc.pool[s], 0, 1) != 0) s = s + 1 == sc.nslots ? 0 : s + 1;
+    s_slot = s;
+  }
+  __syncthreads();
+  return s_slot;
+}
+__device__ __forceinline__ void dcb_release(const DcbScratch& sc, int slot) {
+  __syncthreads();                       // every lane of the workgroup is done with the set
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicExch(&sc.pool[slot], 0);
+  }
+}
+
+// A workgroup's walk through its chunks (normally one): phase 0 leaves the denominators of the chunk's square roots
+// in records 0 .. NINV-1, they are inverted together (one divsteps inversion per lane), phase 1 does the element's
+// work with those inverses, and when the operation ends in an encoding of a point whose isogeny preimage it knows
+// (FINISH) the square-root-free compressor closes the chunk.
 // phase1(i, j, inv): inv[s] = the eight words of 1 / (denominator s of element j) (fe_from_words makes them a field element)
 template <int NINV, bool FINISH, class PT, class P0, class P1>
 __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1) {
   constexpr int NW = NINV > 0 ? NINV : 1;
-  const size_t per_round = (size_t)DCB_K * io.nthreads;
-  for (size_t round = 0; round * per_round < n; ++round) {
-    io.base = round * per_round + io.tid;
+  constexpr size_t CHUNK = (size_t)DCB_K * BLOCK;
+  for (size_t chunk = blockIdx.x; chunk * CHUNK < n; chunk += gridDim.x) {
+    io.base = chunk * CHUNK + threadIdx.x;
     int cnt = 0;
 #pragma unroll 1
     for (int j = 0; j < DCB_K; ++j) {
-      const size_t i = io.base + (size_t)j * io.nthreads;
+      const size_t i = io.base + (size_t)j * BLOCK;
       if (i >= n) break;
       if (NINV > 0) phase0(i, j);
       cnt = j + 1;
@@ -106,12 +137,16 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
       uint32_t cur[NW][8];
 #pragma unroll
       for (int sl = 0; sl < NINV; ++sl) io.get(sl, j, cur[sl]);
-      phase1(io.base + (size_t)j * io.nthreads, j, cur);
+      phase1(io.base + (size_t)j * BLOCK, j, cur);
     }
     if (FINISH) dcb_finish(pt, io, cnt);
   }
 }
-#define D377_DCB_IO(out_ptr) DcbIO io{dcb, reinterpret_cast<uint8_t*>(out_ptr), (size_t)gridDim.x * BLOCK, (size_t)blockIdx.x * BLOCK + threadIdx.x, 0}
+#define D377_DCB_BEGIN(out_ptr)                                                                   \
+  const int dcb_slot_ = dcb_claim(dcb);                                                           \
+  DcbIO io{dcb.rec, reinterpret_cast<uint8_t*>(out_ptr), (size_t)dcb.nslots * BLOCK,             \
+           (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_}
+#define D377_DCB_END() dcb_release(dcb, dcb_slot_)
 
 // ------------------------------------------------------------------------- init kernels ---
 __device__ fe fe_pow_u32(const fe& x, uint32_t e) {   // e >= 1
@@ -206,9 +241,9 @@ __global__ void __launch_bounds__(BLOCK) k_init_fbase(uint32_t* fb) {
 // denominators (dcb_rounds above).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtTables T, const uint8_t* num32,
                                                            const uint8_t* den32, size_t n,
-                                                           uint8_t* root32, uint8_t* was_square, int min_curve_root, uint8_t* dcb) {
+                                                           uint8_t* root32, uint8_t* was_square, int min_curve_root, DcbScratch dcb) {
   D377_POW_LDS();
-  D377_DCB_IO(root32);
+  D377_DCB_BEGIN(root32);
   dcb_rounds<1, false>(n, io, pt,
     [&](size_t i, int j) {
       uint32_t wd[8];
@@ -227,6 +262,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtT
       store32(root32, i, wr);
       was_square[i] = ws ? 1 : 0;
     });
+  D377_DCB_END();
 }
 
 // decompress, compress and the round trip stay one element per lane on the wide grid, each square root in the
@@ -280,9 +316,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_roundtrip(SqrtTables 
 // map's (s, t)): each lane leaves the four 32-byte state records of its elements in `dcb` and the square-root-free
 // compressor finishes the round with one inversion.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtTables T, const uint8_t* fq32, size_t n,
-                                                           uint8_t* out32, uint8_t* dcb) {
+                                                           uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();
-  D377_DCB_IO(out32);
+  D377_DCB_BEGIN(out32);
   dcb_rounds<1, true>(n, io, pt,
     [&](size_t i, int j) {
       uint32_t w[8];
@@ -298,14 +334,15 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtT
       D377_INVARIANT(T, ge_from_jacobi_st(s, t), true);
       dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
     });
+  D377_DCB_END();
 }
 
 // two maps (their square roots take batched inverses), an addition, and the generic compressor: a sum of two points
 // has no known preimage
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTables T, const uint8_t* r1, const uint8_t* r2,
-                                                         size_t n, uint8_t* out32, uint8_t* dcb) {
+                                                         size_t n, uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();
-  D377_DCB_IO(out32);
+  D377_DCB_BEGIN(out32);
   dcb_rounds<2, false>(n, io, pt,
     [&](size_t i, int j) {
       uint32_t w[8];
@@ -325,18 +362,19 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTab
       ge_compress(T, pt, ge_add(a, b), w);
       store32(out32, i, w);
     });
+  D377_DCB_END();
 }
 
 // [k]P = [2]([k/2 mod r]P): the window loop runs on k/2 and the encoding is that of the double (no square root)
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTables T, const uint8_t* enc32,
                                                           const uint8_t* scalar32, size_t n, uint8_t* out32,
-                                                          uint8_t* status, uint32_t* scratch, uint8_t* dcb) {
+                                                          uint8_t* status, uint32_t* scratch, DcbScratch dcb) {
   D377_POW_LDS();
-  D377_DCB_IO(out32);
+  D377_DCB_BEGIN(out32);
   GlobalTab tab;
   tab.base = scratch;
-  tab.nthreads = io.nthreads;
-  tab.tid = io.tid;
+  tab.nthreads = io.nlanes;
+  tab.tid = io.lane;
   dcb_rounds<1, true>(n, io, pt,
     [&](size_t i, int j) {
       uint32_t w[8];
@@ -358,12 +396,14 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
       D377_INVARIANT(T, r, bad == 0);
       dcb_put(io, j, ge_dcb_from_half(r, bad != 0));      // failed lanes: neutral state, all-zero output
     });
+  D377_DCB_END();
 }
 
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
-                                                           const uint8_t* scalar32, size_t n, uint8_t* out32, uint8_t* dcb) {
+                                                           const uint8_t* scalar32, size_t n, uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();
-  D377_DCB_IO(out32);
+  reinterpret_cast<volatile uint32_t*>(lds_pow_)[threadIdx.x] = 0;    // keeps the 72 KiB LDS footprint: at most 2 resident workgroups per CU, one per lane set
+  D377_DCB_BEGIN(out32);
   FixedTab ft{fbase};
   dcb_rounds<0, true>(n, io, pt,
     [&](size_t, int) {},
@@ -376,6 +416,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
       D377_INVARIANT(T, r, true);
       dcb_put(io, j, ge_dcb_from_half(r, false));
     });
+  D377_DCB_END();
 }
 
 // The reference's own signatures for these operations take and return Elements (`Element * Fr`,
@@ -419,9 +460,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_compress_to_field(Sqr
 }
 // second input null: encode_to_curve; otherwise hash_to_curve (two maps and an addition)
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_map_to_element(SqrtTables T, const uint8_t* r1, const uint8_t* r2, size_t n,
-                                                                          uint64_t* out, uint8_t* dcb) {
+                                                                          uint64_t* out, DcbScratch dcb) {
   D377_POW_LDS();
-  D377_DCB_IO(out);
+  D377_DCB_BEGIN(out);
   dcb_rounds<2, false>(n, io, pt,
     [&](size_t i, int j) {
       uint32_t w[8];
@@ -442,6 +483,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_map_to_element(SqrtTa
       }
       store_ge_mont256(out, i, a);
     });
+  D377_DCB_END();
 }
 
 // wide byte strings (48 or 64 bytes per record) -> Fq, optionally straight into the Elligator map
@@ -466,9 +508,9 @@ __global__ void __launch_bounds__(BLOCK) k_fq_from_wide(const uint8_t* in, int l
   }
 }
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(SqrtTables T, const uint8_t* in, int len,
-                                                                                size_t n, uint8_t* out32, uint8_t* dcb) {
+                                                                                size_t n, uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();
-  D377_DCB_IO(out32);
+  D377_DCB_BEGIN(out32);
   dcb_rounds<1, true>(n, io, pt,
     [&](size_t i, int j) { dcb_put_den(io, 0, j, ge_elligator_den(fe_carry(load_wide(in, i, len)))); },
     [&](size_t i, int j, const uint32_t (*invw)[8]) {
@@ -478,6 +520,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(
       D377_INVARIANT(T, ge_from_jacobi_st(s, t), true);
       dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
     });
+  D377_DCB_END();
 }
 // (x/z, y/z) as Montgomery-256 limbs: CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81), with
 // the batched inversion that name implies (Montgomery's trick).  A lane walks its grid-stride elements
@@ -732,9 +775,13 @@ int init_device(DeviceState& d) {
   HIP_TRY(hipMemsetAsync(d.inv_fail, 0, sizeof(uint32_t), d.stream));
   // variable-base window tables: one per resident lane, fixed grid, grid-stride over the batch
   d.vb_blocks = d.cus * WAVES_PER_SIMD;        // exactly the resident blocks: 2 per CU
+
   HIP_TRY(hipMalloc(&d.vb_scratch, (size_t)d.vb_blocks * BLOCK * VB_ENTRIES * VB_ENTRY_WORDS * sizeof(uint32_t)));
-  // round records of the batched inversions: DCB_SLOTS x DCB_K 32-byte records per resident lane (320 MiB)
+  // round records of the batched inversions: DCB_SLOTS x DCB_K 32-byte records per resident lane (160 MiB), and the
+  // pool of lane sets the workgroups claim
   HIP_TRY(hipMalloc(&d.dcb_scratch, (size_t)d.vb_blocks * BLOCK * DCB_SLOTS * DCB_K * 32));
+  HIP_TRY(hipMalloc(&d.slot_pool, (size_t)d.vb_blocks * sizeof(int)));
+  HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.vb_blocks * sizeof(int), d.stream));
   uint32_t* keys = nullptr;
   int* coll = nullptr;
   HIP_TRY(hipMalloc(&keys, 512 * sizeof(uint32_t)));
@@ -752,7 +799,7 @@ void free_device(DeviceState& d) {
   if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
   (void)d.vb_guard.drain();
   (void)d.msm.guard.drain();
-  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.inv_fail);
+  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.inv_fail);
   for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); (void)hipFree(d.shard[i]); }
   for (int i = 0; i < 2; ++i) {
     if (d.ev_in[i]) (void)hipEventDestroy(d.ev_in[i]);
@@ -766,6 +813,13 @@ void free_device(DeviceState& d) {
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
+// Every set of the scratch areas is free when a launch begins (the guard has just queued it behind the areas' last
+// user); clearing the pool here also means a launch that died cannot leave sets claimed for the next one.
+int reset_pool(DeviceState& d, hipStream_t s) {
+  HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.vb_blocks * sizeof(int), s));
+  return D377_OK;
+}
+
 // launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null).
 // aux: the D377_FQ_* selector of OP_FQ_BIN / OP_FQ_UN / OP_FR_BIN / OP_FR_UN, the D377_SQRT_ROOT_* convention of OP_SQRT.
 // The caller holds ctx->mu (the scratch guards are host state).
@@ -773,16 +827,21 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
   if (n == 0) return D377_OK;
   const SqrtTables T = d.tables();
   const int g = grid_for(d, n);
-  const int gv = g < d.vb_blocks ? g : d.vb_blocks;   // the persistent grid: exactly the resident blocks
+  // kernels that work in chunks of DCB_K x 256 elements: one workgroup per chunk (oversubscribed on purpose, see
+  // DcbScratch), each claiming one of the vb_blocks resident lane sets of the per-device scratch areas
+  size_t nchunks = (n + (size_t)DCB_K * BLOCK - 1) / ((size_t)DCB_K * BLOCK);
+  if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
+  const int gv = (int)nchunks;
+  const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.vb_blocks};
   int rc;
   switch (op) {
     // Every kernel with a square root or an encoding keeps per-lane state in scratch areas that exist once per device
     // (round records of the batched inversions, window tables): never more lanes than those areas have (gv), and each
     // launch queues behind the areas' last user.
     case OP_SQRT:
-      if ((rc = d.vb_guard.acquire(s))) return rc;
+      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
       hipLaunchKernelGGL(k_sqrt_ratio_zeta, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
-                         (uint8_t*)out0, (uint8_t*)out1, aux, d.dcb_scratch);
+                         (uint8_t*)out0, (uint8_t*)out1, aux, dcb);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_DECOMPRESS:
@@ -795,26 +854,26 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
       break;
     case OP_MUL_BASE:
-      if ((rc = d.vb_guard.acquire(s))) return rc;
+      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
       hipLaunchKernelGGL(k_scalar_mul_base, dim3(gv), dim3(BLOCK), 0, s, T, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0,
-                         d.dcb_scratch);
+                         dcb);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_MUL_VAR:
-      if ((rc = d.vb_guard.acquire(s))) return rc;
+      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
       hipLaunchKernelGGL(k_scalar_mul_var, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
-                         (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch, d.dcb_scratch);
+                         (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch, dcb);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_ENCODE:
-      if ((rc = d.vb_guard.acquire(s))) return rc;
-      hipLaunchKernelGGL(k_encode_to_curve, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, d.dcb_scratch);
+      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
+      hipLaunchKernelGGL(k_encode_to_curve, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, dcb);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_HASH:
-      if ((rc = d.vb_guard.acquire(s))) return rc;
+      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
       hipLaunchKernelGGL(k_hash_to_curve, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
-                         (uint8_t*)out0, d.dcb_scratch);
+                         (uint8_t*)out0, dcb);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_ADD:
@@ -833,9 +892,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     case OP_ENCODE_WIDE48:
     case OP_ENCODE_WIDE64:
-      if ((rc = d.vb_guard.acquire(s))) return rc;
+      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
       hipLaunchKernelGGL(k_encode_to_curve_wide, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
-                         op == OP_ENCODE_WIDE48 ? 48 : 64, n, (uint8_t*)out0, d.dcb_scratch);
+                         op == OP_ENCODE_WIDE48 ? 48 : 64, n, (uint8_t*)out0, dcb);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_AFFINE: {
@@ -872,8 +931,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_MUL_VAR_EL: {
+      const int gp = g < d.vb_blocks ? g : d.vb_blocks;          // this one walks the batch on the resident grid
       if ((rc = d.vb_guard.acquire(s))) return rc;
-      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3(gv), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
+      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3(gp), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
                          (uint64_t*)out0, d.vb_scratch);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
@@ -886,9 +946,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     case OP_ENCODE_EL:
     case OP_HASH_EL:
-      if ((rc = d.vb_guard.acquire(s))) return rc;
+      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
       hipLaunchKernelGGL(k_map_to_element, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
-                         op == OP_HASH_EL ? (const uint8_t*)in1 : (const uint8_t*)nullptr, n, (uint64_t*)out0, d.dcb_scratch);
+                         op == OP_HASH_EL ? (const uint8_t*)in1 : (const uint8_t*)nullptr, n, (uint64_t*)out0, dcb);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_FR_BIN:

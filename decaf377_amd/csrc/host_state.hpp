@@ -60,7 +60,8 @@ struct DeviceState {
   uint8_t* s_lookup = nullptr;
   uint32_t* fbase = nullptr;
   uint32_t* vb_scratch = nullptr;
-  uint8_t* dcb_scratch = nullptr;        // round records of the square-root-free compressor (curve.hpp, dcb_finish)
+  uint8_t* dcb_scratch = nullptr;        // round records of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish)
+  int* slot_pool = nullptr;              // which of the vb_blocks lane sets of the scratch areas are claimed (d377.hip, DcbScratch)
   int vb_blocks = 0;
   uint32_t* inv_fail = nullptr;          // device counter of the -DD377_CHECK_INVARIANTS build (always allocated)
   ScratchGuard vb_guard;

@@ -561,4 +561,4 @@ run(32, "scalar_mul_var"); run(8, "roundtrip"); run(8, "scalar_mul_base_w8"); ru
     # the bounds build uses the 8-bit comb (32 mixed additions of 7 products); the product build's 14-bit comb has 18
     m8, s8 = got["scalar_mul_base_w8"]
     assert (m8 - 14 * 7, s8) == b.KERNEL_OPS["scalar_mul_base"]
-    assert b.KERNEL_MACS["scalar_mul_var"] == 1668.25 * 153 + 1009.0 * 117 + 2 * 20 * 90 / 16.0
+    assert b.KERNEL_MACS["scalar_mul_var"] == 1668.5 * 153 + 1009.0 * 117 + 2 * 20 * 90 / 8.0
