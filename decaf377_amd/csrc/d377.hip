@@ -78,12 +78,13 @@ struct DcbScratch {
   uint8_t* rec;        // [DCB_SLOTS][DCB_K][nslots * BLOCK] 32-byte records
   int* pool;           // nslots flags, 0 = free (cleared by the host before every launch)
   int nslots;
+  int per_lane;        // elements per lane in a chunk, 1 .. DCB_K: smaller for small batches, so that the grid still fills the chip
 };
 struct DcbIO {
   uint8_t* scratch;
   uint8_t* out32;
   size_t nlanes, lane, base;            // lane of the claimed set; the chunk's j-th element of this lane is record base + j * BLOCK
-  int slot;
+  int slot, per_lane;
   __device__ __forceinline__ size_t rec(int sl, int j) const { return (size_t)(sl * DCB_K + j) * nlanes + lane; }
   __device__ __forceinline__ void put(int sl, int j, const uint32_t w[8]) { store32(scratch, rec(sl, j), w); }
   __device__ __forceinline__ void get(int sl, int j, uint32_t w[8]) const { load32(scratch, rec(sl, j), w); }
@@ -119,12 +120,13 @@ __device__ __forceinline__ void dcb_release(const DcbScratch& sc, int slot) {
 template <int NINV, bool FINISH, class PT, class P0, class P1>
 __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1) {
   constexpr int NW = NINV > 0 ? NINV : 1;
-  constexpr size_t CHUNK = (size_t)DCB_K * BLOCK;
+  const int per_lane = io.per_lane;
+  const size_t CHUNK = (size_t)per_lane * BLOCK;
   for (size_t chunk = blockIdx.x; chunk * CHUNK < n; chunk += gridDim.x) {
     io.base = chunk * CHUNK + threadIdx.x;
     int cnt = 0;
 #pragma unroll 1
-    for (int j = 0; j < DCB_K; ++j) {
+    for (int j = 0; j < per_lane; ++j) {
       const size_t i = io.base + (size_t)j * BLOCK;
       if (i >= n) break;
       if (NINV > 0) phase0(i, j);
@@ -145,7 +147,7 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
 #define D377_DCB_BEGIN(out_ptr)                                                                   \
   const int dcb_slot_ = dcb_claim(dcb);                                                           \
   DcbIO io{dcb.rec, reinterpret_cast<uint8_t*>(out_ptr), (size_t)dcb.nslots * BLOCK,             \
-           (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_}
+           (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_, dcb.per_lane}
 #define D377_DCB_END() dcb_release(dcb, dcb_slot_)
 
 // ------------------------------------------------------------------------- init kernels ---
@@ -829,10 +831,14 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
   const int g = grid_for(d, n);
   // kernels that work in chunks of DCB_K x 256 elements: one workgroup per chunk (oversubscribed on purpose, see
   // DcbScratch), each claiming one of the vb_blocks resident lane sets of the per-device scratch areas
-  size_t nchunks = (n + (size_t)DCB_K * BLOCK - 1) / ((size_t)DCB_K * BLOCK);
+  // DCB_K elements per lane when the batch is large enough to fill the resident lane sets that way, fewer otherwise
+  size_t per_lane = (n + (size_t)d.vb_blocks * BLOCK - 1) / ((size_t)d.vb_blocks * BLOCK);
+  if (per_lane > (size_t)DCB_K) per_lane = DCB_K;
+  if (per_lane < 1) per_lane = 1;
+  size_t nchunks = (n + per_lane * BLOCK - 1) / (per_lane * BLOCK);
   if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
   const int gv = (int)nchunks;
-  const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.vb_blocks};
+  const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.vb_blocks, (int)per_lane};
   int rc;
   switch (op) {
     // Every kernel with a square root or an encoding keeps per-lane state in scratch areas that exist once per device
