@@ -23,9 +23,9 @@
  * Threads and streams.  Calls on one context are serialised by a mutex inside the context, so
  * several host threads may share it; distinct contexts are independent.  The `_dev` entry points
  * return as soon as the work is enqueued, and calls on DIFFERENT streams may be in flight at the
- * same time: the per-device scratch areas some kernels use (the variable-base window tables, the round
- * records of the square-root-free compressor behind scalar_mul_var / scalar_mul_base / encode_to_curve[_wide],
- * the MSM workspace) are handed from one launch to the next by events on the device, so such launches queue
+ * same time: the per-device scratch areas some kernels use (the variable-base window tables, the records of
+ * the batched inversions behind scalar_mul_var / scalar_mul_base / encode_to_curve[_wide] / hash_to_curve /
+ * sqrt_ratio_zeta, the MSM workspace) are handed from one launch to the next by events on the device, so such launches queue
  * up behind each other instead of racing -- results are the same as if the calls had been made one
  * after another; only their overlap is lost.  Kernels that use no scratch overlap freely.
  * `_dev` calls only enqueue kernels (no host synchronisation, no allocation once the workspaces have grown
@@ -69,8 +69,8 @@ const char* d377_last_error(void);
 
 /* Builds the read-only device tables (Sarkar square-root tables of
  * src/ark_curve/invsqrt.rs:14-66, fixed-base table of Element::GENERATOR) once per device
- * and allocates the per-device scratch (about 0.8 GB of HBM per device: window tables, compressor round
- * records, the 21 MB fixed-base comb).  device_ids == NULL, n_dev == 0 -> device 0. */
+ * and allocates the per-device scratch (about 0.4 GB of HBM per device: window tables, the records of the
+ * batched inversions, the 21 MB fixed-base comb).  device_ids == NULL, n_dev == 0 -> device 0. */
 int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out);
 void d377_ctx_destroy(d377_ctx* ctx);
 int d377_ctx_num_devices(const d377_ctx* ctx);
