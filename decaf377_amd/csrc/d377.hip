@@ -427,19 +427,29 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
 // end.  An Element leaves as whatever projective representative the schedule here produces -- the group element
 // (and so its encoding, and decaf equality) is the reference's; its X:Y:Z:T need not be.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n,
-                                                                             uint64_t* out, uint32_t* scratch) {
+                                                                             uint64_t* out, uint32_t* scratch, DcbScratch dcb) {
+  // chunked like the kernels above (one workgroup per per_lane x 256 elements, a claimed set of window tables); 256
+  // VGPRs keep at most two workgroups per CU resident, as many as there are sets
+  const int slot = dcb_claim(dcb);
   GlobalTab tab;
   tab.base = scratch;
-  tab.nthreads = (size_t)gridDim.x * BLOCK;
-  tab.tid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  for (size_t i = tab.tid; i < n; i += tab.nthreads) {
-    uint32_t k[8], dg[8];
-    load32(scalar32, i, k);
-    const ge g = load_ge_mont256(xyzt, i);
-    fr_reduce_words(k);
-    fr_recode_signed16(k, dg);
-    store_ge_mont256(out, i, ge_scalar_mul_w4(g, dg, tab));
+  tab.nthreads = (size_t)dcb.nslots * BLOCK;
+  tab.tid = (size_t)slot * BLOCK + threadIdx.x;
+  const size_t chunk_elems = (size_t)dcb.per_lane * BLOCK;
+  for (size_t chunk = blockIdx.x; chunk * chunk_elems < n; chunk += gridDim.x) {
+#pragma unroll 1
+    for (int j = 0; j < dcb.per_lane; ++j) {
+      const size_t i = chunk * chunk_elems + (size_t)j * BLOCK + threadIdx.x;
+      if (i >= n) break;
+      uint32_t k[8], dg[8];
+      load32(scalar32, i, k);
+      const ge g = load_ge_mont256(xyzt, i);
+      fr_reduce_words(k);
+      fr_recode_signed16(k, dg);
+      store_ge_mont256(out, i, ge_scalar_mul_w4(g, dg, tab));
+    }
   }
+  dcb_release(dcb, slot);
 }
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base_el(const uint32_t* fbase, const uint8_t* scalar32, size_t n,
                                                                               uint64_t* out) {
@@ -937,10 +947,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_MUL_VAR_EL: {
-      const int gp = g < d.vb_blocks ? g : d.vb_blocks;          // this one walks the batch on the resident grid
-      if ((rc = d.vb_guard.acquire(s))) return rc;
-      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3(gp), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
-                         (uint64_t*)out0, d.vb_scratch);
+      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
+      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3(gv), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
+                         (uint64_t*)out0, d.vb_scratch, dcb);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     }
