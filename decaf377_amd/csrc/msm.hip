@@ -111,6 +111,7 @@ __device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t
   uint32_t k[8];
   load32(scalar32, i, k);
   fr_reduce_words(k);
+  fr_half_words(k);                                     // the sum is formed with k/2 mod r and doubled at the end (k_msm_final)
   uint32_t carry = 0;
 #pragma unroll 1
   for (int w = 0; w < W; ++w) {
@@ -620,11 +621,23 @@ k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, 
     if (c & 1) r = ge_neg(r);                                    // an odd number of sign-flipping doublings
     r = ge_add_coop(r, pt_load_ext(sums + (size_t)w * PT_WORDS), role, base);
   }
-  uint32_t w8[8];
-  ge_compress(T, pt, r, w8);
+  // r = sum (k_i / 2) P_i: the result is its double, whose encoding needs no square root (curve.hpp, "compression
+  // without a square root") -- one element, so the inversion is not shared, but a divsteps inversion (~26 000
+  // instructions) is still well under the ~67 000 of a square root on this one dependent chain
+  (void)T;
+  struct OneIO {
+    uint32_t st[4][8], parked_[8], out[8];
+    __device__ __forceinline__ void put(int s, int, const uint32_t* w) { for (int k = 0; k < 8; ++k) st[s][k] = w[k]; }
+    __device__ __forceinline__ void get(int s, int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = st[s][k]; }
+    __device__ __forceinline__ void park(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) parked_[k] = w[k]; }
+    __device__ __forceinline__ void parked(int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = parked_[k]; }
+    __device__ __forceinline__ void emit(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) out[k] = w[k]; }
+  } io;
+  dcb_put(io, 0, ge_dcb_from_half(r, false));
+  dcb_finish(pt, io, 1);
   if (threadIdx.x == 0) {
-    if (xyzt_out) store_ge_mont256(xyzt_out, 0, r);
-    store32(enc_out, 0, w8);
+    if (xyzt_out) store_ge_mont256(xyzt_out, 0, ge_double(r));
+    store32(enc_out, 0, io.out);
   }
 }
 
