@@ -41,7 +41,7 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
 # of a chunk (denominators, compressor: 3-4 M per element each, and one divsteps inversion per lane per 8 elements
 # each: inv30.hpp, 20 rounds x 90 signed 64-bit MACs on 30-bit limbs, + 2 M).  The 2^20 extras are counted at the
 # 8 elements per lane they have.
-KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (137.25, 3.0),
+KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (109.25, 3.0),
               "sqrt_ratio_zeta": (75.25, 241.0)}
 MACS_PER_MUL, MACS_PER_SQR = 153, 117
 DIVSTEP_MACS_PER_INVERSION = 20 * 90                       # v_mad_i64_i32: update_fg_30 (36) + update_de_30 (54) per round

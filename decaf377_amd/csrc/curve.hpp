@@ -878,11 +878,13 @@ D377_HD void fr_recode_signed256(const uint32_t k[8], int digits[32]) {
 
 // [k]B from the shared table FB[i][j] = affine cached j * 2^(FB_BITS i) * B (i < FB_WINDOWS, j <= 2^(FB_BITS-1)):
 // FB_WINDOWS mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.  FB_BITS must divide the 252
-// significant scalar bits evenly so that the top digit needs no carry-out: 14 (18 windows x 8193 entries, 21 MB,
-// resident in the Infinity Cache), 12 (21 x 2049, 6.2 MB) or, as at first, 8 with FB_WINDOWS = 32 (594 KB).
-// Measured at 2^20 scalars with the square-root-free compressor: 7.8e8/s with 12 bits, 8.6e8/s with 14.
+// significant scalar bits evenly so that the top digit needs no carry-out: 18 (14 windows x 131073 entries, 264 MB in
+// HBM), 14 (18 x 8193, 21 MB, resident in the Infinity Cache), 12 (21 x 2049, 6.2 MB) or, as at first, 8 with
+// FB_WINDOWS = 32 (594 KB).  With the square root gone the additions are the element, so the width pays: measured at
+// 2^20 scalars, 7.8e8/s with 12 bits, 8.6e8/s with 14 (same build), and 9.7e8 -> 11.2e8/s from 14 to 18 (the gathers of
+// 144-byte entries from HBM hide behind the previous addition).  The host simulation builds its tables with 12 or 8.
 #ifndef D377_FB_BITS
-#define D377_FB_BITS 14
+#define D377_FB_BITS 18
 #endif
 constexpr int FB_BITS = D377_FB_BITS;
 constexpr int FB_WINDOWS = (FB_BITS == 8) ? 32 : 252 / FB_BITS;
