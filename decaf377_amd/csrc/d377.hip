@@ -239,8 +239,7 @@ __global__ void __launch_bounds__(BLOCK) k_init_fbase(uint32_t* fb) {
 }
 
 // --------------------------------------------------------------------------- batch kernels ---
-// Every kernel with a square root runs on the persistent grid and hands its square roots the inverses of their
-// denominators (dcb_rounds above).
+// The kernels that work in chunks (dcb_rounds above) hand their square roots the inverses of their denominators.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtTables T, const uint8_t* num32,
                                                            const uint8_t* den32, size_t n,
                                                            uint8_t* root32, uint8_t* was_square, int min_curve_root, DcbScratch dcb) {
@@ -268,8 +267,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtT
 }
 
 // decompress, compress and the round trip stay one element per lane on the wide grid, each square root in the
-// reference's inversion-free form: on the persistent grid with batched inverses they execute 4-8 % fewer instructions
-// but finish no sooner (measured, profiles/README.md) -- the oversubscribed grid keeps the issue port fuller.
+// reference's inversion-free form: in chunks with batched inverses they execute 4-8 % fewer instructions, but at 2^20
+// elements the chunked grid has no more workgroups than fit at once, the wide grid keeps the issue port fuller, and
+// they finish no sooner (measured, profiles/README.md).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
                                                       uint64_t* xyzt, uint8_t* status) {
   D377_POW_LDS();

@@ -3,7 +3,7 @@
 // The reference inverts with ark-ff's `Field::inverse` (src/fields/fq/u64/wrapper.rs:104-112; its u32 backend uses
 // the same divsteps family, src/fields/fq/u32/wrapper.rs:129-207); an inverse is a field value, so any correct
 // algorithm gives the reference's result.  x^(q-2) costs 296 S + 53 M = ~63 000 VALU instructions per lane
-// (curve.hpp, fe_invert_chain); this is ~19 000: 20 rounds of 30 constant-time "half-delta" divsteps on the
+// (curve.hpp, fe_invert_chain); this is ~29 000 (26 000 measured in issue slots): 20 rounds of 30 constant-time "half-delta" divsteps on the
 // low words (a 2x2 transition matrix with entries below 2^30), each followed by one matrix application to
 // (f, g) and one to (d, e) modulo q, on nine signed 30-bit limbs.  600 divsteps cover every modulus below 2^256
 // (the bound for this variant is 590).  Same instruction sequence in every lane: no divergence.
