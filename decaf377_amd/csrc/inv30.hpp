@@ -17,6 +17,18 @@ struct s30 { int32_t v[9]; };
 struct trans30 { int32_t u, v, q, r; };
 constexpr int32_t M30 = (int32_t)(0xFFFFFFFFu >> 2);
 
+// c + a * b on signed 32-bit factors: one v_mad_i64_i32.  (Left to itself hipcc recognises the sign-extended form in a
+// quarter of the places below and expands the rest into 64 x 64-bit products: 3 unsigned MACs, 2 v_mul_lo and moves each.)
+D377_HD int64_t mac_i64_i32(int32_t a, int32_t b, int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int64_t r;
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
+  return r;
+#else
+  return c + (int64_t)a * b;
+#endif
+}
+
 // 30 divsteps on the low words.  zeta = -(delta + 1/2).  Returns the new zeta; 2^30 [f', g'] = t [f, g].
 D377_HD int32_t divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, trans30* t) {
   uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
@@ -37,14 +49,14 @@ D377_HD int32_t divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, trans30* t) 
 
 // (f, g) <- t (f, g) / 2^30 (exact)
 D377_HD void update_fg_30(s30* f, s30* g, const trans30& t) {
-  int64_t cf = (int64_t)t.u * f->v[0] + (int64_t)t.v * g->v[0];
-  int64_t cg = (int64_t)t.q * f->v[0] + (int64_t)t.r * g->v[0];
+  int64_t cf = mac_i64_i32(t.v, g->v[0], mac_i64_i32(t.u, f->v[0], 0));
+  int64_t cg = mac_i64_i32(t.r, g->v[0], mac_i64_i32(t.q, f->v[0], 0));
   cf >>= 30; cg >>= 30;
 #pragma unroll
   for (int i = 1; i < 9; ++i) {
     const int32_t fi = f->v[i], gi = g->v[i];
-    cf += (int64_t)t.u * fi + (int64_t)t.v * gi;
-    cg += (int64_t)t.q * fi + (int64_t)t.r * gi;
+    cf = mac_i64_i32(t.v, gi, mac_i64_i32(t.u, fi, cf));
+    cg = mac_i64_i32(t.r, gi, mac_i64_i32(t.q, fi, cg));
     f->v[i - 1] = (int32_t)cf & M30; cf >>= 30;
     g->v[i - 1] = (int32_t)cg & M30; cg >>= 30;
   }
@@ -55,18 +67,18 @@ D377_HD void update_fg_30(s30* f, s30* g, const trans30& t) {
 D377_HD void update_de_30(s30* d, s30* e, const trans30& t) {
   const int32_t sd = d->v[8] >> 31, se = e->v[8] >> 31;
   int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
-  int64_t cd = (int64_t)t.u * d->v[0] + (int64_t)t.v * e->v[0];
-  int64_t ce = (int64_t)t.q * d->v[0] + (int64_t)t.r * e->v[0];
+  int64_t cd = mac_i64_i32(t.v, e->v[0], mac_i64_i32(t.u, d->v[0], 0));
+  int64_t ce = mac_i64_i32(t.r, e->v[0], mac_i64_i32(t.q, d->v[0], 0));
   md -= (int32_t)(((uint32_t)cd + (uint32_t)md) & (uint32_t)M30);     // q^-1 mod 2^30 = 1
   me -= (int32_t)(((uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
-  cd += (int64_t)FQ_MODULUS_S30[0] * md;
-  ce += (int64_t)FQ_MODULUS_S30[0] * me;
+  cd = mac_i64_i32(FQ_MODULUS_S30[0], md, cd);
+  ce = mac_i64_i32(FQ_MODULUS_S30[0], me, ce);
   cd >>= 30; ce >>= 30;
 #pragma unroll
   for (int i = 1; i < 9; ++i) {
     const int32_t di = d->v[i], ei = e->v[i];
-    cd += (int64_t)t.u * di + (int64_t)t.v * ei + (int64_t)FQ_MODULUS_S30[i] * md;
-    ce += (int64_t)t.q * di + (int64_t)t.r * ei + (int64_t)FQ_MODULUS_S30[i] * me;
+    cd = mac_i64_i32(FQ_MODULUS_S30[i], md, mac_i64_i32(t.v, ei, mac_i64_i32(t.u, di, cd)));
+    ce = mac_i64_i32(FQ_MODULUS_S30[i], me, mac_i64_i32(t.r, ei, mac_i64_i32(t.q, di, ce)));
     d->v[i - 1] = (int32_t)cd & M30; cd >>= 30;
     e->v[i - 1] = (int32_t)ce & M30; ce >>= 30;
   }
