@@ -369,6 +369,17 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
         assert torch.equal(k2, fb), n
 
 
+def test_soak_tool_small():
+    """tools/soak.py (the large-sample parity run whose full-size output is profiles/r02d_soak.txt) at 2^14: every
+    operation on seeded random inputs with invalid encodings, identity points, zero operands and the scalars
+    0, 1, 2, 3, r-1, r, r+1, (r+-1)/2, 2^251-1, 2^256-1 mixed in, byte for byte against the oracle."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "14", "7"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("bit-exact") == 6 and "MISMATCH" not in r.stdout
+
+
 def test_full_size_var_base_2_22(ctx, torch_mod, oracle):
     """BASELINE config 4 size on one GPU: 2^22 (point, scalar) pairs.  Property at full size:
     [k]P computed with scalars k and k + r (same class mod r, different bytes) must give identical
