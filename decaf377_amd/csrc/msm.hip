@@ -560,12 +560,16 @@ k_msm_fold(const uint32_t* in, int W, int m, int mout, uint32_t* out) {
 // is two rounds of four independent field products (X^2, Y^2, 2Z^2, 2XY, then EF, GH, FG, EH), and so
 // is an addition after one preparatory product; so four lanes each take one product per round (the
 // same instruction stream on different operands: no divergence), exchange the four results with
-// ds_bpermute, and every lane rebuilds the linear combinations.  Depth per doubling: 2 products instead
+// DPP quad_perm moves, and every lane rebuilds the linear combinations.  Depth per doubling: 2 products instead
 // of 8.  Every lane holds the whole point; lane j & 3 decides which product it computes.
-__device__ __forceinline__ fe fe_from_lane(const fe& v, int lane) {
+// lane K of the caller's group of four, to all four: a DPP quad_perm move per limb (one VALU instruction, no LDS
+// crossbar round trip as with ds_bpermute)
+template <int K>
+__device__ __forceinline__ fe fe_from_quad(const fe& v) {
   fe r;
 #pragma unroll
-  for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)__shfl((int)v.l[i], lane);
+  for (int i = 0; i < NL; ++i)
+    r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], K * 0x55, 0xF, 0xF, false);   // quad_perm:[K,K,K,K]
   return r;
 }
 __device__ __forceinline__ fe fe_pick(int role, const fe& a, const fe& b, const fe& c, const fe& d) {
@@ -581,11 +585,11 @@ __device__ __forceinline__ fe fe_pick(int role, const fe& a, const fe& b, const 
 __device__ __forceinline__ ge ge_double_neg_coop(const ge& p, int role, int base) {
   const fe y2 = fe_dbl(p.y), z2 = fe_dbl(p.z);
   const fe m1 = fe_mul(fe_pick(role, p.x, p.y, p.z, p.x), fe_pick(role, p.x, p.y, z2, y2));
-  const fe a = fe_from_lane(m1, base), b = fe_from_lane(m1, base + 1), c = fe_from_lane(m1, base + 2), e = fe_from_lane(m1, base + 3);
+  const fe a = fe_from_quad<0>(m1), b = fe_from_quad<1>(m1), c = fe_from_quad<2>(m1), e = fe_from_quad<3>(m1);
   const fe h = fe_add(a, b), g = fe_sub(a, b), f = fe_add(g, c);
   const fe m2 = fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));
   ge r;
-  r.x = fe_from_lane(m2, base); r.y = fe_from_lane(m2, base + 1); r.z = fe_from_lane(m2, base + 2); r.t = fe_from_lane(m2, base + 3);
+  r.x = fe_from_quad<0>(m2); r.y = fe_from_quad<1>(m2); r.z = fe_from_quad<2>(m2); r.t = fe_from_quad<3>(m2);
   return r;
 }
 // P + Q (src/min_curve/element.rs:291-322), Q's coordinates products as loaded from a pt_store_ext record
@@ -593,11 +597,11 @@ __device__ __forceinline__ ge ge_add_coop(const ge& p, const ge& q, int role, in
   const fe kt = fe_mul(fe_const(FE_K), q.t);                   // every lane: one product
   const fe m1 = fe_mul(fe_pick(role, fe_sub(p.y, p.x), fe_add(p.y, p.x), p.t, fe_dbl(p.z)),
                        fe_pick(role, fe_sub(q.y, q.x), fe_carry(fe_add(q.y, q.x)), kt, q.z));
-  const fe a = fe_from_lane(m1, base), b = fe_from_lane(m1, base + 1), c = fe_from_lane(m1, base + 2), d = fe_from_lane(m1, base + 3);
+  const fe a = fe_from_quad<0>(m1), b = fe_from_quad<1>(m1), c = fe_from_quad<2>(m1), d = fe_from_quad<3>(m1);
   const fe e = fe_sub(b, a), f = fe_sub(d, c), g = fe_carry(fe_add(d, c)), h = fe_add(b, a);
   const fe m2 = fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));
   ge r;
-  r.x = fe_from_lane(m2, base); r.y = fe_from_lane(m2, base + 1); r.z = fe_from_lane(m2, base + 2); r.t = fe_from_lane(m2, base + 3);
+  r.x = fe_from_quad<0>(m2); r.y = fe_from_quad<1>(m2); r.z = fe_from_quad<2>(m2); r.t = fe_from_quad<3>(m2);
   return r;
 }
 
