@@ -947,9 +947,16 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_MUL_VAR_EL: {
+      // no inversions here, so nothing argues for long chunks: one or two elements per lane keep the grid oversubscribed
+      // at every batch size
+      // (2^20 elements: 7.33e7/s with 8 per lane, 7.44 with 4, 7.59 with 2, 7.54 with 1)
+      DcbScratch dv = dcb;
+      if (dv.per_lane > 2) dv.per_lane = 2;
+      size_t nch = (n + (size_t)dv.per_lane * BLOCK - 1) / ((size_t)dv.per_lane * BLOCK);
+      if (nch > (size_t)d.cus * 64) nch = (size_t)d.cus * 64;
       if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3(gv), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
-                         (uint64_t*)out0, d.vb_scratch, dcb);
+      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3((int)nch), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
+                         (uint64_t*)out0, d.vb_scratch, dv);
       if ((rc = d.vb_guard.release(s))) return rc;
       break;
     }
