@@ -288,6 +288,15 @@ def main():
         extra["scalar_mul_var_element"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}
         ker, _ = time_op(torch, lambda: ctx.fr_op("mul", scalars[:ne], r0[:ne], outs=[o1, s1]), 3, 1)
         extra["fr_mul"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3), "algo_GBps": 97 * ne / (ker * 1e-3) / 1e9}
+        # the remaining group-level entry points of the path, for the record (same 2^20 records)
+        xy = torch.empty((ne, 16), dtype=torch.int64, device=dev)
+        for name, fn in [
+            ("decompress", lambda: ctx.decompress(enc1, outs=[xy, s1])),
+            ("compress", lambda: ctx.compress(pm, outs=[o1])),
+            ("hash_to_curve", lambda: ctx.hash_to_curve(r0[:ne], scalars[:ne], outs=[o1])),
+        ]:
+            ker, _ = time_op(torch, fn, 3, 1)
+            extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}
         extra["encodes_per_sec"] = extra["roundtrip"]["per_sec_all_gpus"]          # whole job, all GPUs
         extra["elligator_encodes_per_sec"] = extra["encode_to_curve"]["per_sec_all_gpus"]
         line["extra"] = extra
