@@ -68,9 +68,63 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="plumbing test of the self-launcher: ranks rendezvous over gloo on the CPU, rank 0 prints "
+                         "{launch_check, ranks_seen}, nothing touches a GPU")
     ap.add_argument("--same-device", action="store_true",
                     help="plumbing test: every rank uses GPU 0 (needs --backend gloo; not a measurement)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes here.  This parent makes no GPU
+    call (it never imports torch): a process that has opened the GPU must not spawn programs on this pool, so the
+    ranks are started first and the parent only relays rank 0's JSON line and the exit codes."""
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "D377_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = b""
+    rc = 0
+    try:
+        # rank 0's stdout is small (one line): read it to the end, then reap everyone; a rank that dies takes the others
+        # down with it instead of leaving them in a collective
+        import threading
+        def drain():
+            nonlocal out0
+            out0 = procs[0].stdout.read()
+        th = threading.Thread(target=drain, daemon=True)
+        th.start()
+        live = set(range(args.gpus))
+        while live:
+            for r in list(live):
+                c = procs[r].poll()
+                if c is not None:
+                    live.discard(r)
+                    if c != 0 and rc == 0:
+                        rc = c if c > 0 else 1
+                        sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, c))
+                        for o in live:
+                            procs[o].terminate()
+            time.sleep(0.05)
+        th.join(timeout=10)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    raise SystemExit(rc)
 
 
 def usable_cores():
@@ -107,24 +161,38 @@ def time_op(torch, fn, steps, warmup):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                          # never returns
     import numpy as np
     import torch
     import torch.distributed as dist
-    import decaf377_amd as d
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "ranks_seen": dist.get_world_size(), "rank_sum": int(t.item()),
+                              "self_launched": bool(os.environ.get("D377_BENCH_SELF_LAUNCHED"))}), flush=True)
+        dist.destroy_process_group()
+        return
+    import decaf377_amd as d
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     if args.same_device:
         local = 0
     ndev = torch.cuda.device_count()
-    if ndev and local >= ndev:          # a launcher that masks devices per rank leaves one visible GPU
-        local = local % ndev
+    if ndev and local >= ndev:
+        if os.environ.get("D377_BENCH_SELF_LAUNCHED") and not args.same_device:
+            raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s) (--same-device --backend gloo is the "
+                             "plumbing mode for one GPU)" % (args.gpus, ndev))
+        local = local % ndev            # a launcher that masks devices per rank leaves one visible GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or "RANK" in os.environ:      # under torch.distributed.run, also with a single rank (RCCL smoke path)
@@ -153,6 +221,7 @@ def main():
         return ctx.encode_to_curve(r0_), k_      # valid encodings, strategy of tests/operations.rs:6-11
 
     kernel_events = []
+    last_local = []                              # this rank's last launch: inputs and outputs (parity sample below)
 
     def compute(points_, scalars_):
         cnt = int(points_.shape[0])
@@ -164,6 +233,7 @@ def main():
             ctx.scalar_mul_var(points_, scalars_, outs=[o, st])
         b.record()
         kernel_events.append((a, b))
+        last_local[:] = [points_, scalars_, o, st]
         return o, st
 
     res = sharding.run_job(mode, n_job, args.steps, args.warmup, make_inputs, compute, dev,
@@ -175,6 +245,23 @@ def main():
     out, status = res["outputs"] if rank == 0 else (None, None)
     if rank == 0 and out is not None:
         assert int(status.sum().item()) == 0, "valid inputs must all decode"
+    # Every rank checks a sample of ITS OWN last launch against the oracle (the checker; after the timed region):
+    # 256 records spread evenly over the shard.  MIN over ranks, so one wrong rank fails the line.
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import Oracle
+    parity_ok, parity_cnt = 1, 0
+    if last_local and int(last_local[0].shape[0]) > 0:
+        lp, lk, lo_, lst = last_local
+        cnt = int(lp.shape[0])
+        sel = torch.linspace(0, cnt - 1, steps=min(256, cnt), device=dev).round().to(torch.int64).unique()
+        o_out, o_st = Oracle().scalar_mul_var(lp[sel].cpu().numpy(), lk[sel].cpu().numpy())
+        parity_ok = int(bool((lo_[sel].cpu().numpy() == o_out).all() and (lst[sel].cpu().numpy() == o_st).all()))
+        parity_cnt = int(sel.numel())
+    ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
+    if dist.is_initialized() and world > 1:
+        tt = torch.tensor([parity_ok, parity_cnt], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        parity_ok, parity_cnt = int(tt[0].item()), int(tt[1].item())
     # the extra ops and the CPU baseline below reuse rank 0's records
     g = torch.Generator(device=dev).manual_seed(666 + rank)
     r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
@@ -207,6 +294,10 @@ def main():
             "inputs": "points = encode_to_curve(rand32), scalars = rand32 (reduced mod r on the GPU), seed 666+rank",
         },
     }
+    line["ranks_seen"] = ranks_seen              # size of the process group the timed region ran in
+    line["backend"] = (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if dist.is_initialized() else "none (one process)"
+    line["parity_sample_ok"] = bool(parity_ok)   # every rank: >= parity_sample_per_rank outputs of its last launch == oracle
+    line["parity_sample_per_rank"] = parity_cnt
     if args.from_root:
         line["collective_ms"] = res["collective_s"] * 1e3 / args.steps
     n = max(n_launch, 1) if mode != "weak" else n
@@ -231,6 +322,10 @@ def main():
         "frac": ach / HBM_PEAK_GBS,
         "traffic": traffic,
         "traffic_source": traffic_source,
+        # what the memory system really moves (per-lane window tables in global scratch), against the same peak; an
+        # upper bound on HBM bytes: the counters also see Infinity-Cache hits
+        "achieved_measured": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+        "frac_measured": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
         "kernel_ms": kernel_ms,
         "note": "integer-ALU-bound kernel: 3.7e5 32-bit MACs per 97 algorithmic bytes; see roofline_valu",
     }
@@ -250,7 +345,9 @@ def main():
         # of `frac` for this instruction stream, and instructions/s against the issue rate says how full the pipe is
         vi = pmc["valu_insts_per_element"]
         line["roofline_valu"]["valu_insts_per_mac"] = vi / KERNEL_MACS["scalar_mul_var"]
-        line["roofline_valu"]["valu_issue_frac"] = vi * n / (kernel_ms * 1e-3) / VALU_MAC_PEAK
+        # VALU instructions/s against one wave-instruction per 4 cycles per SIMD AT THE NOMINAL 2.4 GHz (DESIGN.md section 5's
+        # "issue-slot utilisation" divides by the cycles the chip really ran, GRBM_GUI_ACTIVE, and reads ~0.04 higher)
+        line["roofline_valu"]["valu_issue_frac_at_nominal_clock"] = vi * n / (kernel_ms * 1e-3) / VALU_MAC_PEAK
         line["roofline_valu"]["pmc_source"] = pmc.get("source")
 
     if not args.no_extra:
@@ -302,8 +399,6 @@ def main():
         line["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from _oracle import Oracle
         orc = Oracle(native=True)
         cores = usable_cores()
         # pilot on one thread to size a sample worth ~12 s of wall time on all cores
@@ -347,9 +442,11 @@ def main():
             "cpu_ns_per_call_1_thread": dts / nsq * 1e9, "cpu_per_sec_1_thread": nsq / dts, "matches_gpu_output": ok}
 
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit("bench.py: a rank's outputs differ from the oracle on its parity sample")
 
 
 if __name__ == "__main__":

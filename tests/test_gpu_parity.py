@@ -1147,6 +1147,34 @@ def test_bench_modes_and_rccl_single_rank():
     assert line["collective_ms"] > 0
 
 
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with NO launcher: the parent starts the two ranks itself before anything touches the
+    GPU and relays rank 0's line.  Both ranks share GPU 0 and rendezvous over gloo (this box has one GPU); on a node
+    with N GPUs the same command without --same-device / --backend runs one rank per GPU over RCCL.  The line says how
+    many ranks the process group had and that every rank's outputs matched the oracle on its own sample."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
+                        "--steps", "2", "--warmup", "1", "--log2n", "16", "--no-cpu-baseline", "--no-extra"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    assert line["parity_sample_ok"] is True and line["parity_sample_per_rank"] == 256
+    assert line["config"]["elements_total"] == 2 << 16 and line["value"] > 0
+
+
+def test_multigpu_selftest_tool():
+    """tools/multigpu_selftest.py on whatever this box has (one GPU: every multi-device path runs with GPU 0 listed
+    twice and the RCCL leg with one rank; on a multi-GPU node it uses distinct devices and peer copies)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multigpu_selftest.py"), "--log2n", "14"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "MULTIGPU_SELFTEST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_rccl_sharding_single_rank():
     """decaf377_amd/sharding.py on HBM tensors over the real `nccl` backend (RCCL): scatter / gather of records,
     the all-gather of MSM partial sums and the timing all-reduce, one rank (the builder's boxes have one GPU; the
