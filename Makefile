@@ -1,0 +1,77 @@
+# Builds the product library (HIP kernels + C ABI, gfx950 only) without Python:
+#
+#   make                      decaf377_amd/lib/libdecaf377_amd.so, libdecaf377_amd_check.so and the CPU oracle
+#   make lib                  the product library only (what rust/build.rs and a C consumer link)
+#   make lib FB_BITS=14       options below; a non-default build goes to build/variants/<VARIANT>.so when VARIANT is set
+#   make check                the same sources with -DD377_CHECK_INVARIANTS (the reference's debug assertions)
+#   make oracle               test infrastructure (oracle/Makefile), never linked into the product
+#
+# Options ("config / flags"):
+#   ARCH              offload architecture (gfx950; the kernels are written for nothing else)
+#   FB_BITS           comb width of the fixed-base table: 18 (default), 14, 12 or 8   -> -DD377_FB_BITS
+#   DCB_K             elements per lane per batched inversion: 8 (default), 4, 16      -> -DD377_DCB_K
+#   WAVES_PER_SIMD    occupancy the chunked kernels are built for: 2 (default)         -> -DD377_WAVES_PER_SIMD
+#   CHECK_INVARIANTS  1: curve-equation checks on the device in the product library too
+#   EXTRA             further -D flags (A/B builds: tools/build_variant.sh)
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+FB_BITS ?= 18
+DCB_K ?= 8
+WAVES_PER_SIMD ?= 2
+CHECK_INVARIANTS ?= 0
+EXTRA ?=
+VARIANT ?=
+
+CSRC := decaf377_amd/csrc
+LIBDIR := decaf377_amd/lib
+HDRS := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/decaf377_amd.h
+UNITS := d377 msm
+DEFS := -DD377_FB_BITS=$(FB_BITS) -DD377_DCB_K=$(DCB_K) -DD377_WAVES_PER_SIMD=$(WAVES_PER_SIMD) $(EXTRA)
+ifeq ($(CHECK_INVARIANTS),1)
+DEFS += -DD377_CHECK_INVARIANTS
+endif
+HIPFLAGS := -O3 --offload-arch=$(ARCH) -std=c++17 -fPIC
+
+ifeq ($(VARIANT),)
+OBJDIR := build/obj
+LIB := $(LIBDIR)/libdecaf377_amd.so
+else
+OBJDIR := build/obj_$(VARIANT)
+LIB := build/variants/$(VARIANT).so
+endif
+CHECK_OBJDIR := build/obj_check
+CHECK_LIB := $(LIBDIR)/libdecaf377_amd_check.so
+
+all: lib check oracle
+lib: $(LIB)
+check: $(CHECK_LIB)
+
+# the options are part of the build's identity: a change of FB_BITS etc. rebuilds the objects
+$(OBJDIR)/.flags: FORCE
+	@mkdir -p $(OBJDIR)
+	@echo '$(HIPCC) $(HIPFLAGS) $(DEFS)' | cmp -s - $@ || echo '$(HIPCC) $(HIPFLAGS) $(DEFS)' > $@
+$(CHECK_OBJDIR)/.flags: FORCE
+	@mkdir -p $(CHECK_OBJDIR)
+	@echo '$(HIPCC) $(HIPFLAGS) $(DEFS) -DD377_CHECK_INVARIANTS' | cmp -s - $@ || echo '$(HIPCC) $(HIPFLAGS) $(DEFS) -DD377_CHECK_INVARIANTS' > $@
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS) $(OBJDIR)/.flags
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $< -o $@
+$(CHECK_OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS) $(CHECK_OBJDIR)/.flags
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -DD377_CHECK_INVARIANTS -c $< -o $@
+
+$(LIB): $(UNITS:%=$(OBJDIR)/%.o)
+	@mkdir -p $(dir $@)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $^
+$(CHECK_LIB): $(UNITS:%=$(CHECK_OBJDIR)/%.o)
+	@mkdir -p $(dir $@)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $^
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build/obj build/obj_check build/obj_* build/variants $(LIBDIR)/*.so
+	$(MAKE) -C oracle clean
+
+FORCE:
+.PHONY: all lib check oracle clean FORCE
