@@ -72,11 +72,16 @@ struct FixedTab {
 // and there are as many workgroups as chunks.  Measured at 2^22 variable-base elements: 64.2 ms with exactly the
 // resident workgroups walking 32 elements per lane each, 61.4 ms with four generations of workgroups of 8 per lane,
 // although the latter pays four times as many inversions (profiles/README.md).  A workgroup therefore claims one of
-// the area's `nslots` lane sets when it starts (an atomic on a small pool) and frees it when it is done; LDS keeps
-// at most `nslots` workgroups resident, so a free set always exists.
+// the area's `nslots` lane sets when it starts (an atomic on a small pool) and frees it when it is done.  The launch
+// configuration keeps at most `nslots` workgroups of these kernels resident (d377_ctx_create checks it with the
+// occupancy query and pads a kernel's LDS allocation when its registers alone would let more in: chunk_kernels
+// below), so a free set normally exists; should residency ever exceed the sets -- two such kernels from different
+// streams sharing a CU -- the extra workgroup sleeps and retries until a holder, which never waits on anything,
+// finishes.  Claims are atomic and nothing resets the pool between launches, so kernels from different streams
+// (a replayed hipGraph next to an eager call) can share the areas safely.
 struct DcbScratch {
   uint8_t* rec;        // [DCB_SLOTS][DCB_K][nslots * BLOCK] 32-byte records
-  int* pool;           // nslots flags, 0 = free (cleared by the host before every launch)
+  int* pool;           // nslots flags, 0 = free (cleared once, at context creation; every workgroup frees what it claimed)
   int nslots;
   int per_lane;        // elements per lane in a chunk, 1 .. DCB_K: smaller for small batches, so that the grid still fills the chip
 };
@@ -98,7 +103,11 @@ __device__ __forceinline__ int dcb_claim(const DcbScratch& sc) {
   __shared__ int s_slot;
   if (threadIdx.x == 0) {
     int s = (int)(blockIdx.x % (unsigned)sc.nslots);
-    while (atomicCAS(&sc.pool[s], 0, 1) != 0) s = s + 1 == sc.nslots ? 0 : s + 1;
+    int tries = 0;
+    while (atomicCAS(&sc.pool[s], 0, 1) != 0) {
+      s = s + 1 == sc.nslots ? 0 : s + 1;
+      if (++tries >= sc.nslots) { __builtin_amdgcn_s_sleep(32); tries = 0; }    // a whole lap without a free set: back off
+    }
     s_slot = s;
   }
   __syncthreads();
@@ -403,8 +412,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
 
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
                                                            const uint8_t* scalar32, size_t n, uint8_t* out32, DcbScratch dcb) {
-  D377_POW_LDS();
-  reinterpret_cast<volatile uint32_t*>(lds_pow_)[threadIdx.x] = 0;    // keeps the 72 KiB LDS footprint: at most 2 resident workgroups per CU, one per lane set
+  D377_POW_LDS();                        // unused here (no square root): residency is capped by the launch's LDS padding
   D377_DCB_BEGIN(out32);
   FixedTab ft{fbase};
   dcb_rounds<0, true>(n, io, pt,
@@ -428,8 +436,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
 // (and so its encoding, and decaf equality) is the reference's; its X:Y:Z:T need not be.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n,
                                                                              uint64_t* out, uint32_t* scratch, DcbScratch dcb) {
-  // chunked like the kernels above (one workgroup per per_lane x 256 elements, a claimed set of window tables); 256
-  // VGPRs keep at most two workgroups per CU resident, as many as there are sets
+  // chunked like the kernels above (one workgroup per per_lane x 256 elements, a claimed set of window tables)
   const int slot = dcb_claim(dcb);
   GlobalTab tab;
   tab.base = scratch;
@@ -764,6 +771,44 @@ int init_tables(DeviceState& d, uint32_t* keys, int* coll) {
   return D377_OK;
 }
 
+// The lane-set areas have WAVES_PER_SIMD sets per CU.  Ask the runtime how many workgroups of each chunked kernel fit
+// on a CU (registers, the kernel's own LDS); where that is more than the sets, pad the launch with dynamic LDS until it
+// is not (160 KiB per CU: a pad of a little over 160 / (sets + 1) KiB admits `sets` workgroups and no more).  A kernel
+// that still exceeds the sets would only spin for a free set (dcb_claim), silently slower: refuse to start instead.
+int check_residency(DeviceState& d) {
+  const void* fns[CK_COUNT];
+  fns[CK_SQRT] = reinterpret_cast<const void*>(k_sqrt_ratio_zeta);
+  fns[CK_ENCODE] = reinterpret_cast<const void*>(k_encode_to_curve);
+  fns[CK_HASH] = reinterpret_cast<const void*>(k_hash_to_curve);
+  fns[CK_MUL_VAR] = reinterpret_cast<const void*>(k_scalar_mul_var);
+  fns[CK_MUL_BASE] = reinterpret_cast<const void*>(k_scalar_mul_base);
+  fns[CK_MUL_VAR_EL] = reinterpret_cast<const void*>(k_scalar_mul_var_el);
+  fns[CK_MAP_EL] = reinterpret_cast<const void*>(k_map_to_element);
+  fns[CK_ENCODE_WIDE] = reinterpret_cast<const void*>(k_encode_to_curve_wide);
+  static const char* names[CK_COUNT] = {"k_sqrt_ratio_zeta", "k_encode_to_curve", "k_hash_to_curve", "k_scalar_mul_var",
+                                        "k_scalar_mul_base", "k_scalar_mul_var_el", "k_map_to_element", "k_encode_to_curve_wide"};
+  const int pad = (160 * 1024) / (WAVES_PER_SIMD + 1) + 1024;
+  const bool verbose = getenv("D377_DEBUG_RESIDENCY") != nullptr;
+  for (int k = 0; k < CK_COUNT; ++k) {
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[k], BLOCK, 0));
+    d.chunk_lds[k] = 0;
+    if (nb > WAVES_PER_SIMD) {
+      if (pad > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+      d.chunk_lds[k] = pad;
+      const int before = nb;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[k], BLOCK, (size_t)pad));
+      if (verbose) fprintf(stderr, "d377: %s: %d workgroups per CU by registers / own LDS, %d with %d bytes of LDS padding\n", names[k], before, nb, pad);
+    } else if (verbose) {
+      fprintf(stderr, "d377: %s: %d workgroups per CU\n", names[k], nb);
+    }
+    d.chunk_blocks[k] = nb;
+    if (nb < 1 || nb > WAVES_PER_SIMD)
+      return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", names[k]);
+  }
+  return D377_OK;
+}
+
 int init_device(DeviceState& d) {
   HIP_TRY(hipSetDevice(d.id));
   hipDeviceProp_t prop;
@@ -793,7 +838,8 @@ int init_device(DeviceState& d) {
   // pool of lane sets the workgroups claim
   HIP_TRY(hipMalloc(&d.dcb_scratch, (size_t)d.vb_blocks * BLOCK * DCB_SLOTS * DCB_K * 32));
   HIP_TRY(hipMalloc(&d.slot_pool, (size_t)d.vb_blocks * sizeof(int)));
-  HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.vb_blocks * sizeof(int), d.stream));
+  HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.vb_blocks * sizeof(int), d.stream));      // every set free; workgroups free what they claim
+  if ((rc = check_residency(d))) return rc;
   uint32_t* keys = nullptr;
   int* coll = nullptr;
   HIP_TRY(hipMalloc(&keys, 512 * sizeof(uint32_t)));
@@ -822,15 +868,21 @@ void free_device(DeviceState& d) {
   d.msm.guard.destroy();
   if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
   (void)hipFree(d.msm.mem);
+  for (uint8_t* r : d.msm.retired) (void)hipFree(r);
+  d.msm.retired.clear();
   if (d.stream) (void)hipStreamDestroy(d.stream);
 }
 
-// Every set of the scratch areas is free when a launch begins (the guard has just queued it behind the areas' last
-// user); clearing the pool here also means a launch that died cannot leave sets claimed for the next one.
-int reset_pool(DeviceState& d, hipStream_t s) {
-  HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.vb_blocks * sizeof(int), s));
-  return D377_OK;
-}
+// Holds a scratch area for one launch: queues the launch behind the area's last user and records the hand-over event
+// on EVERY path out of the launch once the area has been acquired -- also when a later step of the launch fails, so
+// that the next user on another stream still queues behind whatever was enqueued.
+struct GuardScope {
+  ScratchGuard& g;
+  hipStream_t s;
+  bool held = false;
+  int acquire() { int rc = g.acquire(s); held = rc == D377_OK; return rc; }
+  ~GuardScope() { if (held) (void)g.release(s); }
+};
 
 // launches one op on device buffers; in0/in1 inputs, out0/out1 outputs (unused ones null).
 // aux: the D377_FQ_* selector of OP_FQ_BIN / OP_FQ_UN / OP_FR_BIN / OP_FR_UN, the D377_SQRT_ROOT_* convention of OP_SQRT.
@@ -849,16 +901,16 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
   if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
   const int gv = (int)nchunks;
   const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.vb_blocks, (int)per_lane};
+  GuardScope vb{d.vb_guard, s};            // released (event recorded) when this function returns, if it was acquired
   int rc;
   switch (op) {
     // Every kernel with a square root or an encoding keeps per-lane state in scratch areas that exist once per device
     // (round records of the batched inversions, window tables): never more lanes than those areas have (gv), and each
     // launch queues behind the areas' last user.
     case OP_SQRT:
-      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_sqrt_ratio_zeta, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+      if ((rc = vb.acquire())) return rc;
+      hipLaunchKernelGGL(k_sqrt_ratio_zeta, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_SQRT], s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
                          (uint8_t*)out0, (uint8_t*)out1, aux, dcb);
-      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_DECOMPRESS:
       hipLaunchKernelGGL(k_decompress, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint64_t*)out0, (uint8_t*)out1);
@@ -870,27 +922,23 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
       break;
     case OP_MUL_BASE:
-      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_scalar_mul_base, dim3(gv), dim3(BLOCK), 0, s, T, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0,
+      if ((rc = vb.acquire())) return rc;
+      hipLaunchKernelGGL(k_scalar_mul_base, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_MUL_BASE], s, T, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0,
                          dcb);
-      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_MUL_VAR:
-      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_scalar_mul_var, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+      if ((rc = vb.acquire())) return rc;
+      hipLaunchKernelGGL(k_scalar_mul_var, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_MUL_VAR], s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
                          (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch, dcb);
-      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_ENCODE:
-      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_encode_to_curve, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, dcb);
-      if ((rc = d.vb_guard.release(s))) return rc;
+      if ((rc = vb.acquire())) return rc;
+      hipLaunchKernelGGL(k_encode_to_curve, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_ENCODE], s, T, (const uint8_t*)in0, n, (uint8_t*)out0, dcb);
       break;
     case OP_HASH:
-      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_hash_to_curve, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+      if ((rc = vb.acquire())) return rc;
+      hipLaunchKernelGGL(k_hash_to_curve, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_HASH], s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
                          (uint8_t*)out0, dcb);
-      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_ADD:
       hipLaunchKernelGGL(k_add, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint64_t*)in1, n, (uint64_t*)out0, aux);
@@ -908,10 +956,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     case OP_ENCODE_WIDE48:
     case OP_ENCODE_WIDE64:
-      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_encode_to_curve_wide, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
+      if ((rc = vb.acquire())) return rc;
+      hipLaunchKernelGGL(k_encode_to_curve_wide, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_ENCODE_WIDE], s, T, (const uint8_t*)in0,
                          op == OP_ENCODE_WIDE48 ? 48 : 64, n, (uint8_t*)out0, dcb);
-      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_AFFINE: {
       // ~AFFINE_PER_LANE elements per lane so that one inversion serves many, but never fewer lanes than one
@@ -954,10 +1001,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       if (dv.per_lane > 2) dv.per_lane = 2;
       size_t nch = (n + (size_t)dv.per_lane * BLOCK - 1) / ((size_t)dv.per_lane * BLOCK);
       if (nch > (size_t)d.cus * 64) nch = (size_t)d.cus * 64;
-      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3((int)nch), dim3(BLOCK), 0, s, (const uint64_t*)in0, (const uint8_t*)in1, n,
+      if ((rc = vb.acquire())) return rc;
+      hipLaunchKernelGGL(k_scalar_mul_var_el, dim3((int)nch), dim3(BLOCK), d.chunk_lds[CK_MUL_VAR_EL], s, (const uint64_t*)in0, (const uint8_t*)in1, n,
                          (uint64_t*)out0, d.vb_scratch, dv);
-      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     }
     case OP_MUL_BASE_EL:
@@ -968,10 +1014,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     case OP_ENCODE_EL:
     case OP_HASH_EL:
-      if ((rc = d.vb_guard.acquire(s)) || (rc = reset_pool(d, s))) return rc;
-      hipLaunchKernelGGL(k_map_to_element, dim3(gv), dim3(BLOCK), 0, s, T, (const uint8_t*)in0,
+      if ((rc = vb.acquire())) return rc;
+      hipLaunchKernelGGL(k_map_to_element, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_MAP_EL], s, T, (const uint8_t*)in0,
                          op == OP_HASH_EL ? (const uint8_t*)in1 : (const uint8_t*)nullptr, n, (uint64_t*)out0, dcb);
-      if ((rc = d.vb_guard.release(s))) return rc;
       break;
     case OP_FR_BIN:
     case OP_FR_UN:
@@ -1184,12 +1229,33 @@ int run_sharded_dev(d377_ctx* ctx, int root, void* stream, Op op, int aux, const
   HIP_TRY(hipSetDevice(R.id));
   HIP_TRY(hipEventRecord(R.ev_shard, s));                 // the inputs are ready at this point of `stream`
   std::vector<size_t> used;
+  // An error after work has been enqueued on other devices' streams: nothing may still be writing into the caller's
+  // output buffers (or reading its inputs) once we return, so drain every stream touched so far and `stream` itself.
+  struct DrainOnError {
+    d377_ctx* ctx; std::vector<size_t>& used; size_t* cur; int root; hipStream_t s; int* rc;
+    ~DrainOnError() {
+      if (*rc == D377_OK) return;
+      char saved[sizeof d377_g_err];
+      memcpy(saved, d377_g_err, sizeof saved);
+      std::vector<size_t> all(used);
+      if (*cur != (size_t)-1) all.push_back(*cur);
+      for (size_t k : all) { (void)hipSetDevice(ctx->devs[k].id); (void)hipStreamSynchronize(ctx->devs[k].stream); }
+      (void)hipSetDevice(ctx->devs[(size_t)root].id);
+      (void)hipStreamSynchronize(s);
+      memcpy(d377_g_err, saved, sizeof saved);
+    }
+  };
+  size_t cur_dev = (size_t)-1;
+  int rc_final = D377_OK;
+  DrainOnError drain{ctx, used, &cur_dev, root, s, &rc_final};
+  auto body = [&]() -> int {
   for (size_t k = 0; k < nd; ++k) {
     const size_t lo = per * k;
     if (lo >= n) break;
     const size_t cnt = (lo + per <= n) ? per : n - lo;
     if ((int)k == root) continue;
     DeviceState& d = ctx->devs[k];
+    cur_dev = k;
     HIP_TRY(hipSetDevice(d.id));
     if ((rc = ensure_shard(d, 0, cnt * sh.in0))) return rc;
     if (sh.in1 && (rc = ensure_shard(d, 1, cnt * sh.in1))) return rc;
@@ -1203,6 +1269,7 @@ int run_sharded_dev(d377_ctx* ctx, int root, void* stream, Op op, int aux, const
     if (sh.out1 && out1) HIP_TRY(hipMemcpyPeerAsync((uint8_t*)out1 + lo * sh.out1, R.id, d.shard[3], d.id, cnt * sh.out1, d.stream));
     HIP_TRY(hipEventRecord(d.ev_shard, d.stream));
     used.push_back(k);
+    cur_dev = (size_t)-1;
   }
   HIP_TRY(hipSetDevice(R.id));
   {
@@ -1216,6 +1283,9 @@ int run_sharded_dev(d377_ctx* ctx, int root, void* stream, Op op, int aux, const
   }
   for (size_t k : used) HIP_TRY(hipStreamWaitEvent(s, ctx->devs[k].ev_shard, 0));   // `stream` continues once every slice is back
   return D377_OK;
+  };
+  rc_final = body();
+  return rc_final;
 }
 
 }  // namespace
@@ -1293,6 +1363,19 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count) {
   *count = 0;
   return D377_OK;                             // not a checking build
 #endif
+}
+int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int* max_blocks_per_cu, int* lds_pad_bytes) {
+  if (!ctx || dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "bad context or device index");
+  const DeviceState& d = ctx->devs[(size_t)dev];
+  int mb = 0, pad = 0;
+  for (int k = 0; k < CK_COUNT; ++k) {
+    if (d.chunk_blocks[k] > mb) mb = d.chunk_blocks[k];
+    if (d.chunk_lds[k] > pad) pad = d.chunk_lds[k];
+  }
+  if (sets_per_cu) *sets_per_cu = d.cus ? d.vb_blocks / d.cus : 0;
+  if (max_blocks_per_cu) *max_blocks_per_cu = mb;
+  if (lds_pad_bytes) *lds_pad_bytes = pad;
+  return D377_OK;
 }
 int d377_ctx_device_id(const d377_ctx* ctx, int dev) {
   if (!ctx || dev < 0 || (size_t)dev >= ctx->devs.size()) return -1;

@@ -35,27 +35,46 @@ struct ScratchGuard {
   int init() { HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); return D377_OK; }
   void destroy() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; used = false; }
   // A stream that is being captured into a hipGraph takes no part in the hand-over (an event recorded outside
-  // the capture cannot be waited on inside it): within the graph the launches keep their stream order, and a
-  // caller who replays graphs on several streams at once owns that ordering, as with any graph.
+  // the capture cannot be waited on inside it): within the graph the launches keep their stream order.  What that
+  // means for a replay that overlaps other calls is area-specific: the lane-set areas (window tables, inversion
+  // records) are claimed atomically by every workgroup and never reset, so overlapping kernels simply share them;
+  // the MSM workspace is exclusive, and a caller who replays a graph containing an MSM while another MSM of the same
+  // device is in flight on a different stream must order the two (include/decaf377_amd.h, "Threads and streams").
   static bool capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
   }
-  int acquire(hipStream_t s) { if (used && !capturing(s)) HIP_TRY(hipStreamWaitEvent(s, ev, 0)); return D377_OK; }
+  bool seen_capture = false;             // some launch on this area has been captured into a graph (see MsmWorkspace)
+  int acquire(hipStream_t s) {
+    if (capturing(s)) { seen_capture = true; return D377_OK; }
+    if (used) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+    return D377_OK;
+  }
   int release(hipStream_t s) { if (capturing(s)) return D377_OK; HIP_TRY(hipEventRecord(ev, s)); used = true; return D377_OK; }
   int drain() { if (used) HIP_TRY(hipEventSynchronize(ev)); return D377_OK; }   // before freeing the area
 };
 
-// workspace of the multi-scalar multiplication (msm.hip), grow-only
+// workspace of the multi-scalar multiplication (msm.hip), grow-only.  Once an MSM has been captured into a hipGraph the
+// graph holds pointers into the workspace it saw: from then on a workspace that is outgrown is retired (kept until the
+// context is destroyed) instead of freed, so a replay never touches freed memory.
 struct MsmWorkspace {
   uint8_t* mem = nullptr;
   size_t cap = 0;
   ScratchGuard guard;
+  std::vector<uint8_t*> retired;
 };
+
+// The kernels that work in chunks and claim a lane set of the per-device scratch areas (d377.hip: dcb_claim).  At most
+// WAVES_PER_SIMD workgroups of them may be resident per CU -- that is how many lane sets exist; d377_ctx_create checks
+// each with hipOccupancyMaxActiveBlocksPerMultiprocessor and pads the launch's LDS allocation for a kernel whose
+// registers and own LDS would let more in (chunk_lds, bytes of dynamic LDS per launch).
+enum ChunkKernel { CK_SQRT, CK_ENCODE, CK_HASH, CK_MUL_VAR, CK_MUL_BASE, CK_MUL_VAR_EL, CK_MAP_EL, CK_ENCODE_WIDE, CK_COUNT };
 
 struct DeviceState {
   int id = -1;
   int cus = 0;
+  int chunk_lds[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int chunk_blocks[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};     // resident workgroups per CU with that padding (occupancy query)
   uint32_t* gtab = nullptr;
   uint8_t* s_lookup = nullptr;
   uint32_t* fbase = nullptr;

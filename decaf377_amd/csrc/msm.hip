@@ -730,13 +730,23 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_f1 = carve((size_t)W * m2 * PT_WORDS * 4);
   int rc;
   if (off > d.msm.cap) {
+    if (ScratchGuard::capturing(s))
+      return fail(D377_ERR_ARG, "%s", "msm: the workspace must grow, which cannot happen inside a stream capture -- run one MSM of this size before capturing");
     if ((rc = d.msm.guard.drain())) return rc;          // a launch on another stream may still be using the old area
-    if (d.msm.mem) HIP_TRY(hipFree(d.msm.mem));
+    if (d.msm.mem) {
+      if (d.msm.guard.seen_capture) d.msm.retired.push_back(d.msm.mem);   // a captured graph may still point into it
+      else HIP_TRY(hipFree(d.msm.mem));
+    }
     d.msm.mem = nullptr; d.msm.cap = 0;
     HIP_TRY(hipMalloc(&d.msm.mem, off + off / 8));
     d.msm.cap = off + off / 8;
   }
+  struct Held {                                          // hand-over event on every path out, error or not
+    ScratchGuard& g; hipStream_t s; bool held;
+    ~Held() { if (held) (void)g.release(s); }
+  } held{d.msm.guard, s, false};
   if ((rc = d.msm.guard.acquire(s))) return rc;         // one workspace per device: queue behind its last user
+  held.held = true;
   uint8_t* m = d.msm.mem;
   uint32_t* pts = (uint32_t*)(m + o_pts);
   int16_t* dig = (int16_t*)(m + o_dig);
@@ -803,7 +813,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   }
   hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, T, cur_in, W, c, enc_out, xyzt_out);
   HIP_TRY(hipGetLastError());
-  return d.msm.guard.release(s);
+  return D377_OK;
 }
 
 // one device's share of a host batch: copies in, MSM, partial sum (Element record) and statuses out, synchronised

@@ -89,6 +89,13 @@ class Context:
             _native.check(rc)
         return rc == 1, int(c.value)
 
+    def chunk_residency(self, dev=0):
+        """(lane sets per CU, largest residency of a set-claiming kernel per CU, LDS padding in bytes):
+        d377_ctx_chunk_residency -- what d377_ctx_create verified with the occupancy query."""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _native.check(self._lib.d377_ctx_chunk_residency(self._h, dev, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.d377_ctx_destroy(self._h)

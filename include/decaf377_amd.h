@@ -29,8 +29,17 @@
  * up behind each other instead of racing -- results are the same as if the calls had been made one
  * after another; only their overlap is lost.  Kernels that use no scratch overlap freely.
  * `_dev` calls only enqueue kernels (no host synchronisation, no allocation once the workspaces have grown
- * to the batch size), so a sequence of them can be captured into a hipGraph and replayed; the scratch
- * hand-over is skipped on a capturing stream (the graph keeps its own order).
+ * to the batch size), so a sequence of them can be captured into a hipGraph and replayed.  A capturing stream takes
+ * no part in the event hand-over (the graph keeps its own order), so for a REPLAY that overlaps other calls on the same
+ * device:
+ *   - the lane-set areas (window tables, inversion records: every batch operation above) are safe -- each workgroup
+ *     claims a free set atomically and nothing resets the pool between launches, so a replay and an eager call, or two
+ *     replays, simply share them;
+ *   - the MSM workspace is exclusive: do not let a replay that contains d377_msm*_dev overlap another MSM of the same
+ *     device on a different stream (order them with the same stream or your own events);
+ *   - a workspace never shrinks, and once an MSM has been captured an outgrown workspace is kept until
+ *     d377_ctx_destroy instead of freed, so an old graph stays valid after later, larger calls; an MSM that would have
+ *     to grow the workspace DURING a capture fails with D377_ERR_ARG (run one call of that size first).
  *
  * Three families:
  *   d377_batch_*          host pointers; the library copies to the context's GPU(s), shards
@@ -75,6 +84,12 @@ int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out);
 void d377_ctx_destroy(d377_ctx* ctx);
 int d377_ctx_num_devices(const d377_ctx* ctx);
 int d377_ctx_device_id(const d377_ctx* ctx, int dev);
+/* The lane-set scratch areas hold `sets_per_cu` sets per compute unit; d377_ctx_create asks the runtime
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor) how many workgroups of each kernel that claims a set can be resident
+ * per CU, pads a kernel's launch with dynamic LDS when its registers alone would admit more, and fails with
+ * D377_ERR_INIT if one still exceeds the sets.  Reports the numbers it settled on: the largest residency over those
+ * kernels (<= sets_per_cu) and the largest LDS padding in use (0 when none was needed).  Any pointer may be NULL. */
+int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int* max_blocks_per_cu, int* lds_pad_bytes);
 /* Debug builds (-DD377_CHECK_INVARIANTS, the counterpart of the reference's debug assertions in
  * Element::new, src/min_curve/element.rs:104-110, and is_on_curve, src/ark_curve/on_curve.rs:14-39): how many
  * group elements failed the curve equation / T Z = X Y / Z != 0 after decompression, the Elligator map or on

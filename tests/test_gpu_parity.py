@@ -338,16 +338,23 @@ def test_full_size_fixed_base_2_20(ctx, torch_mod, oracle):
 
 
 def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
-    """The square-root-free compressor (curve.hpp `dcb_finish`; reference: src/ark_curve/encoding.rs:91-128) works in
-    rounds of 32 elements per lane on the persistent grid (2 blocks x 256 lanes per CU).  Batch sizes that leave lanes
-    with 0, 1, 31, 32 and 33 elements, and one that needs a second round for some lanes only, must give the oracle's
-    bytes on the first, the last (second-round) and a spread of the records -- for the variable-base, the fixed-base
-    and the Elligator kernels, with invalid encodings and identity results sprinkled in."""
+    """The square-root-free compressor (curve.hpp `dcb_finish`; reference: src/ark_curve/encoding.rs:91-128) and the
+    batched inversions work in chunks: one workgroup takes per_lane x 256 consecutive elements, per_lane = ceil(n /
+    resident lanes) capped at DCB_K = 8 (d377.hip `launch`; resident lanes = 2 workgroups x 256 lanes per CU = 131 072
+    on 256 CUs), and a lane inverts once for the per_lane elements it holds.  Sizes around every per_lane transition
+    (k x 131 072 +- 1 for k = 1..8: the last workgroup's lanes then hold per_lane, per_lane - 1 or 0 elements), sizes
+    that leave whole waves of the last chunk empty, and sizes several grid generations long must give the oracle's
+    bytes on the first and last records and a spread in between -- for the variable-base, the fixed-base and the
+    Elligator kernels, with invalid encodings and identity results sprinkled in, and in place."""
     torch = torch_mod
     dev = torch.device("cuda:0")
     lanes = torch.cuda.get_device_properties(0).multi_processor_count * 2 * 256
     g = torch.Generator(device=dev).manual_seed(9077)
-    for n in (lanes - 5, lanes + 7, 31 * lanes + 3, 32 * lanes, 32 * lanes + 4099):
+    sizes = [lanes - 5, lanes + 7, 31 * lanes + 3, 32 * lanes, 32 * lanes + 4099]
+    for kk in range(1, 9):
+        sizes += [kk * lanes - 1, kk * lanes, kk * lanes + 1]
+    sizes += [8 * lanes + 256 * 8 + 1, 255, 257, 64, 1]
+    for n in sorted(set(sizes)):
         r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
         k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
         enc = ctx.encode_to_curve(r0)
@@ -367,6 +374,64 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
         k2 = k.clone()
         ctx.scalar_mul_base(k2, outs=[k2])
         assert torch.equal(k2, fb), n
+
+
+def test_chunk_residency_is_checked(ctx):
+    """The lane-set pool of the scratch areas assumes at most `sets` resident workgroups per CU of every kernel that
+    claims a set.  d377_ctx_create verifies that with the occupancy query (and pads the launch's LDS where registers
+    alone would admit more) instead of trusting what the compiler happened to allocate; the numbers are reported."""
+    sets, blocks, pad = ctx.chunk_residency()
+    assert sets == 2 and 1 <= blocks <= sets
+    assert pad in (0, (160 * 1024) // 3 + 1024)
+
+
+def test_graph_replay_overlaps_eager_calls(ctx, oracle, torch_mod):
+    """A captured graph takes no part in the event hand-over of the scratch areas, so a replay may run while an eager
+    call from another stream uses the same lane-set areas.  Every workgroup claims a free set atomically and nothing
+    resets the pool between launches, so both must come out right (before: the eager call's pool reset could hand
+    two workgroups the same window tables).  Also: an MSM workspace that a graph has seen is retired, not freed, when
+    a later call outgrows it, and the old graph still replays correctly afterwards."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8123)
+    n = 1 << 17
+    r0 = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(dev)
+    k = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(dev)
+    enc = ctx.encode_to_curve(r0)
+    want_out, want_st = ctx.scalar_mul_var(enc, k)
+    want_fb = ctx.scalar_mul_base(k)
+    m = 3000
+    want_msm = ctx.msm(enc[:m], k[:m])[0].clone()
+    torch.cuda.synchronize()
+    sidx = np.arange(0, n, n // 64)
+    o_out, o_st = oracle.scalar_mul_var(enc[sidx].cpu().numpy(), k[sidx].cpu().numpy())
+    assert (want_out[sidx].cpu().numpy() == o_out).all()
+    g_out = torch.empty_like(want_out); g_st = torch.empty_like(want_st)
+    side = torch.cuda.Stream(device=dev)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        ctx.scalar_mul_var(enc, k, outs=[g_out, g_st])
+        g_msm = ctx.msm(enc[:m], k[:m])[0]
+    for rep in range(3):
+        g_out.zero_(); g_st.fill_(9)
+        torch.cuda.synchronize()
+        gr.replay()                                     # on torch's current stream ...
+        with torch.cuda.stream(side):                   # ... while eager calls on another stream use the same areas
+            e_fb = ctx.scalar_mul_base(k)
+            e_out, e_st = ctx.scalar_mul_var(enc, k)
+        torch.cuda.synchronize()
+        assert torch.equal(g_out, want_out) and torch.equal(g_st, want_st), rep
+        assert torch.equal(e_out, want_out) and torch.equal(e_st, want_st) and torch.equal(e_fb, want_fb), rep
+        assert torch.equal(g_msm, want_msm)
+    # outgrow the MSM workspace the graph has seen, then replay the old graph
+    big = 1 << 19
+    rb = torch.from_numpy(rng.integers(0, 256, (big, 32), dtype=np.uint8)).to(dev)
+    ctx.msm(ctx.encode_to_curve(rb), rb)
+    torch.cuda.synchronize()
+    g_out.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g_out, want_out) and torch.equal(g_msm, want_msm)
 
 
 def test_soak_tool_small():
