@@ -49,16 +49,12 @@ struct GlobalTab {
     return c;
   }
 };
-// shared fixed-base comb FB[i][j] = affine cached j * 2^(FB_BITS i) * B, [FB_WINDOWS][FB_ENTRIES][3 slots]
+// shared fixed-base comb FB[i][j] = affine cached j * 2^(FB_BITS i) * B, [FB_WINDOWS][FB_ENTRIES] 128-byte records
+// (device_util.hpp: pt_load_affine -- two sectors per gather; round 2's three 48-byte slots cost 3.25)
 struct FixedTab {
   const uint32_t* base;
   __device__ __forceinline__ gea load(int i, int j, bool swap) const {
-    const uint32_t* p = base + ((size_t)i * FB_ENTRIES + j) * FBW_ENTRY_WORDS;
-    gea c;
-    c.ypx = slot_load(p + (swap ? SLOT : 0));
-    c.ymx = slot_load(p + (swap ? 0 : SLOT));
-    c.kt = slot_load(p + 2 * SLOT);
-    return c;
+    return pt_load_affine(base + ((size_t)i * FB_ENTRIES + j) * FBW_ENTRY_WORDS, swap);
   }
 };
 
@@ -241,10 +237,11 @@ __global__ void __launch_bounds__(BLOCK) k_init_fbase(uint32_t* fb) {
   }
   const fe zi = fe_invert(acc.z);
   const fe x = fe_mul(acc.x, zi), y = fe_mul(acc.y, zi);
-  uint32_t* p = fb + (size_t)idx * FBW_ENTRY_WORDS;
-  slot_store(p, fe_carry(fe_add(y, x)));
-  slot_store(p + SLOT, fe_sub(y, x));
-  slot_store(p + 2 * SLOT, fe_mul(fe_mul(fe_const(FE_K), x), y));
+  gea c;
+  c.ypx = fe_carry(fe_add(y, x));
+  c.ymx = fe_sub(y, x);
+  c.kt = fe_mul(fe_mul(fe_const(FE_K), x), y);
+  pt_store_affine(fb + (size_t)idx * FBW_ENTRY_WORDS, c);
 }
 
 // --------------------------------------------------------------------------- batch kernels ---

@@ -15,7 +15,8 @@ constexpr int WAVES_PER_SIMD = D377_WAVES_PER_SIMD;   // occupancy the kernels a
 constexpr int SLOT = 12;                     // one field element slot in a table entry: 9 limbs + 3 pad = 3 x 16 B
 constexpr int VB_ENTRIES = 9;                // cached 0..8 times P
 constexpr int VB_ENTRY_WORDS = 4 * SLOT;     // ypx, ymx, z2, kt: 192 B, 64-B aligned
-constexpr int FBW_ENTRY_WORDS = 3 * SLOT;    // affine cached: ypx, ymx, kt: 144 B
+constexpr int AP_WORDS = 32;                 // affine cached point record: ypx, ymx, kt = 27 limbs in a 128-byte, 128-byte-aligned slot
+constexpr int FBW_ENTRY_WORDS = AP_WORDS;    // fixed-base comb entries are such records
 
 // ------------------------------------------------------------------ record I/O helpers ---
 __device__ __forceinline__ void load32(const uint8_t* base, size_t i, uint32_t w[8]) {
@@ -75,6 +76,35 @@ __device__ __forceinline__ fe slot_load(const uint32_t* p) {
   r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
   r.l[8] = c.x;
   return r;
+}
+
+// Cached AFFINE point record: Y+X, Y-X (both carried: a negative digit swaps them), 2dXY -- 27 limbs packed into a
+// 128-byte, 128-byte-aligned slot, fetched as seven 16-byte loads = exactly two 64-byte sectors per gather.  (Three
+// padded 48-byte slots, 144 bytes, straddle sector boundaries: 3.25 sectors per gather on average.)  Shared by the
+// MSM's point records and the fixed-base comb.
+__device__ __forceinline__ void pt_store_affine(uint32_t* p, const gea& c) {
+  uint32_t w[AP_WORDS];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { w[i] = c.ypx.l[i]; w[NL + i] = c.ymx.l[i]; w[2 * NL + i] = c.kt.l[i]; }
+#pragma unroll
+  for (int i = 3 * NL; i < AP_WORDS; ++i) w[i] = 0;
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < AP_WORDS / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ gea pt_load_affine(const uint32_t* p, bool swap) {
+  uint32_t w[28];
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+  gea c;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    c.ypx.l[i] = swap ? w[NL + i] : w[i];
+    c.ymx.l[i] = swap ? w[i] : w[NL + i];
+    c.kt.l[i] = w[2 * NL + i];
+  }
+  return c;
 }
 
 // the 8 odd powers of the fixed exponentiation, one LDS column per lane (bank = lane: no conflicts)

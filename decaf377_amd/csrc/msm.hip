@@ -49,35 +49,10 @@ constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a seri
 constexpr int SEG = 32;                 // points per lane in k_msm_segments
 
 // Every input point is normalised to affine form once (Z = 1 already after decompression; one batched inversion
-// per lane for Element inputs) and stored as a cached AFFINE record: Y+X, Y-X (both carried: a negative digit
-// swaps them by address), 2dXY -- 27 limbs in a 128-byte, 128-byte-aligned slot.  These records are gathered
-// once per window in bucket order (n x W records: the MSM's dominant HBM traffic), so two 64-byte sectors
-// instead of the three of a projective cached point, and a mixed addition (7 products) instead of 8.
-constexpr int AP_WORDS = 32;
-__device__ __forceinline__ void pt_store_affine(uint32_t* p, const gea& c) {
-  uint32_t w[AP_WORDS];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) { w[i] = c.ypx.l[i]; w[NL + i] = c.ymx.l[i]; w[2 * NL + i] = c.kt.l[i]; }
-#pragma unroll
-  for (int i = 3 * NL; i < AP_WORDS; ++i) w[i] = 0;
-  uint4* q = reinterpret_cast<uint4*>(p);
-#pragma unroll
-  for (int i = 0; i < AP_WORDS / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-__device__ __forceinline__ gea pt_load_affine(const uint32_t* p, bool swap) {
-  uint32_t w[28];
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-#pragma unroll
-  for (int i = 0; i < 7; ++i) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
-  gea c;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    c.ypx.l[i] = swap ? w[NL + i] : w[i];
-    c.ymx.l[i] = swap ? w[i] : w[NL + i];
-    c.kt.l[i] = w[2 * NL + i];
-  }
-  return c;
-}
+// per lane for Element inputs) and stored as a cached AFFINE record (device_util.hpp: pt_store_affine, 128 bytes,
+// 128-byte aligned).  These records are gathered once per window in bucket order (n x W records: the MSM's dominant
+// HBM traffic), so two 64-byte sectors instead of the three of a projective cached point, and a mixed addition
+// (7 products) instead of 8.
 // affine (x, y) -> cached affine; the identity (0, 1) for a point that contributes nothing
 __device__ __forceinline__ gea gea_from_affine(const fe& x, const fe& y) {
   gea c;

@@ -358,7 +358,8 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
         r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
         k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
         enc = ctx.encode_to_curve(r0)
-        idx = np.unique(np.concatenate([np.arange(40), np.arange(n - 300, n), np.arange(17, n, max(1, n // 97))]))
+        idx = np.unique(np.concatenate([np.arange(min(40, n)), np.arange(max(0, n - 300), n), np.arange(17, n, max(1, n // 97))]))
+        assert idx.min() >= 0 and idx.max() < n
         ti = torch.from_numpy(idx).to(dev)
         assert (enc[ti].cpu().numpy() == oracle.encode_to_curve(r0[ti].cpu().numpy())).all(), n
         raw = enc.clone()
@@ -367,7 +368,7 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
         out, st = ctx.scalar_mul_var(raw, k)
         o_out, o_st = oracle.scalar_mul_var(raw[ti].cpu().numpy(), k[ti].cpu().numpy())
         assert (out[ti].cpu().numpy() == o_out).all() and (st[ti].cpu().numpy() == o_st).all(), n
-        assert o_st.any() and not o_st.all()
+        assert n < 64 or (o_st.any() and not o_st.all())
         fb = ctx.scalar_mul_base(k)
         assert (fb[ti].cpu().numpy() == oracle.scalar_mul_base(k[ti].cpu().numpy())).all(), n
         # in place: the output records double as the parking places of the prefix products
