@@ -164,13 +164,15 @@ D377_HD bool fe_strict_is_zero(const fe& a) {
 // the same two field values are z^((m-1)/2) and its product with z, and everything after them is unchanged.
 template <bool NUM_IS_ONE, class PT>
 D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, const fe& den, fe* res,
-                                bool min_curve_root = false, const fe* inv_den = nullptr) {
+                                bool min_curve_root = false, const fe* inv_den = nullptr, bool use_inv = true) {
   const bool den_zero = fe_strict_is_zero(den);
   bool num_zero = false;
   if (!NUM_IS_ONE) num_zero = fe_strict_is_zero(num);
 
   fe v, uv;
-  if (inv_den != nullptr) {
+  // use_inv: a launch-uniform switch for callers that always hold a (possibly meaningless) inverse: a pointer that is
+  // null on one path and the address of a local on the other would force that local into scratch memory
+  if (inv_den != nullptr && use_inv) {
     const fe z = NUM_IS_ONE ? *inv_den : fe_mul(num, *inv_den);
     v = fe_pow_m12(z, pt);
     uv = fe_mul(v, z);
@@ -546,13 +548,14 @@ D377_HD fe ge_elligator_den(const fe& r0) {
   return fe_mul_strict(fe_mul(fe_add(r, one), fe_const(FE_A_MINUS_2D)), den);
 }
 template <class PT>
-D377_HD void ge_elligator_st(const SqrtTables& T, PT& pt, const fe& r0, fe* s_out, fe* t_out, const fe* inv_den = nullptr) {
+D377_HD void ge_elligator_st(const SqrtTables& T, PT& pt, const fe& r0, fe* s_out, fe* t_out, const fe* inv_den = nullptr,
+                             bool use_inv = true) {
   const fe one = fe_const(FE_ONE), dma = fe_const(FE_D_MINUS_A), dd = fe_const(FE_D);
   fe r = fe_mul(fe_const(FE_ZETA), fe_sqr(r0));                                   // :20
   fe den = fe_mul(fe_sub(fe_mul(dd, r), dma), fe_sub(fe_mul(dma, r), dd));        // :22
   fe num = fe_mul(fe_add(r, one), fe_const(FE_A_MINUS_2D));                       // :23
   fe isri;
-  const bool iss = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(num, den), &isri, false, inv_den);   // :25-26
+  const bool iss = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(num, den), &isri, false, inv_den, use_inv);   // :25-26
   isri = fe_select(iss, isri, fe_mul(isri, r0));                                  // twiddle, :28-38
   fe s = fe_mul(isri, num);                                                       // :40
   fe p = fe_mul(fe_mul(fe_mul(isri, s), fe_sub(r, one)), fe_const(FE_A_MINUS_2D_SQ));
@@ -572,9 +575,9 @@ D377_HD ge ge_from_jacobi_st(const fe& s, const fe& t) {
   return o;
 }
 template <class PT>
-D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0, const fe* inv_den = nullptr) {
+D377_HD ge ge_elligator_map(const SqrtTables& T, PT& pt, const fe& r0, const fe* inv_den = nullptr, bool use_inv = true) {
   fe s, t;
-  ge_elligator_st(T, pt, r0, &s, &t, inv_den);
+  ge_elligator_st(T, pt, r0, &s, &t, inv_den, use_inv);
   ge o = ge_from_jacobi_st(s, t);
   D377_INVARIANT(T, o, true);                                                     // :56-59
   return o;
@@ -828,6 +831,31 @@ D377_HD ge ge_add_affine(const ge& p, const gea& q, bool neg, bool with_t) {
   r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g);
   r.t = p.t;
   if (with_t) r.t = fe_mul(e, h);
+  return r;
+}
+
+// ---- cached affine records (the MSM's point records, the fixed-base comb) -----------------------
+// affine (x, y) -> cached affine; the identity (0, 1) for a point that contributes nothing
+D377_HD gea gea_from_affine(const fe& x, const fe& y) {
+  gea c;
+  c.ypx = fe_carry(fe_add(y, x));
+  c.ymx = fe_sub(y, x);
+  c.kt = fe_mul(fe_mul(fe_const(FE_K), x), y);
+  return c;
+}
+// The point of a cached affine record in extended coordinates with Z = 2: X = 2x = (y+x) - (y-x), Y = 2y, T = X Y / Z =
+// 2xy = (2/K) * (K x y): the first point of a run costs 4 products instead of a 7-product addition to the identity.
+// The record's y-x is a carried difference (value up to 41q, beyond what a subtrahend may be: fq29.hpp), so it is
+// brought down by a product with 1 first, and X, Y leave as products like the coordinates every group formula expects.
+// (swap / neg: the record of -P has y+x and y-x exchanged by the loader, which negates X; T follows.)
+D377_HD ge ge_from_cached_affine(const gea& q, bool neg) {
+  const fe one = fe_const(FE_ONE);
+  ge r;
+  r.x = fe_mul(fe_sub(q.ypx, fe_mul(q.ymx, one)), one);
+  r.y = fe_mul(fe_add(q.ypx, q.ymx), one);
+  r.z = fe_const(FE_TWO);
+  const fe t = fe_mul(q.kt, fe_const(FE_2_OVER_K));
+  r.t = fe_select(neg, fe_neg(t), t);
   return r;
 }
 

@@ -121,11 +121,19 @@ __device__ __forceinline__ void dcb_release(const DcbScratch& sc, int slot) {
 // in records 0 .. NINV-1, they are inverted together (one divsteps inversion per lane), phase 1 does the element's
 // work with those inverses, and when the operation ends in an encoding of a point whose isogeny preimage it knows
 // (FINISH) the square-root-free compressor closes the chunk.
-// phase1(i, j, inv): inv[s] = the eight words of 1 / (denominator s of element j) (fe_from_words makes them a field element)
-template <int NINV, bool FINISH, class PT, class P0, class P1>
+// phase1(i, j, inv, have): inv[s] = the eight words of 1 / (denominator s of element j) (fe_from_words makes them a field
+// element) when `have`; otherwise there are no inverses this launch: take the square roots in the reference's
+// inversion-free form.
+// A shared inversion costs ~26 000 instructions per lane plus 4 products per element; the chain it replaces in each
+// square root (den^(2^47-1), 46 S + 9 M) ~9 500: with fewer than DCB_ASSIST_MIN elements per lane the inversion loses,
+// and at those batch sizes (n <= 2 x the resident lanes) its latency is the whole call.  SMALL_OK = false keeps a
+// kernel on the always-assisted form (k_scalar_mul_var: its codegen is left exactly as it was measured).
+constexpr int DCB_ASSIST_MIN = 3;
+template <int NINV, bool FINISH, bool SMALL_OK = true, class PT, class P0, class P1>
 __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1) {
   constexpr int NW = NINV > 0 ? NINV : 1;
   const int per_lane = io.per_lane;
+  const bool assist = NINV > 0 && (!SMALL_OK || per_lane >= DCB_ASSIST_MIN);      // uniform over the launch
   const size_t CHUNK = (size_t)per_lane * BLOCK;
   for (size_t chunk = blockIdx.x; chunk * CHUNK < n; chunk += gridDim.x) {
     io.base = chunk * CHUNK + threadIdx.x;
@@ -134,17 +142,21 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
     for (int j = 0; j < per_lane; ++j) {
       const size_t i = io.base + (size_t)j * BLOCK;
       if (i >= n) break;
-      if (NINV > 0) phase0(i, j);
+      if (assist) phase0(i, j);
       cnt = j + 1;
     }
+    if (assist) {
 #pragma unroll 1
-    for (int sl = 0; sl < NINV; ++sl) dcb_invert_slot(io, sl, cnt);
+      for (int sl = 0; sl < NINV; ++sl) dcb_invert_slot(io, sl, cnt);
+    }
 #pragma unroll 1
     for (int j = 0; j < cnt; ++j) {
-      uint32_t cur[NW][8];
+      uint32_t cur[NW][8] = {};
+      if (assist) {
 #pragma unroll
-      for (int sl = 0; sl < NINV; ++sl) io.get(sl, j, cur[sl]);
-      phase1(io.base + (size_t)j * BLOCK, j, cur);
+        for (int sl = 0; sl < NINV; ++sl) io.get(sl, j, cur[sl]);
+      }
+      phase1(io.base + (size_t)j * BLOCK, j, cur, assist);
     }
     if (FINISH) dcb_finish(pt, io, cnt);
   }
@@ -257,14 +269,14 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtT
       load32(den32, i, wd);
       dcb_put_den(io, 0, j, fe_from_words_mod_order_strict(wd));
     },
-    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+    [&](size_t i, int j, const uint32_t (*invw)[8], bool have) {
       uint32_t wn[8], wd[8], wr[8];
       load32(num32, i, wn);
       load32(den32, i, wd);
-      const fe inv = fe_from_words(invw[0]);
+      fe inv = fe_from_words(invw[0]);            // meaningless words when !have (never read then)
       fe r;
       const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, fe_from_words_mod_order_strict(wn), fe_from_words_mod_order_strict(wd), &r,
-                                                min_curve_root != 0, &inv);
+                                                min_curve_root != 0, &inv, have);
       fe_to_bytes_words(r, wr);
       store32(root32, i, wr);
       was_square[i] = ws ? 1 : 0;
@@ -333,12 +345,12 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtT
       load32(fq32, i, w);
       dcb_put_den(io, 0, j, ge_elligator_den(fe_from_words_mod_order(w)));
     },
-    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+    [&](size_t i, int j, const uint32_t (*invw)[8], bool have) {
       uint32_t w[8];
       load32(fq32, i, w);
-      const fe inv = fe_from_words(invw[0]);
+      fe inv = fe_from_words(invw[0]);            // meaningless words when !have (never read then)
       fe s, t;
-      ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s, &t, &inv);
+      ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s, &t, &inv, have);
       D377_INVARIANT(T, ge_from_jacobi_st(s, t), true);
       dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
     });
@@ -359,14 +371,14 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTab
       load32(r2, i, w);
       dcb_put_den(io, 1, j, ge_elligator_den(fe_from_words_mod_order(w)));
     },
-    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+    [&](size_t i, int j, const uint32_t (*invw)[8], bool have) {
       uint32_t w[8];
       load32(r1, i, w);
-      fe inv = fe_from_words(invw[0]);
-      const ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv);
+      fe inv = fe_from_words(invw[0]);            // meaningless words when !have (never read then)
+      const ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv, have);
       load32(r2, i, w);
       inv = fe_from_words(invw[1]);
-      const ge b = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv);
+      const ge b = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv, have);
       ge_compress(T, pt, ge_add(a, b), w);
       store32(out32, i, w);
     });
@@ -383,13 +395,13 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
   tab.base = scratch;
   tab.nthreads = io.nlanes;
   tab.tid = io.lane;
-  dcb_rounds<1, true>(n, io, pt,
+  dcb_rounds<1, true, false>(n, io, pt,
     [&](size_t i, int j) {
       uint32_t w[8];
       load32(enc32, i, w);
       dcb_put_den(io, 0, j, ge_decompress_den(w));
     },
-    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+    [&](size_t i, int j, const uint32_t (*invw)[8], bool have) {
       uint32_t w[8], k[8], dg[8];
       load32(enc32, i, w);
       load32(scalar32, i, k);
@@ -414,7 +426,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
   FixedTab ft{fbase};
   dcb_rounds<0, true>(n, io, pt,
     [&](size_t, int) {},
-    [&](size_t i, int j, const uint32_t (*)[8]) {
+    [&](size_t i, int j, const uint32_t (*)[8], bool) {
       uint32_t k[8];
       load32(scalar32, i, k);
       fr_reduce_words(k);
@@ -487,15 +499,15 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_map_to_element(SqrtTa
       if (r2) load32(r2, i, w);                            // without a second input slot 1 repeats slot 0 (unused)
       dcb_put_den(io, 1, j, ge_elligator_den(fe_from_words_mod_order(w)));
     },
-    [&](size_t i, int j, const uint32_t (*invw)[8]) {
+    [&](size_t i, int j, const uint32_t (*invw)[8], bool have) {
       uint32_t w[8];
       load32(r1, i, w);
-      fe inv = fe_from_words(invw[0]);
-      ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv);
+      fe inv = fe_from_words(invw[0]);            // meaningless words when !have (never read then)
+      ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv, have);
       if (r2) {
         load32(r2, i, w);
         inv = fe_from_words(invw[1]);
-        a = ge_add(a, ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv));
+        a = ge_add(a, ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv, have));
       }
       store_ge_mont256(out, i, a);
     });
@@ -529,10 +541,10 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(
   D377_DCB_BEGIN(out32);
   dcb_rounds<1, true>(n, io, pt,
     [&](size_t i, int j) { dcb_put_den(io, 0, j, ge_elligator_den(fe_carry(load_wide(in, i, len)))); },
-    [&](size_t i, int j, const uint32_t (*invw)[8]) {
-      const fe inv = fe_from_words(invw[0]);
+    [&](size_t i, int j, const uint32_t (*invw)[8], bool have) {
+      fe inv = fe_from_words(invw[0]);            // meaningless words when !have (never read then)
       fe s, t;
-      ge_elligator_st(T, pt, fe_carry(load_wide(in, i, len)), &s, &t, &inv);
+      ge_elligator_st(T, pt, fe_carry(load_wide(in, i, len)), &s, &t, &inv, have);
       D377_INVARIANT(T, ge_from_jacobi_st(s, t), true);
       dcb_put(io, j, ge_dcb_from_jacobi_st(s, t));
     });

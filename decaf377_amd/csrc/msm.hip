@@ -46,21 +46,15 @@ namespace {
 constexpr int PT_WORDS = 4 * SLOT;      // one cached or extended point record: 192 B
 constexpr int CHUNK = 8;                // buckets per lane in k_msm_chunks (short chains: this phase is latency-bound)
 constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a serial chain per lane: short chains, more levels)
-constexpr int SEG = 32;                 // points per lane in k_msm_segments
+constexpr int RED = 32;                 // partial sums per lane in the further reduction levels (k_msm_reduce)
+// Points per lane in k_msm_segments (`seg`, a launch parameter): 8, 16 or 32 by batch size -- pick_seg() below.
+constexpr int MAX_SEG = 128;
 
 // Every input point is normalised to affine form once (Z = 1 already after decompression; one batched inversion
 // per lane for Element inputs) and stored as a cached AFFINE record (device_util.hpp: pt_store_affine, 128 bytes,
 // 128-byte aligned).  These records are gathered once per window in bucket order (n x W records: the MSM's dominant
 // HBM traffic), so two 64-byte sectors instead of the three of a projective cached point, and a mixed addition
 // (7 products) instead of 8.
-// affine (x, y) -> cached affine; the identity (0, 1) for a point that contributes nothing
-__device__ __forceinline__ gea gea_from_affine(const fe& x, const fe& y) {
-  gea c;
-  c.ypx = fe_carry(fe_add(y, x));
-  c.ymx = fe_sub(y, x);
-  c.kt = fe_mul(fe_mul(fe_const(FE_K), x), y);
-  return c;
-}
 __device__ __forceinline__ void pt_store_ext(uint32_t* p, const ge& g) {
   slot_store(p, g.x); slot_store(p + SLOT, g.y); slot_store(p + 2 * SLOT, g.z); slot_store(p + 3 * SLOT, g.t);
 }
@@ -113,35 +107,46 @@ k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, s
   }
 }
 
-// Elements (any Z): Montgomery's trick per lane, as in k_to_affine -- forward pass multiplies the z's of the
+// Elements.  Decompression output and affine inputs have Z = 1 (the record's words are those of 1 * 2^256 mod q); then
+// the points are affine already and need no inversion.  k_msm_prepare_affine (one lane per point, the wide grid) does
+// that work for every point whose Z is 1 and raises *flag when it meets any other Z; k_msm_prepare_el (Montgomery's
+// trick, ~32 points per lane sharing one inversion, every point again) runs only when the flag is up and returns at
+// once otherwise.  (Round 2 made the choice per wave inside the 32-per-lane kernel, which left the common Z = 1 case
+// on a grid sized for sharing inversions it did not need: 0.48 ms per 2^22 points.)
+__global__ void __launch_bounds__(BLOCK, 4)
+k_msm_prepare_affine(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c, int W, uint32_t* pts, int16_t* digits,
+                     uint32_t* flag) {
+  const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
+  bool all_one = true;
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    uint32_t w[8];
+    load32(b, 4 * i + 2, w);
+    bool one = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) one &= w[k] == ONE_MONT256_WORDS[k];
+    all_one &= one;
+    if (!one) continue;                                   // k_msm_prepare_el redoes the whole batch
+    load32(b, 4 * i + 0, w);
+    const fe x = fe_from_mont256_words(w);
+    load32(b, 4 * i + 1, w);
+    const fe y = fe_from_mont256_words(w);
+    pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
+    msm_write_digits(scalar32, i, n, c, W, false, digits);
+  }
+  if (__any(!all_one) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+// Elements with some Z != 1: Montgomery's trick per lane, as in k_to_affine -- forward pass multiplies the z's of the
 // lane's grid-stride elements up, parking each prefix product in the element's own record slot; one inversion;
 // the backward pass peels 1/z_i off, writes the affine record and the digits.  A record with z = 0 is no group
 // element: it becomes the identity with digits 0.
 __global__ void __launch_bounds__(BLOCK, 4)
-k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c, int W, uint32_t* pts, int16_t* digits) {
+k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c, int W, uint32_t* pts, int16_t* digits,
+                 const uint32_t* flag) {
+  if (*flag == 0) return;
   const size_t Tn = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (t >= n) return;
   const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
-  // Pass 0: is every Z this wave will see the canonical 1 (decompress output, the common case)?  Then the points
-  // are affine already: convert x and y and build the records, no products of Z and no inversion.
-  bool all_one = true;
-  for (size_t i = t; i < n; i += Tn) {
-    uint32_t w[8];
-    load32(b, 4 * i + 2, w);
-    for (int k = 0; k < 8; ++k) all_one &= w[k] == ONE_MONT256_WORDS[k];
-  }
-  if (!__any(!all_one)) {
-    for (size_t i = t; i < n; i += Tn) {
-      uint32_t w[8];
-      load32(b, 4 * i + 0, w);
-      const fe x = fe_from_mont256_words(w);
-      load32(b, 4 * i + 1, w);
-      const fe y = fe_from_mont256_words(w);
-      pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
-      msm_write_digits(scalar32, i, n, c, W, false, digits);
-    }
-    return;
-  }
   fe p = fe_const(FE_ONE);
   size_t last = t;
   for (size_t i = t; i < n; i += Tn) {
@@ -200,13 +205,13 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digit
 // Prefix sums of the sort, two small kernels over workgroups (window, 1024 buckets).
 // In: blockhist[w][s][b] = points of slice s in bucket b.  Out: blockhist[w][s][b] = points of the slices before s in
 // bucket b; offs[w][0..nb] = exclusive prefix of the bucket sizes (offs[w][nb] = total); segoff[l][w][0..nb],
-// l = 0..REDUCE_LEVELS-1 = the same for ceil(size / SEG^(l+1)): the number of SEG-point segments per bucket, of
-// SEG-segment groups, ... (the levels of the bucket reduction).  k_msm_scan1 leaves prefixes local to its 1024 buckets
+// l = 0..REDUCE_LEVELS-1 = the same for ceil(size / seg), ceil(that / RED), ...: the number of seg-point segments per
+// bucket, of RED-segment groups, ... (the levels of the bucket reduction).  k_msm_scan1 leaves prefixes local to its 1024 buckets
 // and the four totals of the workgroup in tot[w][chunk][]; k_msm_scan2 adds the totals of the chunks before.  (One
 // workgroup per window walking its buckets 1024 at a time took 0.12 ms at every size: 18 workgroups on 256 CUs.)
 constexpr int REDUCE_LEVELS = 3;
 __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, uint32_t* tot, int nb,
-                                                    int S, int W, int nchunk) {
+                                                    int S, int W, int nchunk, int seg) {
   __shared__ uint32_t part[1 + REDUCE_LEVELS][1024];
   const int w = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk, t = threadIdx.x;
   const int len = nb + 1;
@@ -221,7 +226,8 @@ __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_
     }
   uint32_t own[1 + REDUCE_LEVELS];
   own[0] = c;
-  for (int l = 1; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + SEG - 1) / SEG;
+  own[1] = (own[0] + (uint32_t)seg - 1) / (uint32_t)seg;
+  for (int l = 2; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + RED - 1) / RED;
   for (int l = 0; l <= REDUCE_LEVELS; ++l) part[l][t] = own[l];
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -414,13 +420,13 @@ __device__ __forceinline__ size_t msm_window_base(const uint32_t* so_all, int w,
   return base;
 }
 
-// One lane per SEG-point segment of a bucket run (runs are Poisson-distributed around n / 2^(c-1);
+// One lane per seg-point segment of a bucket run (runs are Poisson-distributed around n / 2^(c-1);
 // one lane per whole bucket left lanes of a wave waiting for the longest run and quantised the
-// grid to ~1.1 residency rounds).  Lane gi finds its (window, bucket, segment), adds its <= SEG cached points
+// grid to ~1.1 residency rounds).  Lane gi finds its (window, bucket, segment), adds its <= seg cached points
 // (next record in flight while the current one is added) and writes one partial sum.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, const uint32_t* segoff, size_t n, int W,
-               int nb, size_t max_segs, uint32_t* partial) {
+               int nb, size_t max_segs, int seg, uint32_t* partial) {
   const int len = nb + 1;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_segs; gi += (size_t)gridDim.x * BLOCK) {
     int w, b;
@@ -428,14 +434,21 @@ k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, c
     size_t base;
     if (!msm_locate(gi, segoff, W, nb, &w, &b, &k, &base)) break;   // beyond the last real segment
     const uint32_t run_lo = offs[(size_t)w * len + b], run_hi = offs[(size_t)w * len + b + 1];
-    uint32_t lo = run_lo + k * SEG, hi = lo + SEG;
+    uint32_t lo = run_lo + k * (uint32_t)seg, hi = lo + (uint32_t)seg;
     if (hi > run_hi) hi = run_hi;
     ge acc = ge_identity();
     if (lo < hi) {
       uint32_t e = idx[(size_t)w * n + lo];
       gea q = pt_load_affine(pts + (size_t)(e & 0x7FFFFFFFu) * AP_WORDS, (e >> 31) != 0);
+      const bool neg0 = (e >> 31) != 0;
+      const gea first = q;
+      if (lo + 1 < hi) {
+        e = idx[(size_t)w * n + lo + 1];
+        q = pt_load_affine(pts + (size_t)(e & 0x7FFFFFFFu) * AP_WORDS, (e >> 31) != 0);
+      }
+      acc = ge_from_cached_affine(first, neg0);
 #pragma unroll 1
-      for (uint32_t j = lo; j < hi; ++j) {
+      for (uint32_t j = lo + 1; j < hi; ++j) {
         const bool neg = (e >> 31) != 0;
         const gea cur = q;
         if (j + 1 < hi) {
@@ -449,10 +462,10 @@ k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, c
   }
 }
 
-// A further level of the same reduction: one lane per group of <= SEG partial sums of one bucket (so_in: prefix of
+// A further level of the same reduction: one lane per group of <= RED partial sums of one bucket (so_in: prefix of
 // the partials per bucket, so_out: of the groups).  With random scalars a bucket has a handful of partials and one
 // level finishes it; with many equal scalars (all coefficients 1, say) a run holds most of the n points, and every
-// level cuts its partials by SEG instead of leaving them to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
+// level cuts its partials by RED instead of leaving them to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, int W, int nb, size_t max_groups, uint32_t* out) {
   const int len = nb + 1;
@@ -463,11 +476,14 @@ k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, 
     if (!msm_locate(gi, so_out, W, nb, &w, &b, &k, &base)) break;
     const size_t in_base = msm_window_base(so_in, w, nb);
     const uint32_t s0 = so_in[(size_t)w * len + b], s1 = so_in[(size_t)w * len + b + 1];
-    uint32_t lo = s0 + k * SEG, hi = lo + SEG;
+    uint32_t lo = s0 + k * RED, hi = lo + RED;
     if (hi > s1) hi = s1;
     ge acc = ge_identity();
+    if (lo < hi) {                                       // a group of one is copied, not added to the identity
+      acc = pt_load_ext(in + (in_base + lo) * PT_WORDS);
 #pragma unroll 1
-    for (uint32_t j = lo; j < hi; ++j) acc = ge_add(acc, pt_load_ext(in + (in_base + j) * PT_WORDS));
+      for (uint32_t j = lo + 1; j < hi; ++j) acc = ge_add(acc, pt_load_ext(in + (in_base + j) * PT_WORDS));
+    }
     pt_store_ext(out + gi * PT_WORDS, acc);
   }
 }
@@ -482,8 +498,11 @@ k_msm_buckets(const uint32_t* partial, const uint32_t* segoff, int W, int nb, ui
     const size_t base = msm_window_base(segoff, w, nb);
     const uint32_t s0 = segoff[(size_t)w * len + b], s1 = segoff[(size_t)w * len + b + 1];
     ge acc = ge_identity();
+    if (s0 < s1) {
+      acc = pt_load_ext(partial + (base + s0) * PT_WORDS);
 #pragma unroll 1
-    for (uint32_t j = s0; j < s1; ++j) acc = ge_add(acc, pt_load_ext(partial + (base + j) * PT_WORDS));
+      for (uint32_t j = s0 + 1; j < s1; ++j) acc = ge_add(acc, pt_load_ext(partial + (base + j) * PT_WORDS));
+    }
     pt_store_ext(buckets + gi * PT_WORDS, acc);
   }
 }
@@ -498,8 +517,12 @@ k_msm_chunks(const uint32_t* buckets, int W, int nb, int nchunks, uint32_t* chun
     int hi = lo + CHUNK - 1;
     if (hi > nb - 1) hi = nb - 1;
     ge run = ge_identity(), acc = ge_identity();
+    if (hi >= lo) {
+      run = pt_load_ext(buckets + ((size_t)w * nb + hi) * PT_WORDS);
+      acc = run;
+    }
 #pragma unroll 1
-    for (int b = hi; b >= lo; --b) {
+    for (int b = hi - 1; b >= lo; --b) {
       run = ge_add(run, pt_load_ext(buckets + ((size_t)w * nb + b) * PT_WORDS));
       acc = ge_add(acc, run);                       // acc = sum (b - lo + 1) * B_b
     }
@@ -654,6 +677,18 @@ int pick_window(size_t n) {
   return c;
 }
 
+// Points per segment lane.  Measured on one MI355X (D377_MSM_SEG sweep, whole MSM, Elements): 2^20 points 2.12 / 2.15 /
+// 2.26 / 2.64 ms and 2^22 points 6.70 / 6.62 / 6.71 / 6.97 ms with 16 / 32 / 64 / 128 -- once a group of one partial is
+// copied instead of added to the identity, more and shorter segments cost little afterwards and balance the last
+// generation of lanes better.  Small batches take 8: the longest serial chain is what such a call waits for.
+int pick_seg(const DeviceState& d, size_t n, int W) {
+  (void)d;
+  const size_t adds = n * (size_t)W;
+  int seg = adds >= ((size_t)1 << 26) ? 32 : adds >= ((size_t)1 << 22) ? 16 : 8;
+  if (const char* e = getenv("D377_MSM_SEG")) { int v = atoi(e); if (v >= 1 && v <= MAX_SEG) seg = v; }   // developer override (sweeps)
+  return seg;
+}
+
 int grid_of(const DeviceState& d, size_t n) {
   size_t blocks = (n + BLOCK - 1) / BLOCK;
   size_t cap = (size_t)d.cus * 32;
@@ -679,6 +714,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   if ((size_t)S > (n + 8191) / 8192) S = (int)((n + 8191) / 8192);
   if (S < 1) S = 1;
   const size_t per = (n + (size_t)S - 1) / (size_t)S;
+  const size_t o_flag = carve(256);
   const size_t o_pts = carve(n * AP_WORDS * 4);
   const size_t o_dig = carve((size_t)W * n * 2);
   const size_t o_bh = carve((size_t)W * S * nb * 4);
@@ -686,15 +722,17 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_seg = carve((size_t)REDUCE_LEVELS * W * (nb + 1) * 4);
   const int scan_chunks = (nb + 1 + 1023) / 1024;
   const size_t o_tot = carve((size_t)W * scan_chunks * (1 + REDUCE_LEVELS) * 4);
-  const size_t max_segs = ((size_t)n * W) / SEG + (size_t)W * nb;      // sum of ceil(run / SEG) never exceeds this
-  const size_t o_par = carve(max_segs * PT_WORDS * 4);
+  const int seg = pick_seg(d, n, W);
+  const size_t max_segs = ((size_t)n * W) / (size_t)seg + (size_t)W * nb;      // sum of ceil(run / seg) never exceeds this
+  // the level-1 index array of the sort (W * n words) borrows the segment partials' area, which is free until k_msm_segments
+  const size_t par_bytes = max_segs * PT_WORDS * 4, tmp_bytes = (size_t)W * n * 4;
+  const size_t o_par = carve(par_bytes > tmp_bytes ? par_bytes : tmp_bytes);
   const size_t o_idx = carve((size_t)W * n * 4);
   const size_t o_sub = carve((size_t)W * n);                            // level-1 placement: bucket index within the super-bucket
-  static_assert(PT_WORDS >= SEG, "the level-1 index array borrows the segment partials' area");
   const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
-  // further levels of the bucket reduction: groups of SEG partials, then groups of those (never more than this many)
+  // further levels of the bucket reduction: groups of RED partials, then groups of those (never more than this many)
   const int levels = n <= ((size_t)1 << 11) ? 1 : n <= ((size_t)1 << 16) ? 2 : REDUCE_LEVELS;
-  const size_t max_g2 = max_segs / SEG + (size_t)W * nb, max_g3 = max_g2 / SEG + (size_t)W * nb;
+  const size_t max_g2 = max_segs / RED + (size_t)W * nb, max_g3 = max_g2 / RED + (size_t)W * nb;
   const size_t o_r2 = carve(levels >= 2 ? max_g2 * PT_WORDS * 4 : 0);
   const size_t o_r3 = carve(levels >= 3 ? max_g3 * PT_WORDS * 4 : 0);
   const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
@@ -728,7 +766,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   uint32_t *bh = (uint32_t*)(m + o_bh), *offs = (uint32_t*)(m + o_off);
   uint32_t *segoff = (uint32_t*)(m + o_seg), *partial = (uint32_t*)(m + o_par);
   uint32_t* idx = (uint32_t*)(m + o_idx);
-  uint32_t* tmp_idx = partial;                                // W * n words <= max_segs records: free until k_msm_segments writes it
+  uint32_t* tmp_idx = partial;                                // free until k_msm_segments writes it
   uint8_t* tmp_sub = m + o_sub;
   uint32_t *bkt = (uint32_t*)(m + o_bkt), *ch = (uint32_t*)(m + o_ch), *f0 = (uint32_t*)(m + o_f0), *f1 = (uint32_t*)(m + o_f1);
   const SqrtTables T = d.tables();
@@ -742,22 +780,26 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
       hipLaunchKernelGGL(k_msm_prepare_enc, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, c, W, pts,
                          dig, status);
     } else {
+      uint32_t* zflag = (uint32_t*)(m + o_flag);
+      HIP_TRY(hipMemsetAsync(zflag, 0, sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k_msm_prepare_affine, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, (const uint64_t*)pts_in, scalars, n, c, W, pts,
+                         dig, zflag);
       // ~32 elements per lane share one inversion, but never fewer lanes than one wave per SIMD (see k_to_affine)
       size_t lanes = (n + 31) / 32;
       const size_t fill = (size_t)d.cus * BLOCK;
       if (lanes < fill) lanes = fill < n ? fill : n;
       hipLaunchKernelGGL(k_msm_prepare_el, dim3((unsigned)((lanes + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, (const uint64_t*)pts_in,
-                         scalars, n, c, W, pts, dig);
+                         scalars, n, c, W, pts, dig, zflag);
     }
   }
   hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
   uint32_t* tot = (uint32_t*)(m + o_tot);
-  hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, segoff, tot, nb, S, W, scan_chunks);
+  hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, segoff, tot, nb, S, W, scan_chunks, seg);
   hipLaunchKernelGGL(k_msm_scan2, dim3(W * scan_chunks), dim3(1024), 0, s, offs, segoff, tot, nb, W, scan_chunks);
   hipLaunchKernelGGL(k_msm_place1, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
   hipLaunchKernelGGL(k_msm_place2, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
   hipLaunchKernelGGL(k_msm_segments, dim3(grid_of(d, max_segs)), dim3(BLOCK), 0, s, pts, idx, offs, segoff, n, W, nb,
-                     max_segs, partial);
+                     max_segs, seg, partial);
   const uint32_t* last = partial;                      // what k_msm_buckets finishes, with its prefix array
   const uint32_t* last_so = segoff;
   const size_t so_stride = (size_t)W * (nb + 1);

@@ -223,6 +223,25 @@ void sim_raw_forms(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* sum
     f_ok[i] = ok ? 1 : 0;
   }
 }
+// msm.hip's per-lane chain for one bucket run, twice, and the reduction level above it: points -> cached affine
+// records (a negative digit exchanges y+x / y-x as the loader does), the first point of a run taken as is
+// (ge_from_cached_affine), mixed additions for the rest, then one full addition of the two partial sums.
+// xyzt: n x 32 words (Z = 1 records: decompress output), negs: one byte per point.  n >= 2.
+void sim_msm_bucket(const uint32_t* xyzt, const uint8_t* negs, size_t n, uint32_t* out) {
+  auto run = [&](size_t lo, size_t hi) {
+    ge acc = ge_identity();
+    for (size_t i = lo; i < hi; ++i) {
+      const ge p = ge_load256(xyzt + 32 * i);
+      gea q = gea_from_affine(p.x, p.y);
+      const bool neg = negs[i] != 0;
+      if (neg) { fe t = q.ypx; q.ypx = q.ymx; q.ymx = t; }
+      acc = (i == lo) ? ge_from_cached_affine(q, neg) : ge_add_affine(acc, q, neg, true);
+    }
+    return acc;
+  };
+  const ge a = run(0, n / 2), b = run(n / 2, n);
+  ge_store256(ge_add(ge_add(a, b), ge_add(a, a)), out);          // a + b + 2a: partial sums meet in every position of ge_add
+}
 // Element - Element as k_add does it with negate = 1
 void sim_raw_ge_sub(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* out) {
   for (size_t i = 0; i < n; ++i) {

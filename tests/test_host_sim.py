@@ -488,6 +488,7 @@ L.sim_scalar_mul_var(p(enc), p(k), n_(n), p(out), p(st))
 L.sim_scalar_mul_base(p(k), n_(n), p(out))
 L.sim_double_variants(p(xyzt), n_(n), p(x2), p(a), p(b))
 L.sim_group_misc(p(xyzt), p(x2), n_(n), p(a), p(b))
+L.sim_decompress(p(enc), n_(n), p(x2), p(st)); L.sim_msm_bucket(p(x2), p(np.array([0, 1, 1, 0, 0, 1, 0, 1], np.uint8)), n_(n), p(a)); L.sim_msm_bucket(p(x2), p(np.ones(n, np.uint8)), n_(2), p(a)); L.sim_msm_bucket(p(x2), p(np.zeros(n, np.uint8)), n_(3), p(a))
 f = [np.zeros((n, 4), np.uint64) for _ in range(5)]
 fl = [np.zeros(n, np.uint8) for _ in range(3)]
 full = np.full((n, 16), 0xFFFFFFFFFFFFFFFF, np.uint64)      # every word string the conversion-free forms may be handed
@@ -503,6 +504,29 @@ print("BOUNDS_OK")
 """
     r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "BOUNDS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_msm_bucket_chain_matches_oracle(sim, oracle):
+    """The per-lane chain of the MSM's bucket sums (msm.hip k_msm_segments / k_msm_reduce): cached affine records, the
+    first point of a run converted instead of added to the identity, mixed additions, full additions of partial sums --
+    the same group element as the oracle's fold, for every sign pattern of a short run."""
+    rng = np.random.default_rng(29)
+    for n in (2, 3, 5, 8, 33):
+        for rep in range(6):
+            enc = oracle.encode_to_curve(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+            P, st = oracle.decompress(enc)
+            negs = rng.integers(0, 2, n).astype(np.uint8) if rep else np.zeros(n, np.uint8)
+            out = np.zeros((1, 16), np.uint64)
+            sim.sim_msm_bucket(_p(P), _p(negs), n_(n), _p(out))
+            signed = [oracle.neg_xyzt(P[i:i + 1]) if negs[i] else P[i:i + 1] for i in range(n)]
+            a = signed[0]
+            for i in range(1, n // 2):
+                a = oracle.add_xyzt(a, signed[i])
+            b = signed[n // 2]
+            for i in range(n // 2 + 1, n):
+                b = oracle.add_xyzt(b, signed[i])
+            want = oracle.add_xyzt(oracle.add_xyzt(a, b), oracle.add_xyzt(a, a))
+            assert bytes(oracle.compress(out)[0]) == bytes(oracle.compress(want)[0]), (n, rep)
 
 
 def test_doubling_variants_agree(sim, oracle):
