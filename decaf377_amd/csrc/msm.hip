@@ -46,7 +46,15 @@ namespace {
 constexpr int PT_WORDS = 4 * SLOT;      // one cached or extended point record: 192 B
 constexpr int CHUNK = 8;                // buckets per lane in k_msm_chunks (short chains: this phase is latency-bound)
 constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a serial chain per lane: short chains, more levels)
-constexpr int RED = 32;                 // partial sums per lane in the further reduction levels (k_msm_reduce)
+// Partial sums per lane in the further reduction levels (k_msm_reduce), level 2, 3, 4.  With random scalars a bucket of a
+// 2^22-point MSM leaves 16 partials: eight per lane keeps 2 x the buckets busy instead of one lane per bucket walking
+// 15 dependent additions (883 workgroups of 4 waves on 768 places: 335 us for 2.2 M additions, against ~120 us of
+// issue time); the wide last level is for runs that hold most of the points (many equal scalars).
+__device__ __constant__ const int RED_G[3] = {8, 8, 32};
+constexpr int RED_HOST[3] = {8, 8, 32};
+// A level runs only if some bucket still has more than this many partials; fewer are summed by the lane that finishes
+// the bucket (a level of its own for two or three leftovers -- the tail of the Poisson run lengths -- cost 27-56 us).
+constexpr uint32_t RED_SKIP = 4;
 // Points per lane in k_msm_segments (`seg`, a launch parameter): 8, 16 or 32 by batch size -- pick_seg() below.
 constexpr int MAX_SEG = 128;
 
@@ -193,7 +201,28 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digit
   __syncthreads();
   const size_t lo = (size_t)sl * per, hi = (lo + per < n) ? lo + per : n;
   const int16_t* dw = digits + (size_t)w * n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+  // eight digits per 16-byte load where the row allows it (one 2-byte load per lane and trip left the kernel waiting on
+  // memory latency: 1 TB/s); the unaligned head and the tail go one by one
+  const size_t a0 = ((reinterpret_cast<uintptr_t>(dw + lo) + 15) & ~(uintptr_t)15) - reinterpret_cast<uintptr_t>(dw + lo);
+  size_t head = lo + a0 / 2;
+  if (head > hi) head = hi;
+  const size_t nvec = (hi - head) / 8;
+  for (size_t i = lo + threadIdx.x; i < head; i += SORT_THREADS) {
+    const int d = dw[i];
+    if (d != 0) atomicAdd(&h[d < 0 ? -d : d], 1u);
+  }
+  const uint4* dv = reinterpret_cast<const uint4*>(dw + head);
+  for (size_t v = threadIdx.x; v < nvec; v += SORT_THREADS) {
+    const uint4 q = dv[v];
+    const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d0 = (int16_t)(ws[k] & 0xFFFFu), d1 = (int16_t)(ws[k] >> 16);
+      if (d0 != 0) atomicAdd(&h[d0 < 0 ? -d0 : d0], 1u);
+      if (d1 != 0) atomicAdd(&h[d1 < 0 ? -d1 : d1], 1u);
+    }
+  }
+  for (size_t i = head + nvec * 8 + threadIdx.x; i < hi; i += SORT_THREADS) {
     const int d = dw[i];
     if (d != 0) atomicAdd(&h[d < 0 ? -d : d], 1u);
   }
@@ -205,14 +234,18 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digit
 // Prefix sums of the sort, two small kernels over workgroups (window, 1024 buckets).
 // In: blockhist[w][s][b] = points of slice s in bucket b.  Out: blockhist[w][s][b] = points of the slices before s in
 // bucket b; offs[w][0..nb] = exclusive prefix of the bucket sizes (offs[w][nb] = total); segoff[l][w][0..nb],
-// l = 0..REDUCE_LEVELS-1 = the same for ceil(size / seg), ceil(that / RED), ...: the number of seg-point segments per
-// bucket, of RED-segment groups, ... (the levels of the bucket reduction).  k_msm_scan1 leaves prefixes local to its 1024 buckets
+// l = 0..REDUCE_LEVELS-1 = the same for ceil(size / seg), ceil(that / RED_G[0]), ...: the number of seg-point segments per
+// bucket, of groups of segments, ... (the levels of the bucket reduction).  k_msm_scan1 leaves prefixes local to its 1024 buckets
 // and the four totals of the workgroup in tot[w][chunk][]; k_msm_scan2 adds the totals of the chunks before.  (One
 // workgroup per window walking its buckets 1024 at a time took 0.12 ms at every size: 18 workgroups on 256 CUs.)
-constexpr int REDUCE_LEVELS = 3;
+constexpr int REDUCE_LEVELS = 4;
+// lvlmax[l] (zeroed by the host before the launch) receives the largest number of level-(l+1) partials any bucket has:
+// a reduction level whose input leaves no bucket with more than RED_SKIP partials returns at once.
 __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, uint32_t* tot, int nb,
-                                                    int S, int W, int nchunk, int seg) {
+                                                    int S, int W, int nchunk, int seg, uint32_t* lvlmax) {
   __shared__ uint32_t part[1 + REDUCE_LEVELS][1024];
+  __shared__ uint32_t bmax[REDUCE_LEVELS];
+  if (threadIdx.x < REDUCE_LEVELS) bmax[threadIdx.x] = 0;
   const int w = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk, t = threadIdx.x;
   const int len = nb + 1;
   const int j = chunk * 1024 + t;
@@ -227,9 +260,13 @@ __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_
   uint32_t own[1 + REDUCE_LEVELS];
   own[0] = c;
   own[1] = (own[0] + (uint32_t)seg - 1) / (uint32_t)seg;
-  for (int l = 2; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + RED - 1) / RED;
+  for (int l = 2; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + (uint32_t)RED_G[l - 2] - 1) / (uint32_t)RED_G[l - 2];
   for (int l = 0; l <= REDUCE_LEVELS; ++l) part[l][t] = own[l];
   __syncthreads();
+  for (int l = 1; l <= REDUCE_LEVELS; ++l)
+    if (own[l] > 1) atomicMax(&bmax[l - 1], own[l]);
+  __syncthreads();
+  if (t < REDUCE_LEVELS && bmax[t] > 1) atomicMax(&lvlmax[t], bmax[t]);
   for (int off = 1; off < 1024; off <<= 1) {
     uint32_t v[1 + REDUCE_LEVELS];
     for (int l = 0; l <= REDUCE_LEVELS; ++l) v[l] = (t >= off) ? part[l][t - off] : 0u;
@@ -462,12 +499,14 @@ k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, c
   }
 }
 
-// A further level of the same reduction: one lane per group of <= RED partial sums of one bucket (so_in: prefix of
+// A further level of the same reduction: one lane per group of <= `red` partial sums of one bucket (so_in: prefix of
 // the partials per bucket, so_out: of the groups).  With random scalars a bucket has a handful of partials and one
 // level finishes it; with many equal scalars (all coefficients 1, say) a run holds most of the n points, and every
-// level cuts its partials by RED instead of leaving them to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
+// level cuts its partials by `red` instead of leaving them to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, int W, int nb, size_t max_groups, uint32_t* out) {
+k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, int W, int nb, size_t max_groups, uint32_t* out,
+             int red, const uint32_t* in_max) {
+  if (*in_max <= RED_SKIP) return;                       // every bucket is down to a few partials: k_msm_buckets adds those itself
   const int len = nb + 1;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_groups; gi += (size_t)gridDim.x * BLOCK) {
     int w, b;
@@ -476,23 +515,37 @@ k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, 
     if (!msm_locate(gi, so_out, W, nb, &w, &b, &k, &base)) break;
     const size_t in_base = msm_window_base(so_in, w, nb);
     const uint32_t s0 = so_in[(size_t)w * len + b], s1 = so_in[(size_t)w * len + b + 1];
-    uint32_t lo = s0 + k * RED, hi = lo + RED;
+    uint32_t lo = s0 + k * (uint32_t)red, hi = lo + (uint32_t)red;
     if (hi > s1) hi = s1;
     ge acc = ge_identity();
     if (lo < hi) {                                       // a group of one is copied, not added to the identity
       acc = pt_load_ext(in + (in_base + lo) * PT_WORDS);
+      ge nx = acc;
+      if (lo + 1 < hi) nx = pt_load_ext(in + (in_base + lo + 1) * PT_WORDS);
 #pragma unroll 1
-      for (uint32_t j = lo + 1; j < hi; ++j) acc = ge_add(acc, pt_load_ext(in + (in_base + j) * PT_WORDS));
+      for (uint32_t j = lo + 1; j < hi; ++j) {           // the next partial is in flight while this one is added
+        const ge cur = nx;
+        if (j + 1 < hi) nx = pt_load_ext(in + (in_base + j + 1) * PT_WORDS);
+        acc = ge_add(acc, cur);
+      }
     }
     pt_store_ext(out + gi * PT_WORDS, acc);
   }
 }
 
-// one lane per bucket: sum of what the last level left of it (one partial with random scalars)
+// one lane per bucket: sum of what the last level that ran left of it (a few partials at most with random scalars).
+// Level l + 1 ran iff lvlmax[l - 1] > RED_SKIP; the levels that ran are a prefix.
+struct MsmLevels {
+  const uint32_t* buf[REDUCE_LEVELS];                     // partial sums after level 1 (segments), 2, ...
+};
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_buckets(const uint32_t* partial, const uint32_t* segoff, int W, int nb, uint32_t* buckets) {
+k_msm_buckets(MsmLevels lv, const uint32_t* segoff_all, const uint32_t* lvlmax, int W, int nb, uint32_t* buckets) {
   const int len = nb + 1;
   const size_t total = (size_t)W * nb;
+  int last = 0;
+  while (last + 1 < REDUCE_LEVELS && lvlmax[last] > RED_SKIP) ++last;
+  const uint32_t* partial = lv.buf[last];
+  const uint32_t* segoff = segoff_all + (size_t)last * W * len;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < total; gi += (size_t)gridDim.x * BLOCK) {
     const int w = (int)(gi / nb), b = (int)(gi % nb);
     const size_t base = msm_window_base(segoff, w, nb);
@@ -500,8 +553,14 @@ k_msm_buckets(const uint32_t* partial, const uint32_t* segoff, int W, int nb, ui
     ge acc = ge_identity();
     if (s0 < s1) {
       acc = pt_load_ext(partial + (base + s0) * PT_WORDS);
+      ge nx = acc;
+      if (s0 + 1 < s1) nx = pt_load_ext(partial + (base + s0 + 1) * PT_WORDS);
 #pragma unroll 1
-      for (uint32_t j = s0 + 1; j < s1; ++j) acc = ge_add(acc, pt_load_ext(partial + (base + j) * PT_WORDS));
+      for (uint32_t j = s0 + 1; j < s1; ++j) {
+        const ge cur = nx;
+        if (j + 1 < s1) nx = pt_load_ext(partial + (base + j + 1) * PT_WORDS);
+        acc = ge_add(acc, cur);
+      }
     }
     pt_store_ext(buckets + gi * PT_WORDS, acc);
   }
@@ -553,21 +612,106 @@ k_msm_fold(const uint32_t* in, int W, int m, int mout, uint32_t* out) {
   }
 }
 
-// ---- Horner tail, four lanes per group element -------------------------------------------------
-// The tail is one dependency chain (252 doublings + W additions) whatever the batch size.  A doubling
-// is two rounds of four independent field products (X^2, Y^2, 2Z^2, 2XY, then EF, GH, FG, EH), and so
-// is an addition after one preparatory product; so four lanes each take one product per round (the
-// same instruction stream on different operands: no divergence), exchange the four results with
-// DPP quad_perm moves, and every lane rebuilds the linear combinations.  Depth per doubling: 2 products instead
-// of 8.  Every lane holds the whole point; lane j & 3 decides which product it computes.
-// lane K of the caller's group of four, to all four: a DPP quad_perm move per limb (one VALU instruction, no LDS
-// crossbar round trip as with ds_bpermute)
-template <int K>
-__device__ __forceinline__ fe fe_from_quad(const fe& v) {
+// ---- weighted bucket sums ------------------------------------------------------------------------
+// S_w = sum_b b * B_b over the buckets of a window.  With U_j = the sum of the buckets whose index has bit j set,
+// S_w = sum_j 2^j U_j, and the U_j come out of one pairwise tree: a node over 2^j consecutive buckets carries its total T
+// and the bit-sums V_0 .. V_(j-1) of its own range; merging a left and a right node adds them position by position and
+// appends V_j = T(right).  Level j has 2^(c-1-j) merges of j + 1 independent additions each -- 2 additions per bucket
+// in all, like the running-sum trick, but c levels deep instead of a serial walk: the chunked running sums this
+// replaces (8 buckets per lane, then a 16-bit double-and-add for the chunk's offset, then five 4-to-1 folds) were ~55
+// dependent group operations, 245 us at every batch size.  k_msm_wsum_block takes 2^m buckets per workgroup through m
+// levels in LDS (points as structure-of-arrays, 36 words each); k_msm_wsum_window merges the block nodes of a window
+// (first level straight from global memory) and finishes with Horner over the c bit-sums, four lanes per point.
+constexpr int WS_M = 8;                          // at most 2^WS_M buckets per block workgroup
+constexpr int WS_THREADS = 1 << (WS_M - 2);      // one wave: a lane takes FOUR buckets through levels 0 and 1 in registers
+constexpr int LP_WORDS = 4 * NL;
+struct LdsPts {
+  uint32_t* base;
+  int cap;                                       // word k of point p lives at base[k * cap + p]
+  __device__ __forceinline__ ge load(int p) const {
+    ge g;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      g.x.l[i] = base[(0 * NL + i) * cap + p]; g.y.l[i] = base[(1 * NL + i) * cap + p];
+      g.z.l[i] = base[(2 * NL + i) * cap + p]; g.t.l[i] = base[(3 * NL + i) * cap + p];
+    }
+    return g;
+  }
+  __device__ __forceinline__ void store(int p, const ge& g) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      base[(0 * NL + i) * cap + p] = g.x.l[i]; base[(1 * NL + i) * cap + p] = g.y.l[i];
+      base[(2 * NL + i) * cap + p] = g.z.l[i]; base[(3 * NL + i) * cap + p] = g.t.l[i];
+    }
+  }
+};
+// one level of merges inside LDS: `cur` holds 2 * merges nodes of (j + 1) points, `nxt` receives merges nodes of (j + 2)
+__device__ __forceinline__ void wsum_level(const LdsPts& cur, LdsPts& nxt, int j, int merges, int t, int nthreads) {
+  const int per = j + 1;
+  for (int l = t; l < merges * per; l += nthreads) {
+    const int mu = l / per, tt = l - mu * per;
+    const ge a = cur.load((2 * mu) * per + tt), b = cur.load((2 * mu + 1) * per + tt);
+    nxt.store(mu * (per + 1) + tt, ge_add(a, b));
+    if (tt == 0) nxt.store(mu * (per + 1) + per, b);          // V_j of the merged node = the right node's total
+  }
+}
+// One wave per workgroup and four buckets per lane: 18 windows x 33 blocks = 594 waves at c = 14, fewer than the chip has
+// SIMDs, so every wave runs alone on its SIMD (with two buckets per lane there were 1170 waves on 1024 SIMDs and the
+// kernel took as long as the SIMDs that got two: 100-130 us against 47 us for the same depth at c = 7).
+constexpr int WSA_CAP0 = 3 << (WS_M - 2), WSA_CAP1 = 1 << (WS_M - 1);     // points after level 1 (192) and level 2 (128)
+__global__ void __launch_bounds__(WS_THREADS)
+k_msm_wsum_block(const uint32_t* buckets, int nb, int m, int nblk, uint32_t* nodes) {
+  __shared__ uint32_t lds[(WSA_CAP0 + WSA_CAP1) * LP_WORDS];
+  const int w = blockIdx.x / nblk, blk = blockIdx.x % nblk, t = threadIdx.x;
+  LdsPts A{lds, WSA_CAP0}, B{lds + WSA_CAP0 * LP_WORDS, WSA_CAP1};
+  const int M1 = 1 << (m - 2);                                 // nodes after level 1 (m >= 2)
+  if (t < M1) {                                                // buckets 4t .. 4t + 3: T = B0 + B1 + B2 + B3, V_0 = B1 + B3, V_1 = B2 + B3
+    const int b0 = (blk << m) + 4 * t;
+    const uint32_t* src = buckets + ((size_t)w * nb + b0) * PT_WORDS;
+    const ge p0 = b0 < nb ? pt_load_ext(src) : ge_identity();
+    const ge p1 = b0 + 1 < nb ? pt_load_ext(src + PT_WORDS) : ge_identity();
+    const ge p2 = b0 + 2 < nb ? pt_load_ext(src + 2 * PT_WORDS) : ge_identity();
+    const ge p3 = b0 + 3 < nb ? pt_load_ext(src + 3 * PT_WORDS) : ge_identity();
+    const ge r = ge_add(p2, p3);                               // total of the right pair
+    A.store(3 * t, ge_add(ge_add(p0, p1), r));
+    A.store(3 * t + 1, ge_add(p1, p3));
+    A.store(3 * t + 2, r);
+  }
+  __syncthreads();
+  LdsPts cur = A, nxt = B;
+#pragma unroll 1
+  for (int j = 2; j < m; ++j) {
+    wsum_level(cur, nxt, j, M1 >> (j - 1), t, WS_THREADS);
+    __syncthreads();
+    const LdsPts tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (t <= m) pt_store_ext(nodes + (((size_t)w * nblk + blk) * (WS_M + 1) + t) * PT_WORDS, cur.load(t));
+}
+
+// ---- group operations on four lanes ------------------------------------------------------------
+// The Horner chains (over the bit-sums of a window, over the windows) are dependency chains whatever the batch size:
+// 252 doublings in the tail.  A doubling is two rounds of four independent field products (X^2, Y^2, 2Z^2, 2XY, then
+// EF, GH, FG, EH) and so is an addition, so four lanes each take one product per round -- the same instruction stream
+// on different operands, no divergence.  The point lives DISTRIBUTED over the quad: lane r holds coordinate r (X, Y, Z,
+// T), which is exactly what lane r's second product produces, and a round's operands are fetched with DPP quad_perm
+// moves (one VALU instruction per limb, no LDS round trip).  (Round 2 kept the whole point in every lane and picked
+// operands with selects: ~660 instructions per doubling, 392 of them the two products; this form is ~540.)
+// The other operand of an addition comes from memory in CACHED form -- (Y-X, Y+X, 2dT, Z), made once per point, in
+// parallel, before the chain starts -- so lane r just loads the slot it multiplies by; subtracting a point swaps two
+// slots and two sums, which is how the chains absorb the sign of the sign-folded doubling (-[2]P, curve.hpp
+// ge_double_neg) instead of negating after every step.
+template <int P0, int P1, int P2, int P3>
+__device__ __forceinline__ fe fe_quad_perm(const fe& v) {       // lane r of every quad <- lane P_r
   fe r;
 #pragma unroll
   for (int i = 0; i < NL; ++i)
-    r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], K * 0x55, 0xF, 0xF, false);   // quad_perm:[K,K,K,K]
+    r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, false);
+  // Keep the moves as moves: hipcc's DPP combiner folds them into the additions and subtractions that consume them
+  // (v_add_u32_dpp / v_subrev_u32_dpp whose destination is also their second source), and some of those folded
+  // subtractions came back computed on the lane's OWN value instead of the permuted one (measured: limbs 0 and 1 of
+  // A - B in gq_double_neg, lanes 0, 2, 3, once the doubling sat in a loop; tests/cpp/gq_selftest.hip).
+#pragma unroll
+  for (int i = 0; i < NL; ++i) asm("" : "+v"(r.l[i]));
   return r;
 }
 __device__ __forceinline__ fe fe_pick(int role, const fe& a, const fe& b, const fe& c, const fe& d) {
@@ -579,28 +723,101 @@ __device__ __forceinline__ fe fe_pick(int role, const fe& a, const fe& b, const 
   }
   return r;
 }
-// -[2]P (same formulas as ge_double_neg)
-__device__ __forceinline__ ge ge_double_neg_coop(const ge& p, int role, int base) {
-  const fe y2 = fe_dbl(p.y), z2 = fe_dbl(p.z);
-  const fe m1 = fe_mul(fe_pick(role, p.x, p.y, p.z, p.x), fe_pick(role, p.x, p.y, z2, y2));
-  const fe a = fe_from_quad<0>(m1), b = fe_from_quad<1>(m1), c = fe_from_quad<2>(m1), e = fe_from_quad<3>(m1);
-  const fe h = fe_add(a, b), g = fe_sub(a, b), f = fe_add(g, c);
-  const fe m2 = fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));
+// -[2]P (same formulas and operand forms as ge_double_neg, whose bounds the host build checks)
+__device__ __forceinline__ fe gq_double_neg(const fe& v, int role) {
+  const fe opa = fe_quad_perm<0, 1, 2, 0>(v);                   // X, Y, Z, X
+  fe opb = fe_quad_perm<0, 1, 2, 1>(v);                         // X, Y, 2Z, 2Y
+  const uint32_t sh = (uint32_t)role >> 1;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) opb.l[i] <<= sh;
+  const fe m1 = fe_mul(opa, opb);                               // A = X^2, B = Y^2, C = 2Z^2, E = 2XY
+  const fe a = fe_quad_perm<0, 0, 0, 0>(m1), b = fe_quad_perm<1, 1, 1, 1>(m1);
+  const fe h = fe_add(a, b), g = fe_sub(a, b);                  // H' = A + B (lazy), G' = A - B (carried)
+  const fe f = fe_add(g, fe_quad_perm<2, 2, 2, 2>(m1));         // F' = G' + C (lazy)
+  const fe e = fe_quad_perm<3, 3, 3, 3>(m1);
+  return fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));   // E F', G' H', F' G', E H'
+}
+// A point of a chain's other operands in cached form, four 9-word slots in LDS: slot 0 Y-X, 1 Y+X (both carried), 2 2dT, 3 Z
+constexpr int GQ_WORDS = 4 * NL;
+__device__ __forceinline__ void gq_store_cached(uint32_t* rec, const ge& p) {
+  const fe ymx = fe_sub(p.y, p.x), ypx = fe_carry(fe_add(p.y, p.x)), kt = fe_mul(fe_const(FE_K), p.t);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { rec[i] = ymx.l[i]; rec[NL + i] = ypx.l[i]; rec[2 * NL + i] = kt.l[i]; rec[3 * NL + i] = p.z.l[i]; }
+}
+// P + Q, or P - Q with neg_q (wave-uniform): src/min_curve/element.rs:291-322 with Q cached, as ge_add_cached
+__device__ __forceinline__ fe gq_add(const fe& v, const uint32_t* qrec, int role, bool neg_q) {
+  // lane 0: (Yp - Xp)(Yq - Xq), lane 1: (Yp + Xp)(Yq + Xq), lane 2: Tp * 2dTq, lane 3: 2Zp * Zq
+  const fe x = fe_quad_perm<0, 0, 3, 2>(v);                     // X, X, T, Z
+  const fe y = fe_quad_perm<1, 1, 1, 1>(v);
+  const fe opa = fe_pick(role, fe_sub(y, x), fe_add(y, x), x, fe_add(x, x));
+  const int slot = (role < 2 && neg_q) ? (role ^ 1) : role;     // -Q: Y-X and Y+X change places
+  fe opb;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) opb.l[i] = qrec[slot * NL + i];
+  const fe m1 = fe_mul(opa, opb);                               // a, b, c, d
+  const fe a = fe_quad_perm<0, 0, 0, 0>(m1), b = fe_quad_perm<1, 1, 1, 1>(m1);
+  const fe c = fe_quad_perm<2, 2, 2, 2>(m1), d = fe_quad_perm<3, 3, 3, 3>(m1);
+  const fe e = fe_sub(b, a), h = fe_add(b, a);
+  const fe dmc = fe_sub(d, c), dpc = fe_carry(fe_add(d, c));
+  const fe f = fe_select(neg_q, dpc, dmc), g = fe_select(neg_q, dmc, dpc);      // the sign of 2dT: F and G change places
+  return fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));   // E F, G H, F G, E H
+}
+// a whole point (every lane the same copy) -> its distributed form, and back
+__device__ __forceinline__ fe gq_from_ge(const ge& p, int role) { return fe_pick(role, p.x, p.y, p.z, p.t); }
+__device__ __forceinline__ ge gq_to_ge(const fe& v) {
   ge r;
-  r.x = fe_from_quad<0>(m2); r.y = fe_from_quad<1>(m2); r.z = fe_from_quad<2>(m2); r.t = fe_from_quad<3>(m2);
+  r.x = fe_quad_perm<0, 0, 0, 0>(v); r.y = fe_quad_perm<1, 1, 1, 1>(v); r.z = fe_quad_perm<2, 2, 2, 2>(v); r.t = fe_quad_perm<3, 3, 3, 3>(v);
   return r;
 }
-// P + Q (src/min_curve/element.rs:291-322), Q's coordinates products as loaded from a pt_store_ext record
-__device__ __forceinline__ ge ge_add_coop(const ge& p, const ge& q, int role, int base) {
-  const fe kt = fe_mul(fe_const(FE_K), q.t);                   // every lane: one product
-  const fe m1 = fe_mul(fe_pick(role, fe_sub(p.y, p.x), fe_add(p.y, p.x), p.t, fe_dbl(p.z)),
-                       fe_pick(role, fe_sub(q.y, q.x), fe_carry(fe_add(q.y, q.x)), kt, q.z));
-  const fe a = fe_from_quad<0>(m1), b = fe_from_quad<1>(m1), c = fe_from_quad<2>(m1), d = fe_from_quad<3>(m1);
-  const fe e = fe_sub(b, a), f = fe_sub(d, c), g = fe_carry(fe_add(d, c)), h = fe_add(b, a);
-  const fe m2 = fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));
-  ge r;
-  r.x = fe_from_quad<0>(m2); r.y = fe_from_quad<1>(m2); r.z = fe_from_quad<2>(m2); r.t = fe_from_quad<3>(m2);
-  return r;
+
+// The block nodes of one window -> S_w.  Levels m .. c-1 (none when one block covers the window), then Horner over the
+// bit-sums with the cooperative doubling / addition of the tail below.
+constexpr int WSB_THREADS = 512;
+constexpr int WSB_CAP0 = 32 * (WS_M + 2), WSB_CAP1 = 16 * (WS_M + 3);   // points after the first / second level at c = 14 (320, 176)
+__global__ void __launch_bounds__(WSB_THREADS)
+k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, uint32_t* sums) {
+  __shared__ uint32_t lds[(WSB_CAP0 + WSB_CAP1) * LP_WORDS];
+  const int w = blockIdx.x, t = threadIdx.x;
+  LdsPts X{lds, WSB_CAP0}, Y{lds + WSB_CAP0 * LP_WORDS, WSB_CAP1};
+  const uint32_t* wn = nodes + (size_t)w * nblk * (WS_M + 1) * PT_WORDS;
+  LdsPts cur = X, nxt = Y;
+  if (c == m) {                                                // the block node is the window's node
+    if (t <= m) X.store(t, pt_load_ext(wn + (size_t)t * PT_WORDS));
+  } else {
+    const int per = m + 1, merges = 1 << (c - m - 1);         // level m, operands in global memory; nodes beyond nblk are empty
+    for (int l = t; l < merges * per; l += WSB_THREADS) {
+      const int mu = l / per, tt = l - mu * per;
+      const ge a = 2 * mu < nblk ? pt_load_ext(wn + ((size_t)(2 * mu) * (WS_M + 1) + tt) * PT_WORDS) : ge_identity();
+      const ge b = 2 * mu + 1 < nblk ? pt_load_ext(wn + ((size_t)(2 * mu + 1) * (WS_M + 1) + tt) * PT_WORDS) : ge_identity();
+      X.store(mu * (per + 1) + tt, ge_add(a, b));
+      if (tt == 0) X.store(mu * (per + 1) + per, b);
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int j = m + 1; j < c; ++j) {
+    wsum_level(cur, nxt, j, 1 << (c - j - 1), t, WSB_THREADS);
+    __syncthreads();
+    const LdsPts tmp = cur; cur = nxt; nxt = tmp;
+  }
+  // Horner over the bit-sums: S = V_(c-1); S = 2 S + V_j.  Their cached forms first, one lane each, into the buffer
+  // that is free now; then one wave runs the chain, every group of four lanes the same work.
+  uint32_t* crec = nxt.base;                                   // c records of GQ_WORDS words (c * 36 <= the smaller buffer)
+  if (t < c) gq_store_cached(crec + t * GQ_WORDS, cur.load(1 + t));       // point 1 + j of the node is V_j
+  __syncthreads();
+  if (t >= 64) return;
+  const int role = t & 3;
+  fe v = gq_from_ge(cur.load(c), role);                        // the top bit-sum
+  bool negated = false;                                        // v holds -S after an odd number of sign-folded doublings
+#pragma unroll 1
+  for (int j = c - 2; j >= 0; --j) {
+    v = gq_double_neg(v, role);
+    negated = !negated;
+    v = gq_add(v, crec + j * GQ_WORDS, role, negated);         // -2S - V_j, or 2S + V_j
+  }
+  ge r = gq_to_ge(v);
+  if (negated) r = ge_neg(r);
+  if (t == 0) pt_store_ext(sums + (size_t)w * PT_WORDS, r);
 }
 
 // Horner over the window sums S_w (lanes 0-3 of one wave), result as Element record and as encoding
@@ -614,15 +831,22 @@ k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, 
   } pt;
   pt.col = lds_pow_ + threadIdx.x;
   if (blockIdx.x != 0) return;
-  const int role = threadIdx.x & 3, base = threadIdx.x & ~3;     // every group of four lanes computes the same thing
-  ge r = pt_load_ext(sums + (size_t)(W - 1) * PT_WORDS);
+  // cached forms of the window sums, one lane each (W <= 63), then the chain on every group of four lanes alike
+  __shared__ uint32_t crec[63 * GQ_WORDS];
+  if ((int)threadIdx.x < W - 1) gq_store_cached(crec + threadIdx.x * GQ_WORDS, pt_load_ext(sums + (size_t)threadIdx.x * PT_WORDS));
+  __syncthreads();
+  const int role = threadIdx.x & 3;
+  fe v = gq_from_ge(pt_load_ext(sums + (size_t)(W - 1) * PT_WORDS), role);
+  bool negated = false;                                          // v holds minus the running sum
 #pragma unroll 1
   for (int w = W - 2; w >= 0; --w) {
 #pragma unroll 1
-    for (int j = 0; j < c; ++j) r = ge_double_neg_coop(r, role, base);
-    if (c & 1) r = ge_neg(r);                                    // an odd number of sign-flipping doublings
-    r = ge_add_coop(r, pt_load_ext(sums + (size_t)w * PT_WORDS), role, base);
+    for (int j = 0; j < c; ++j) v = gq_double_neg(v, role);
+    if (c & 1) negated = !negated;                               // an odd number of sign-folded doublings
+    v = gq_add(v, crec + w * GQ_WORDS, role, negated);
   }
+  ge r = gq_to_ge(v);
+  if (negated) r = ge_neg(r);
   // r = sum (k_i / 2) P_i: the result is its double, whose encoding needs no square root (curve.hpp, "compression
   // without a square root") -- one element, so the inversion is not shared, but a divsteps inversion (~26 000
   // instructions) is still well under the ~67 000 of a square root on this one dependent chain
@@ -709,7 +933,9 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   // slices per window of the counting sort: enough workgroups to cover the chip, never less than 8192 points each
-  int S = (int)((size_t)2 * d.cus / (size_t)W) + 1;
+  // (W * S <= the 2 workgroups of 1024 threads a CU holds: with one more slice per window, 18 x 29 = 522 workgroups on 512
+  // places, the count and level-1 placement kernels ran a second generation for ten workgroups)
+  int S = (int)((size_t)2 * d.cus / (size_t)W);
   if (const char* e = getenv("D377_MSM_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 4096) S = v; }   // developer override (sweeps)
   if ((size_t)S > (n + 8191) / 8192) S = (int)((n + 8191) / 8192);
   if (S < 1) S = 1;
@@ -730,17 +956,29 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_idx = carve((size_t)W * n * 4);
   const size_t o_sub = carve((size_t)W * n);                            // level-1 placement: bucket index within the super-bucket
   const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
-  // further levels of the bucket reduction: groups of RED partials, then groups of those (never more than this many)
-  const int levels = n <= ((size_t)1 << 11) ? 1 : n <= ((size_t)1 << 16) ? 2 : REDUCE_LEVELS;
-  const size_t max_g2 = max_segs / RED + (size_t)W * nb, max_g3 = max_g2 / RED + (size_t)W * nb;
-  const size_t o_r2 = carve(levels >= 2 ? max_g2 * PT_WORDS * 4 : 0);
-  const size_t o_r3 = carve(levels >= 3 ? max_g3 * PT_WORDS * 4 : 0);
+  // further levels of the bucket reduction: groups of partials, then groups of those (never more than this many); every
+  // level is launched and decides on the device whether it has anything to do (k_msm_scan1, lvlmax)
+  size_t max_g[REDUCE_LEVELS];
+  size_t o_r[REDUCE_LEVELS];
+  max_g[0] = max_segs; o_r[0] = o_par;
+  for (int l = 1; l < REDUCE_LEVELS; ++l) {
+    max_g[l] = max_g[l - 1] / (size_t)RED_HOST[l - 1] + (size_t)W * nb;
+    o_r[l] = carve(max_g[l] * PT_WORDS * 4);
+  }
+  const size_t o_lvl = carve(256);
   const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
   // ping-pong buffers of the 32-to-1 folds, sized from the fold sequence itself: the first fold writes
   // ceil(nchunks / FOLD) records per window into f0, the second ceil(that / FOLD) into f1, and so on
   const size_t m1 = (size_t)(nchunks + FOLD - 1) / FOLD, m2 = (m1 + FOLD - 1) / FOLD;
   const size_t o_f0 = carve((size_t)W * m1 * PT_WORDS * 4);
   const size_t o_f1 = carve((size_t)W * m2 * PT_WORDS * 4);
+  // weighted bucket sums by the pairwise tree (c <= 14: every width pick_window chooses); wider windows -- developer
+  // override only -- keep the chunked running sums
+  const bool tree = c <= 14 && getenv("D377_MSM_CHUNKED") == nullptr;
+  const int ws_m = c < WS_M ? c : WS_M;                      // >= 2: window widths start at 2
+  const int ws_nblk = (nb + (1 << ws_m) - 1) >> ws_m;
+  const size_t o_nodes = carve(tree ? (size_t)W * ws_nblk * (WS_M + 1) * PT_WORDS * 4 : 0);
+  const size_t o_sums = carve((size_t)W * PT_WORDS * 4);
   int rc;
   if (off > d.msm.cap) {
     if (ScratchGuard::capturing(s))
@@ -794,39 +1032,45 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   }
   hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
   uint32_t* tot = (uint32_t*)(m + o_tot);
-  hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, segoff, tot, nb, S, W, scan_chunks, seg);
+  uint32_t* lvlmax = (uint32_t*)(m + o_lvl);
+  HIP_TRY(hipMemsetAsync(lvlmax, 0, REDUCE_LEVELS * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, segoff, tot, nb, S, W, scan_chunks, seg, lvlmax);
   hipLaunchKernelGGL(k_msm_scan2, dim3(W * scan_chunks), dim3(1024), 0, s, offs, segoff, tot, nb, W, scan_chunks);
   hipLaunchKernelGGL(k_msm_place1, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
   hipLaunchKernelGGL(k_msm_place2, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
   hipLaunchKernelGGL(k_msm_segments, dim3(grid_of(d, max_segs)), dim3(BLOCK), 0, s, pts, idx, offs, segoff, n, W, nb,
                      max_segs, seg, partial);
-  const uint32_t* last = partial;                      // what k_msm_buckets finishes, with its prefix array
-  const uint32_t* last_so = segoff;
   const size_t so_stride = (size_t)W * (nb + 1);
-  if (levels >= 2) {
-    uint32_t* r2 = (uint32_t*)(m + o_r2);
-    hipLaunchKernelGGL(k_msm_reduce, dim3(grid_of(d, max_g2)), dim3(BLOCK), 0, s, last, last_so, segoff + so_stride, W, nb, max_g2, r2);
-    last = r2; last_so = segoff + so_stride;
+  MsmLevels lv;
+  lv.buf[0] = partial;
+  for (int l = 1; l < REDUCE_LEVELS; ++l) {
+    uint32_t* r = (uint32_t*)(m + o_r[l]);
+    hipLaunchKernelGGL(k_msm_reduce, dim3(grid_of(d, max_g[l])), dim3(BLOCK), 0, s, lv.buf[l - 1], segoff + (size_t)(l - 1) * so_stride,
+                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, RED_HOST[l - 1], lvlmax + (l - 1));
+    lv.buf[l] = r;
   }
-  if (levels >= 3) {
-    uint32_t* r3 = (uint32_t*)(m + o_r3);
-    hipLaunchKernelGGL(k_msm_reduce, dim3(grid_of(d, max_g3)), dim3(BLOCK), 0, s, last, last_so, segoff + 2 * so_stride, W, nb, max_g3, r3);
-    last = r3; last_so = segoff + 2 * so_stride;
-  }
-  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, last, last_so, W, nb, bkt);
-  hipLaunchKernelGGL(k_msm_chunks, dim3(grid_of(d, (size_t)W * nchunks)), dim3(BLOCK), 0, s, bkt, W, nb, nchunks, ch);
-  // fold chunk results down to one point per window
-  const uint32_t* cur_in = ch;
-  int mcur = nchunks;
-  uint32_t* bufs[2] = {f0, f1};
-  int which = 0;
-  const size_t fold_cap[2] = {m1, m2};
-  while (mcur > 1) {
-    const int mout = (mcur + FOLD - 1) / FOLD;
-    if ((size_t)mout > fold_cap[which]) return fail(D377_ERR_ARG, "%s", "msm: fold buffer too small (internal)");
-    uint32_t* o = bufs[which];
-    hipLaunchKernelGGL(k_msm_fold, dim3(grid_of(d, (size_t)W * mout)), dim3(BLOCK), 0, s, cur_in, W, mcur, mout, o);
-    cur_in = o; mcur = mout; which ^= 1;
+  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, lv, segoff, lvlmax, W, nb, bkt);
+  const uint32_t* cur_in;
+  if (tree) {
+    uint32_t *nodes = (uint32_t*)(m + o_nodes), *sums = (uint32_t*)(m + o_sums);
+    hipLaunchKernelGGL(k_msm_wsum_block, dim3(W * ws_nblk), dim3(WS_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
+    hipLaunchKernelGGL(k_msm_wsum_window, dim3(W), dim3(WSB_THREADS), 0, s, nodes, c, ws_m, ws_nblk, sums);
+    cur_in = sums;
+  } else {
+    hipLaunchKernelGGL(k_msm_chunks, dim3(grid_of(d, (size_t)W * nchunks)), dim3(BLOCK), 0, s, bkt, W, nb, nchunks, ch);
+    // fold chunk results down to one point per window
+    cur_in = ch;
+    int mcur = nchunks;
+    uint32_t* bufs[2] = {f0, f1};
+    int which = 0;
+    const size_t fold_cap[2] = {m1, m2};
+    while (mcur > 1) {
+      const int mout = (mcur + FOLD - 1) / FOLD;
+      if ((size_t)mout > fold_cap[which]) return fail(D377_ERR_ARG, "%s", "msm: fold buffer too small (internal)");
+      uint32_t* o = bufs[which];
+      hipLaunchKernelGGL(k_msm_fold, dim3(grid_of(d, (size_t)W * mout)), dim3(BLOCK), 0, s, cur_in, W, mcur, mout, o);
+      cur_in = o; mcur = mout; which ^= 1;
+    }
   }
   hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, T, cur_in, W, c, enc_out, xyzt_out);
   HIP_TRY(hipGetLastError());

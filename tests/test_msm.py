@@ -33,6 +33,22 @@ def ctx():
 
 
 @pytest.mark.gpu
+def test_four_lane_group_operations_selftest():
+    """tests/cpp/gq_selftest.hip: the cooperative (four lanes per point) doubling and addition of the MSM's Horner
+    chains against the single-lane formulas, one at a time and inside loops, compiled and run on the GPU box."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "gq_selftest")
+    src = os.path.join(root, "tests", "cpp", "gq_selftest.hip")
+    deps = [src] + [os.path.join(root, "decaf377_amd", "csrc", f) for f in os.listdir(os.path.join(root, "decaf377_amd", "csrc"))]
+    if not os.path.exists(exe) or any(os.path.getmtime(d_) > os.path.getmtime(exe) for d_ in deps):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "--offload-arch=gfx950", "-std=c++17", src, "-o", exe],
+                              timeout=900)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "GQ_SELFTEST_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [0, 1, 2, 7, 64, 257, 1000, 5000])
 def test_msm_matches_oracle(ctx, oracle, n):
     rng = np.random.default_rng(701 + n)
