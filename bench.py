@@ -19,7 +19,9 @@ Besides the contract keys the line carries
                  ceiling (one wave-instruction per 4 cycles per SIMD; tools/valu_mix.hip, profiles/r02_valu_mix*.txt);
   cpu_baseline   the C restatement of the reference algorithm (oracle/, kind "port") timed on the
                  host cores of this box on the same workload (rank 0, N = 1 only);
-  extra          encodes/s of the other batch operations (round trip, Elligator, fixed base, sqrt).
+  extra          encodes/s of the other batch operations (round trip, Elligator, fixed base, sqrt, decompress, compress,
+                 hash_to_curve, MSM), each with its own roofline_valu (BASELINE.json configs[1], [2], [4] are the round
+                 trip, fixed base and Elligator entries).
 """
 import argparse
 import json
@@ -42,11 +44,23 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
 # each: inv30.hpp, 20 rounds x 90 signed 64-bit MACs on 30-bit limbs, + 2 M).  The 2^20 extras are counted at the
 # 8 elements per lane they have.
 KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (109.25, 3.0),
-              "sqrt_ratio_zeta": (75.25, 241.0)}
+              "sqrt_ratio_zeta": (75.25, 241.0), "encode_to_curve": (102.5, 243.0), "hash_to_curve": (285.5, 777.0),
+              "decompress": (93.0, 291.0), "compress": (92.0, 289.0)}
+# divsteps inversions per element (one per lane per 8 elements and per batched-inversion pass of the kernel)
+KERNEL_INVERSIONS = {"scalar_mul_var": 2 / 8.0, "scalar_mul_base": 1 / 8.0, "sqrt_ratio_zeta": 1 / 8.0, "encode_to_curve": 2 / 8.0,
+                     "hash_to_curve": 2 / 8.0}
 MACS_PER_MUL, MACS_PER_SQR = 153, 117
 DIVSTEP_MACS_PER_INVERSION = 20 * 90                       # v_mad_i64_i32: update_fg_30 (36) + update_de_30 (54) per round
-KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR for k, (m, s) in KERNEL_OPS.items()}
-KERNEL_MACS["scalar_mul_var"] += 2 * DIVSTEP_MACS_PER_INVERSION / 8.0                         # 373784
+KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR + KERNEL_INVERSIONS.get(k, 0.0) * DIVSTEP_MACS_PER_INVERSION
+               for k, (m, s) in KERNEL_OPS.items()}                                           # scalar_mul_var: 373784
+MSM_MACS_PER_ADDITION = 7 * MACS_PER_MUL                   # one mixed addition per point and window: 7 field products
+
+
+def valu_view(macs_per_element, n, kernel_ms):
+    """roofline_valu of one extra: executed MACs / s against the v_mad_u64_u32 issue ceiling."""
+    rate = macs_per_element * n / (kernel_ms * 1e-3)
+    return {"bound": "valu_int32_mac", "macs_per_element": macs_per_element, "achieved": rate / 1e12, "peak": VALU_MAC_PEAK / 1e12,
+            "unit": "TMAC/s", "frac": rate / VALU_MAC_PEAK}
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 # v_mad_u64_u32 issues one wave-instruction per 4 cycles per SIMD (16 lanes / cycle): 256 CUs x 4 SIMDs x 16
 # lanes x 2.4 GHz.  Measured on this chip: 3.74-3.80e13/s = 95-97 % of it, because the sustained clock under this
@@ -370,11 +384,16 @@ def main():
                 ker_all = float(tt.item())
             extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3),
                            "per_sec_all_gpus": ne * world / (ker_all * 1e-3),
-                           "algo_GBps": ALGO_BYTES[name] * ne / (ker * 1e-3) / 1e9}
+                           "algo_GBps": ALGO_BYTES[name] * ne / (ker * 1e-3) / 1e9,
+                           "roofline_valu": valu_view(KERNEL_MACS[name], ne, ker)}
         # vartime_multiscalar_mul (Pippenger MSM), 2^20 Elements -> one Encoding
         pm, _ = ctx.decompress(enc1)
         ker, _ = time_op(torch, lambda: ctx.msm(pm, scalars[:ne]), 3, 1)
+        msm_w = 18 if ne >= (1 << 18) else None             # 14-bit windows from 2^18 points up (msm.hip pick_window)
         extra["msm_2^20"] = {"n": ne, "ms": ker, "per_sec": ne / (ker * 1e-3)}
+        if msm_w:
+            extra["msm_2^20"]["roofline_valu"] = valu_view(msm_w * MSM_MACS_PER_ADDITION, ne, ker)
+            extra["msm_2^20"]["roofline_valu"]["note"] = "one 7-product mixed addition per point and window (18 windows); whole call"
         aff = torch.empty((ne, 8), dtype=torch.int64, device=dev)
         ker, _ = time_op(torch, lambda: ctx.to_affine(pm, outs=[aff]), 3, 1)
         extra["to_affine"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}
@@ -393,7 +412,8 @@ def main():
             ("hash_to_curve", lambda: ctx.hash_to_curve(r0[:ne], scalars[:ne], outs=[o1])),
         ]:
             ker, _ = time_op(torch, fn, 3, 1)
-            extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}
+            extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3),
+                           "roofline_valu": valu_view(KERNEL_MACS[name], ne, ker)}
         extra["encodes_per_sec"] = extra["roundtrip"]["per_sec_all_gpus"]          # whole job, all GPUs
         extra["elligator_encodes_per_sec"] = extra["encode_to_curve"]["per_sec_all_gpus"]
         line["extra"] = extra

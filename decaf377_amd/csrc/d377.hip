@@ -372,13 +372,21 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTab
       dcb_put_den(io, 1, j, ge_elligator_den(fe_from_words_mod_order(w)));
     },
     [&](size_t i, int j, const uint32_t (*invw)[8], bool have) {
+      // both maps as far as their Jacobi-quartic points (s, t) first, the isogeny to the Edwards curve afterwards: across the
+      // second square root the first point is then two field elements instead of four (the kernel sat at the 256-VGPR limit
+      // with 12 registers spilled; 4 now.  Setting (s, t) aside in the lane's round records as well changed nothing: the
+      // peak is inside the square root of the final compression.)
       uint32_t w[8];
       load32(r1, i, w);
       fe inv = fe_from_words(invw[0]);            // meaningless words when !have (never read then)
-      const ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv, have);
+      fe s1, t1, s2, t2;
+      ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s1, &t1, &inv, have);
       load32(r2, i, w);
       inv = fe_from_words(invw[1]);
-      const ge b = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv, have);
+      ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s2, &t2, &inv, have);
+      const ge a = ge_from_jacobi_st(s1, t1), b = ge_from_jacobi_st(s2, t2);
+      D377_INVARIANT(T, a, true);
+      D377_INVARIANT(T, b, true);
       ge_compress(T, pt, ge_add(a, b), w);
       store32(out32, i, w);
     });
@@ -503,12 +511,19 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_map_to_element(SqrtTa
       uint32_t w[8];
       load32(r1, i, w);
       fe inv = fe_from_words(invw[0]);            // meaningless words when !have (never read then)
-      ge a = ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv, have);
-      if (r2) {
+      fe s1, t1;
+      ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s1, &t1, &inv, have);
+      ge a;
+      if (r2) {                                   // (s, t) of the first map across the second square root, as in k_hash_to_curve
         load32(r2, i, w);
         inv = fe_from_words(invw[1]);
-        a = ge_add(a, ge_elligator_map(T, pt, fe_from_words_mod_order(w), &inv, have));
+        fe s2, t2;
+        ge_elligator_st(T, pt, fe_from_words_mod_order(w), &s2, &t2, &inv, have);
+          a = ge_add(ge_from_jacobi_st(s1, t1), ge_from_jacobi_st(s2, t2));
+      } else {
+        a = ge_from_jacobi_st(s1, t1);
       }
+      D377_INVARIANT(T, a, true);
       store_ge_mont256(out, i, a);
     });
   D377_DCB_END();

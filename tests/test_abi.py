@@ -95,3 +95,17 @@ def test_c99_client_runs(libpath):
     import subprocess
     r = subprocess.run([_build_c99(libpath), "--run"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "C_ABI_RUN_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_pmc_record_matches_sources():
+    """profiles/pmc_traffic.json (what bench.py replays as roofline.traffic and valu_insts_per_mac) was collected on
+    exactly the kernels in the tree: the record carries a hash of decaf377_amd/csrc/* and this test recomputes it, so a
+    kernel change without a fresh `tools/collect_pmc.sh` run fails here instead of leaving stale counters in the line."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("pmc_summarize", os.path.join(ROOT, "tools", "pmc_summarize.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert rec.get("_sources", {}).get("csrc_sha256") == m.csrc_sha256(), \
+        "profiles/pmc_traffic.json predates the current kernels: run tools/collect_pmc.sh on the GPU box and copy it over"

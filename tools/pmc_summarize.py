@@ -6,10 +6,25 @@ usage: tools/pmc_summarize.py <dir> [label [elements]]   -> <dir>/pmc_summary.cs
 record carries valu_insts_per_element = SQ_INSTS_VALU (wave-instructions) / (elements / 64)."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha256():
+    """Identity of the kernels the counters were collected on: sha256 over the names and contents of decaf377_amd/csrc/*.
+    tests/test_abi.py::test_pmc_record_matches_sources recomputes it, so a profile that predates a kernel change fails."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "decaf377_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def short(name):
@@ -71,8 +86,11 @@ def main():
             rec["elements"] = elements
             rec["valu_insts_per_element"] = c["SQ_INSTS_VALU"] / (elements / 64.0)
         out[kern] = rec
+    out["_sources"] = {"csrc_sha256": csrc_sha256(), "note": "sha256 over decaf377_amd/csrc/*.{hip,hpp,inc} of the build that was profiled"}
     json.dump(out, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
     for k, v in out.items():
+        if k.startswith("_"):
+            continue
         print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a not in ("correction", "source")})
 
 
