@@ -20,6 +20,7 @@
 #include "../../include/decaf377_amd.h"
 #include "curve.hpp"
 #include "device_util.hpp"
+#include "quad_ops.hpp"
 #include "host_state.hpp"
 
 using namespace d377;
@@ -446,6 +447,100 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
   D377_DCB_END();
 }
 
+// ---- small batches: one group element per QUAD of lanes -----------------------------------------------------------------
+// Below ~2^14 elements the chip is not full with one lane per element and a call takes as long as ONE element's
+// dependency chain: 1.06 ms for a variable-base multiplication, whatever the batch (profiles/r03_size_sweep.txt).  Most
+// of that chain is group operations, and those split four ways (quad_ops.hpp: a doubling or an addition is two rounds of
+// four independent products): a quad of lanes takes one element, each lane one product per round.  The square root of
+// the decompression and the final inversion stay one dependent chain of squarings and are simply done by all four
+// lanes alike.  The window table (cached 0 .. 8 P, the slots each lane multiplies by) lives in LDS, one per quad.
+// Four times the lanes and ~2.4 x fewer instructions per lane: used while n <= the quads the chip holds at one wave
+// per SIMD (launch(): small_max), where the other lanes would have idled anyway.
+constexpr int SMALL_THREADS = 64;                              // one wave per workgroup, 16 elements
+constexpr int SMALL_QUADS = SMALL_THREADS / 4;
+struct OneDcbIO {                                              // the square-root-free compressor's records for a single element
+  uint32_t st[4][8], parked_[8], out[8];
+  __device__ __forceinline__ void put(int s, int, const uint32_t* w) { for (int k = 0; k < 8; ++k) st[s][k] = w[k]; }
+  __device__ __forceinline__ void get(int s, int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = st[s][k]; }
+  __device__ __forceinline__ void park(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) parked_[k] = w[k]; }
+  __device__ __forceinline__ void parked(int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = parked_[k]; }
+  __device__ __forceinline__ void emit(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) out[k] = w[k]; }
+};
+// ELEMENT: the reference's own signature (Element * Fr -> Element, src/min_curve/ops.rs:89-95): records in and out, no
+// square root at either end, so the whole chain splits four ways (0.88 -> ~0.36 ms per call).
+template <bool ELEMENT>
+__global__ void __launch_bounds__(SMALL_THREADS)
+k_scalar_mul_var_small(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, uint8_t* out32, uint8_t* status) {
+  __shared__ uint32_t lds_pow_[POW_TAB * NL * SMALL_THREADS];
+  __shared__ uint32_t tab[SMALL_QUADS * VB_ENTRIES * GQ_WORDS];
+  struct Pow64 {                                               // the square root's odd powers, one LDS column per lane
+    uint32_t* col;
+    __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * SMALL_THREADS] = v.l[k]; }
+    __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * SMALL_THREADS]; return r; }
+  } pt;
+  pt.col = lds_pow_ + threadIdx.x;
+  const int role = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  uint32_t* qtab = tab + quad * VB_ENTRIES * GQ_WORDS;
+  for (size_t base = (size_t)blockIdx.x * SMALL_QUADS; base < n; base += (size_t)gridDim.x * SMALL_QUADS) {
+    const bool active = base + quad < n;
+    const size_t e = active ? base + quad : n - 1;             // idle quads redo the last element and store nothing
+    uint32_t w[8], k[8], dg[8];
+    load32(scalar32, e, k);
+    ge g;
+    uint32_t bad = 0;
+    fr_reduce_words(k);
+    if (ELEMENT) {
+      g = load_ge_mont256(reinterpret_cast<const uint64_t*>(enc32), e);
+    } else {
+      load32(enc32, e, w);
+      bad = ge_decompress(T, pt, w, &g);                        // every lane of the quad: the same chain of squarings
+      fr_half_words(k);                                        // [k]P = [2]([k/2 mod r]P): the encoding of a double needs no square root
+    }
+    fr_recode_signed16(k, dg);
+    // table: entry j = the cached slots of [j]P, each lane the slot it will multiply by
+    const fe id_slot = fe_pick(role, fe_const(FE_ONE), fe_const(FE_ONE), fe_zero(), fe_const(FE_ONE));
+    const fe v1 = gq_from_ge(g, role);
+    const fe s1 = gq_cached_slot(v1, role);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { qtab[role * NL + i] = id_slot.l[i]; qtab[GQ_WORDS + role * NL + i] = s1.l[i]; }
+    __syncthreads();
+    fe acc = v1;
+#pragma unroll 1
+    for (int j = 2; j < VB_ENTRIES; ++j) {
+      acc = gq_add(acc, qtab + GQ_WORDS, role, false);         // [j]P = [j-1]P + P (the unified addition also doubles)
+      const fe sj = gq_cached_slot(acc, role);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) qtab[j * GQ_WORDS + role * NL + i] = sj.l[i];
+    }
+    __syncthreads();
+    // signed 4-bit windows, most significant first: 63 x (4 doublings, 1 addition); four sign-folded doublings keep the sign
+    int d = fr_digit(dg, 63);                                  // 0 or 1
+    fe v = fe_select(d != 0, v1, gq_from_ge(ge_identity(), role));
+#pragma unroll 1
+    for (int i = 62; i >= 0; --i) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) v = gq_double_neg(v, role);
+      d = fr_digit(dg, i);
+      const bool neg = d < 0;
+      v = gq_add(v, qtab + (neg ? -d : d) * GQ_WORDS, role, neg);
+    }
+    const ge r = gq_to_ge(v);
+    D377_INVARIANT(T, r, bad == 0);
+    if (ELEMENT) {
+      if (active && role == 0) store_ge_mont256(reinterpret_cast<uint64_t*>(out32), e, r);
+    } else {
+      OneDcbIO io;
+      dcb_put(io, 0, ge_dcb_from_half(r, bad != 0));           // failed elements: neutral state, all-zero output
+      dcb_finish(pt, io, 1);
+      if (active && role == 0) {
+        store32(out32, e, io.out);
+        status[e] = (uint8_t)bad;
+      }
+    }
+    __syncthreads();                                           // the table is rewritten by the next element
+  }
+}
+
 // The reference's own signatures for these operations take and return Elements (`Element * Fr`,
 // src/min_curve/ops.rs:89-95; `Element::encode_to_curve`, `hash_to_curve`, src/min_curve/element.rs:235-244;
 // `vartime_compress_to_field`, :163-181): the same per-lane code as above without the encoding step at either
@@ -774,6 +869,14 @@ int d377::debug_device_delay_ms() {
 
 namespace {
 
+// Batches up to this many elements take the quad-per-element kernel (k_scalar_mul_var_small): one wave of 16 quads per
+// SIMD.  Beyond it the quads would queue behind each other and one lane per element is the better use of the chip.
+// D377_SMALL_MAX: developer override (0 switches the small-batch kernel off).
+size_t small_batch_max(const DeviceState& d) {
+  if (const char* e = getenv("D377_SMALL_MAX")) return (size_t)strtoull(e, nullptr, 10);
+  return (size_t)d.cus * 4 * SMALL_QUADS;
+}
+
 int grid_for(const DeviceState& d, size_t n) {
   // >> 256 workgroups when the batch allows it; capped so huge batches grid-stride
   size_t blocks = (n + BLOCK - 1) / BLOCK;
@@ -951,6 +1054,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
                          dcb);
       break;
     case OP_MUL_VAR:
+      if (n <= small_batch_max(d)) {                          // one element per quad of lanes, table in LDS: no scratch, no hand-over
+        hipLaunchKernelGGL(k_scalar_mul_var_small<false>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, T,
+                           (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0, (uint8_t*)out1);
+        break;
+      }
       if ((rc = vb.acquire())) return rc;
       hipLaunchKernelGGL(k_scalar_mul_var, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_MUL_VAR], s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
                          (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch, dcb);
@@ -1018,6 +1126,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_MUL_VAR_EL: {
+      if (n <= small_batch_max(d)) {
+        hipLaunchKernelGGL(k_scalar_mul_var_small<true>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, T,
+                           (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0, (uint8_t*)nullptr);
+        break;
+      }
       // no inversions here, so nothing argues for long chunks: one or two elements per lane keep the grid oversubscribed
       // at every batch size
       // (2^20 elements: 7.33e7/s with 8 per lane, 7.44 with 4, 7.59 with 2, 7.54 with 1)

@@ -377,6 +377,50 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
         assert torch.equal(k2, fb), n
 
 
+def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
+    """Batches that cannot fill the chip with one lane per element (n <= 4 x 16 quads per CU) run one element per QUAD of
+    lanes (d377.hip k_scalar_mul_var_small, quad_ops.hpp).  Same bytes as the one-lane-per-element kernel (forced with
+    D377_SMALL_MAX=0) at sizes around every edge of the quad kernel's grid -- invalid encodings, zero and extreme
+    scalars included -- and as the oracle; likewise the Element form (records in, records out)."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4401)
+    small_max = torch.cuda.get_device_properties(0).multi_processor_count * 4 * 16
+    old = os.environ.pop("D377_SMALL_MAX", None)
+    try:
+        for n in (1, 3, 16, 17, 1000, small_max - 1, small_max, small_max + 1):
+            enc = oracle.encode_to_curve(rng.integers(0, 256, (min(n, 2048), 32), dtype=np.uint8))
+            enc = np.tile(enc, ((n + enc.shape[0] - 1) // enc.shape[0], 1))[:n].copy()
+            k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            enc[::13, 31] |= 0x80                            # invalid encodings
+            for i, v in enumerate([0, 1, 2, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1][:n]):
+                k[i] = ibytes(v)
+            te, tk = torch.from_numpy(enc).to(dev), torch.from_numpy(k).to(dev)
+            os.environ.pop("D377_SMALL_MAX", None)
+            out_q, st_q = ctx.scalar_mul_var(te, tk)
+            os.environ["D377_SMALL_MAX"] = "0"
+            out_l, st_l = ctx.scalar_mul_var(te, tk)
+            assert torch.equal(out_q, out_l) and torch.equal(st_q, st_l), n
+            sel = np.unique(np.concatenate([np.arange(min(n, 24)), np.arange(max(0, n - 24), n)]))
+            o_out, o_st = oracle.scalar_mul_var(enc[sel], k[sel])
+            assert (out_q.cpu().numpy()[sel] == o_out).all() and (st_q.cpu().numpy()[sel] == o_st).all(), n
+            # Element form: compare the group elements (encodings of the returned representatives)
+            valid = torch.from_numpy(oracle.encode_to_curve(rng.integers(0, 256, (min(n, 512), 32), dtype=np.uint8))).to(dev)
+            valid = valid.repeat((n + valid.shape[0] - 1) // valid.shape[0], 1)[:n].contiguous()
+            P, _ = ctx.decompress(valid)
+            os.environ.pop("D377_SMALL_MAX", None)
+            e_q = ctx.compress(ctx.scalar_mul_var_element(P, tk))
+            os.environ["D377_SMALL_MAX"] = "0"
+            e_l = ctx.compress(ctx.scalar_mul_var_element(P, tk))
+            assert torch.equal(e_q, e_l), n
+            want, _ = ctx.scalar_mul_var(valid, tk)
+            assert torch.equal(e_q, want), n
+    finally:
+        os.environ.pop("D377_SMALL_MAX", None)
+        if old is not None:
+            os.environ["D377_SMALL_MAX"] = old
+
+
 def test_chunk_residency_is_checked(ctx):
     """The lane-set pool of the scratch areas assumes at most `sets` resident workgroups per CU of every kernel that
     claims a set.  d377_ctx_create verifies that with the occupancy query (and pads the launch's LDS where registers
