@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   export D377_LIB=$ROOT/build/variants/$v.so
   i=0
-  for grp in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_WAVES SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_WAVES SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
     i=$((i+1))
     timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$ROOT/$out/$v/pmc$i" -- python3 "$ROOT/tools/size_sweep.py" --ops scalar_mul_base --sizes 1048576 > "$ROOT/$out/$v.pmc$i.log" 2>&1
   done
