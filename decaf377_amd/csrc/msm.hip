@@ -4,24 +4,23 @@
 // `acc + scalar * point`.  Same result, different schedule: Pippenger's bucket method with
 // signed c-bit windows, laid out for one-lane-per-bucket execution:
 //
-//   k_msm_prepare_* one lane per (point, scalar): decompress (Encodings) or batched-inversion normalisation
-//                   (Elements) -> cached AFFINE record in HBM (128 bytes); scalar mod r -> W signed digits
+//   k_msm_prepare_* one lane per (point, scalar): decompress (Encodings), conversion (Elements with Z = 1) or batched-inversion
+//                   normalisation (any Z) -> cached AFFINE record in HBM (128 bytes); scalar mod r -> W signed digits
 //   k_msm_count     counting sort, pass 1: workgroup (window, slice) builds the histogram of |digit| over
 //                   its slice of the points in LDS (the whole histogram of a window, <= 2^13 + 1 counters,
 //                   fits) and writes it out
 //   k_msm_scan1/2   per-bucket prefix over the slices, then the exclusive prefix sums over the buckets of a window
-//                   (bucket sizes, and segment / group counts for the reduction levels)
+//                   (bucket sizes, and segment / group counts for the reduction levels, and each level's largest count)
 //   k_msm_place1    pass 2, level 1: the same workgroup scatters each point's index (sign in bit 31) into the
 //                   super-bucket (128 consecutive buckets) it belongs to; LDS atomics hand out the positions
 //   k_msm_place2    level 2: workgroup (window, super-bucket) spreads its entries over the 128 bucket runs
-//   k_msm_segments  one lane per 32-point segment of a bucket run: mixed additions (7 M each)
-//   k_msm_reduce    the same again on the partial sums (groups of 32, up to two more levels): a bucket that holds
-//                   most of the points (many equal scalars) is cut down by 32 per level, not summed by one lane
-//   k_msm_buckets   one lane per bucket: sum of what is left of it (one partial with random scalars)
-//   k_msm_chunks    one lane per 32 consecutive buckets: running-sum trick inside the chunk,
-//                   plus (lo - 1) * (chunk total) by double-and-add:  sum_b b * B_b
-//   k_msm_fold      32-to-1 folds until one point per window
-//   k_msm_final     Horner over the windows (c doublings per window), compress
+//   k_msm_segments  one lane per segment (8 / 16 / 32 points) of a bucket run: mixed additions (7 M each)
+//   k_msm_reduce    the same again on the partial sums (groups of 8, 8, 32): every level decides on the device whether
+//                   it runs; a bucket that holds most of the points (many equal scalars) is cut down level by level
+//   k_msm_buckets   one lane per bucket: sum of what is left of it (a few partials with random scalars)
+//   k_msm_wsum_*    sum_b b * B_b per window by a pairwise tree of bit-sums, then Horner over the bits on four lanes
+//                   (k_msm_chunks / k_msm_fold, the chunked running sums, remain for windows wider than 14 bits)
+//   k_msm_final     Horner over the windows (c doublings per window) on four lanes per point (quad_ops.hpp), the encoding
 //
 // Group-element outputs are canonical as encodings, so the result bytes equal the reference's
 // whatever the summation order (the scatter order is non-deterministic; the sum is not).

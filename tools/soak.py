@@ -72,6 +72,19 @@ def main():
     num[4::997] = 0
     root, ws = ctx.sqrt_ratio_zeta(num, den)
     check("sqrt_ratio_zeta", (root, ws), "sqrt_ratio_zeta", num, den)
+    # small batches take other kernels (one element per quad of lanes up to 16 384 elements; inversion-free roots below 3
+    # elements per lane): many calls of awkward sizes, checked as one concatenated batch
+    sizes = [1, 2, 3, 15, 16, 17, 63, 64, 65, 255, 1000, 4097, 16383, 16384, 16385, 40000] * 8
+    off = 0
+    outs, sts, encs = [], [], []
+    for sz in sizes:
+        p_, k_ = pts[off: off + sz], k[off: off + sz]
+        o_, s_ = ctx.scalar_mul_var(p_.contiguous(), k_.contiguous())
+        outs.append(o_); sts.append(s_)
+        encs.append(ctx.encode_to_curve(r0[off: off + sz].contiguous()))
+        off += sz
+    check("var-base, small calls", (torch.cat(outs), torch.cat(sts)), "scalar_mul_var", pts[:off], k[:off])
+    check("Elligator, small calls", (torch.cat(encs),), "encode_to_curve", r0[:off], None)
     nh = min(n // 2, 1 << 18)                                      # the oracle's hash_to_curve is single-threaded
     h = ctx.hash_to_curve(r0[:nh], r0[n: n + nh])
     ho = orc.hash_to_curve(r0[:nh].cpu().numpy(), r0[n: n + nh].cpu().numpy())
