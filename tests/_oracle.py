@@ -11,9 +11,17 @@ LIB = os.path.join(ORACLE_DIR, "libd377_oracle.so")
 
 
 def build_oracle():
+    """Builds the checker if it is missing or older than its source.  Several ranks of a multi-GPU bench may get here at
+    once: the check and the build happen under a file lock, so one of them builds and the others find it done."""
+    import fcntl
     src = os.path.join(ORACLE_DIR, "d377_oracle.c")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
@@ -39,7 +47,10 @@ class Oracle:
         self.flags = "-O3 -march=x86-64-v3"
         if native:
             try:
-                subprocess.check_call(["make", "-C", ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                import fcntl
+                with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    subprocess.check_call(["make", "-C", ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 path = os.path.join(ORACLE_DIR, "libd377_oracle_native.so")
                 self.flags = "-O3 -march=native (built on this host)"
             except Exception:

@@ -480,14 +480,15 @@ def test_graph_replay_overlaps_eager_calls(ctx, oracle, torch_mod):
 
 
 def test_soak_tool_small():
-    """tools/soak.py (the large-sample parity run whose full-size output is profiles/r02d_soak.txt) at 2^14: every
+    """tools/soak.py (the large-sample parity run whose full-size output is profiles/r03_soak.txt) at 2^14: every
     operation on seeded random inputs with invalid encodings, identity points, zero operands and the scalars
-    0, 1, 2, 3, r-1, r, r+1, (r+-1)/2, 2^251-1, 2^256-1 mixed in, byte for byte against the oracle."""
+    0, 1, 2, 3, r-1, r, r+1, (r+-1)/2, 2^251-1, 2^256-1 mixed in, and a train of small calls of awkward sizes (the
+    small-batch kernels), byte for byte against the oracle."""
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "14", "7"], cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("bit-exact") == 6 and "MISMATCH" not in r.stdout
+    assert r.stdout.count("bit-exact") == 8 and "MISMATCH" not in r.stdout
 
 
 def test_full_size_var_base_2_22(ctx, torch_mod, oracle):

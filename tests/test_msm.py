@@ -133,7 +133,7 @@ def test_msm_equal_and_few_distinct_scalars(ctx, oracle, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window", [4, 5, 7, 12, 14, 16])
+@pytest.mark.parametrize("window", [4, 5, 6, 7, 9, 12, 14, 16])
 def test_msm_every_window_width(oracle, window):
     """Same inputs through different bucket widths (developer override) give the same bytes."""
     import decaf377_amd as d

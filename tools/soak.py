@@ -78,6 +78,8 @@ def main():
     off = 0
     outs, sts, encs = [], [], []
     for sz in sizes:
+        if off + sz > n:
+            break
         p_, k_ = pts[off: off + sz], k[off: off + sz]
         o_, s_ = ctx.scalar_mul_var(p_.contiguous(), k_.contiguous())
         outs.append(o_); sts.append(s_)
