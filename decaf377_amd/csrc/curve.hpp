@@ -1053,6 +1053,44 @@ D377_HD dcb_state ge_dcb_from_jacobi_st(const fe& s_in, const fe& t) {
   st.n1 = fe_mul_strict(t, fe_const(FE_ONE));           // n1 / p = 1 / s
   return dcb_guard_zero(st, false);
 }
+// State of the SUM of two Elligator points, from their Jacobi-quartic preimages (hash_to_curve, elligator.rs:67-71).
+// The decaf isogeny J -> E, (s, t) -> (2s t : (1 - s^2)(1 + s^2) : (1 - s^2) t : 2s (1 + s^2)), is a homomorphism, so
+// map(r1) + map(r2) = image of (s1, t1) + (s2, t2) ADDED ON THE QUARTIC  J: t^2 = s^4 - 2 delta s^2 + 1, delta = 1 + 2d
+// (a = -1), and a point with a known preimage encodes without a square root (above): the reference's third square root
+// of hash_to_curve -- the compression of a sum of two Edwards points -- disappears.  Addition law of a Jacobi quartic in
+// this form, kept projective (s3 = X / Z, t3 = Y / Z^2):
+//     X = s1 t2 + t1 s2,   Z = 1 - (s1 s2)^2,   Y = (1 + (s1 s2)^2)(t1 t2 - 2 delta s1 s2) + 2 s1 s2 (s1^2 + s2^2);
+// with s = X / Z, t = Y / Z^2 the state (p, w, n0, n1) of ge_dcb_from_jacobi_st, cleared of denominators by Z^3, is
+//     p = X Y Z,  w = 2 (X Z)^2,  n0 = X^2 Y,  n1 = Y Z^2          (w / p = 2s / t, n0 / p = s, n1 / p = 1 / s).
+// X = 0 or Y = 0 is the identity class (encoding 0, as the p = 0 rule gives).  Z = 0 (s1 s2 = +-1) is the one exceptional
+// case of the law -- the sum has no finite (s, t) and X, Y may vanish with it -- reported through *exceptional: the caller
+// takes the reference's route (Edwards addition, compression with its square root) for such a pair.  Checked against the
+// big-integer model for random pairs, doubling, opposite points and constructed exceptional pairs
+// (tests/test_host_sim.py::test_hash_to_curve_on_the_quartic).  8 M + 3 S for the sum, 5 M + 3 S for the state.
+D377_HD dcb_state ge_dcb_from_jacobi_sum(const fe& s1, const fe& t1, const fe& s2, const fe& t2, bool* exceptional) {
+  const fe one = fe_const(FE_ONE);
+  const fe xx = fe_mul(s1, s2);
+  const fe xx2 = fe_sqr_strict(xx);                                 // strict: Z = 1 - xx2 feeds a zero test
+  const fe x = fe_mul(fe_add(fe_mul(s1, t2), fe_mul(t1, s2)), one); // X (a product again: it is squared and multiplied below)
+  const fe z = fe_mul_strict(fe_sub(one, xx2), one);                // Z, value below 2q
+  *exceptional = fe_strict_is_zero(z);
+  const fe inner = fe_sub(fe_mul(t1, t2), fe_mul(fe_const(FE_2_PLUS_4D), xx));
+  const fe outer = fe_mul(fe_dbl(xx), fe_add(fe_sqr(s1), fe_sqr(s2)));
+  const fe y = fe_mul(fe_add(fe_mul(fe_add(one, xx2), inner), outer), one);   // Y
+  const fe xz = fe_mul(x, z), x2 = fe_sqr(x), z2 = fe_sqr(z);
+  dcb_state st;
+  st.p = fe_mul_strict(xz, y);
+  st.w = fe_mul_strict(xz, fe_dbl(xz));
+  st.n0 = fe_mul_strict(x2, y);
+  st.n1 = fe_mul_strict(z2, y);
+  return dcb_guard_zero(st, false);
+}
+// a finished encoding (canonical words of s) as a state: p = 1, w = 0 (non-negative: n0 is taken), n0 = s
+D377_HD dcb_state dcb_from_encoding_words(const uint32_t w[8]) {
+  dcb_state st = dcb_neutral();
+  st.n0 = fe_mul_strict(fe_from_words(w), fe_const(FE_R2));
+  return st;
+}
 // IO: where a lane keeps the states of its current round and where results go --
 //   get(slot, j, w) / put(slot, j, w): 32-byte record `slot` (0 p, 1 w, 2 n0, 3 n1) of the round's j-th element;
 //   park(j, w) / parked(j, w): a 32-byte place per element that is free until its result is written (the output

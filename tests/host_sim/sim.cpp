@@ -376,6 +376,38 @@ void sim_hash_to_curve(const uint32_t* r1, const uint32_t* r2, size_t n, uint32_
       ge_compress(g_T, pt, ge_add(a, b), enc + 8 * i);
     });
 }
+// k_hash_to_curve as the kernel does it now: both maps as far as (s, t), the sum on the Jacobi quartic, the square-root-free
+// compressor; exceptional pairs by the reference's route.  force_exceptional: every pair takes that route (its plumbing).
+// st1 / st2 (optional): instead of mapping r1 / r2, take these (s, t) pairs (4 x 8 words: canonical s1, t1, s2, t2 per
+// element) -- lets a test hand in points that hit the addition law's exceptional case.
+void sim_hash_to_curve_quartic(const uint32_t* r1, const uint32_t* r2, size_t n, uint32_t* enc, int force_exceptional,
+                               const uint32_t* st_pairs, uint8_t* exceptional_out) {
+  dcb_rounds<2>(n, enc, true,
+    [&](HostDcbIO& io, size_t i, int j) {
+      dcb_put_den(io, 0, j, ge_elligator_den(fe_from_words_mod_order(r1 + 8 * i)));
+      dcb_put_den(io, 1, j, ge_elligator_den(fe_from_words_mod_order(r2 + 8 * i)));
+    },
+    [&](HostDcbIO& io, size_t i, int j) {
+      const fe i1 = dcb_get_inv(io, 0, j), i2 = dcb_get_inv(io, 1, j);
+      RegPowTab pt;
+      fe s1, t1, s2, t2;
+      ge_elligator_st(g_T, pt, fe_from_words_mod_order(r1 + 8 * i), &s1, &t1, &i1);
+      ge_elligator_st(g_T, pt, fe_from_words_mod_order(r2 + 8 * i), &s2, &t2, &i2);
+      if (st_pairs) {
+        s1 = fe_from_words_mod_order(st_pairs + 32 * i); t1 = fe_from_words_mod_order(st_pairs + 32 * i + 8);
+        s2 = fe_from_words_mod_order(st_pairs + 32 * i + 16); t2 = fe_from_words_mod_order(st_pairs + 32 * i + 24);
+      }
+      bool exc;
+      dcb_state st = ge_dcb_from_jacobi_sum(s1, t1, s2, t2, &exc);
+      if (exceptional_out) exceptional_out[i] = exc ? 1 : 0;
+      if (exc || force_exceptional) {
+        uint32_t w[8];
+        ge_compress(g_T, pt, ge_add(ge_from_jacobi_st(s1, t1), ge_from_jacobi_st(s2, t2)), w);
+        st = dcb_from_encoding_words(w);
+      }
+      dcb_put(io, j, st);
+    });
+}
 void sim_fr_half(const uint32_t* k, size_t n, uint32_t* out) {
   for (size_t i = 0; i < n; ++i) { memcpy(out + 8 * i, k + 8 * i, 32); fr_reduce_words(out + 8 * i); fr_half_words(out + 8 * i); }
 }

@@ -1208,7 +1208,8 @@ out, st = ctx.scalar_mul_var(raw, k); o_out, o_st = orc.scalar_mul_var(raw, k)
 assert (out == o_out).all() and (st == o_st).all() and st.any()
 rt, st = ctx.roundtrip(raw); o_rt, o_st = orc.roundtrip(raw)
 assert (rt == o_rt).all() and (st == o_st).all()
-assert (ctx.hash_to_curve(r0, r1) == orc.hash_to_curve(r0, r1)).all()
+assert (ctx.hash_to_curve(r0, r1) == orc.hash_to_curve(r0, r1)).all()     # this build routes every fourth pair through the
+                                                                           # exceptional case of the quartic's addition law
 assert (ctx.scalar_mul_base(k) == orc.scalar_mul_base(k)).all()
 xyzt, st = ctx.decompress(enc)
 assert (ctx.compress(ctx.double(ctx.add(xyzt, xyzt[::-1].copy()))) == orc.compress(orc.double_xyzt(orc.add_xyzt(xyzt, xyzt[::-1].copy())))).all()

@@ -495,6 +495,7 @@ full = np.full((n, 16), 0xFFFFFFFFFFFFFFFF, np.uint64)      # every word string 
 for u, v in ((xyzt, x2), (full, full)):
     L.sim_raw_forms(p(u), p(v), n_(n), p(a), p(b), p(np.zeros((n, 16), np.uint64)), p(fl[0]), p(fl[1]), p(f[0]), p(f[1]), p(f[2]), p(f[3]), p(f[4]), p(fl[2]))
 L.sim_raw_ge_sub(p(xyzt), p(x2), n_(n), p(a)); L.sim_raw_ge_sub(p(full), p(full), n_(n), p(a))
+L.sim_hash_to_curve_quartic(p(r0), p(k), n_(n), p(out), 0, None, None); L.sim_hash_to_curve_quartic(p(r0), p(k), n_(n), p(out), 1, None, None)
 L.sim_hash_to_curve(p(r0), p(k), n_(n), p(out)); L.sim_compress_assisted(p(xyzt), n_(n), p(out)); L.sim_sqrt_ratio_zeta_plain(p(r0), p(k), n_(n), p(out), p(st))
 L.sim_decompress_assisted(p(enc), n_(n), p(x2), p(st)); L.sim_roundtrip_assisted(p(k), n_(n), p(out), p(st))
 L.sim_scalar_mul_var_sqrt(p(enc), p(k), n_(n), p(out), p(st)); L.sim_encode_to_curve_sqrt(p(r0), n_(n), p(out))
@@ -527,6 +528,68 @@ def test_msm_bucket_chain_matches_oracle(sim, oracle):
                 b = oracle.add_xyzt(b, signed[i])
             want = oracle.add_xyzt(oracle.add_xyzt(a, b), oracle.add_xyzt(a, a))
             assert bytes(oracle.compress(out)[0]) == bytes(oracle.compress(want)[0]), (n, rep)
+
+
+def test_hash_to_curve_on_the_quartic(sim, oracle):
+    """hash_to_curve with the sum formed on the Jacobi quartic and encoded without a square root (curve.hpp
+    ge_dcb_from_jacobi_sum) gives the reference's bytes (src/ark_curve/elligator.rs:67-71, oracle): random pairs, r2 = r1
+    (a doubling), r2 = -r1, zeros; the route for exceptional pairs forced for every element; and constructed pairs
+    (s, t), (+-1/s, +-t/s^2) that really hit the exceptional case, against the big-integer model."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("d377_model", os.path.join(ROOT, "oracle", "d377_model.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    rng = np.random.default_rng(31)
+    n = 96
+    r1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    r2 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    r2[0] = r1[0]
+    neg = (M.Q - M.fq_from_le_bytes_mod_order(bytes(r1[1]))) % M.Q
+    r2[1] = np.frombuffer(neg.to_bytes(32, "little"), np.uint8)
+    r1[2] = 0
+    r1[3] = 0; r2[3] = 0
+    want = oracle.hash_to_curve(r1, r2)
+    for force in (0, 1):
+        out = np.zeros((n, 32), np.uint8)
+        exc = np.zeros(n, np.uint8)
+        sim.sim_hash_to_curve_quartic(_p(r1), _p(r2), n_(n), _p(out), force, None, _p(exc))
+        assert (out == want).all(), force
+        assert not exc.any()
+    # constructed exceptional pairs: (s, t) and (e1 / s, e2 t / s^2) are both on the quartic and s1 s2 = e1 = +-1
+    Q, D = M.Q, M.COEFF_D
+
+    def phi(s, t):
+        E, F, G = 2 * s % Q, (1 - s * s) % Q, (1 + s * s) % Q
+        return (E * t % Q, F * G % Q, F * t % Q, E * G % Q)
+
+    m = 16
+    pairs = np.zeros((m, 4, 32), np.uint8)
+    expect = []
+    for i in range(m):
+        r = M.fq_from_le_bytes_mod_order(bytes(r2[8 + i]))
+        rr = M.ZETA * r % Q * r % Q
+        # (s, t) of the map of r, by the model's own elligator (affine x, y -> not needed: rebuild s, t from its steps)
+        A = M.COEFF_A
+        den = (D * rr - (D - A)) % Q * (((D - A) * rr - D) % Q) % Q
+        num = (rr + 1) * (A - 2 * D) % Q
+        iss, isri = M.sqrt_ratio_zeta(1, num * den % Q)
+        sgn, tw = (1, 1) if iss else (Q - 1, r % Q)
+        isri = isri * tw % Q
+        s = isri * num % Q
+        t = ((-sgn) * isri % Q * s % Q * (rr - 1) % Q * pow((A - 2 * D) % Q, 2, Q) - 1) % Q
+        if M.is_negative(s) == iss:
+            s = (-s) % Q
+        e1, e2 = (1, Q - 1)[i & 1], (1, Q - 1)[(i >> 1) & 1]
+        si = pow(s, Q - 2, Q)
+        s2, t2 = e1 * si % Q, e2 * t % Q * si % Q * si % Q
+        for c, v in enumerate((s, t, s2, t2)):
+            pairs[i, c] = np.frombuffer(v.to_bytes(32, "little"), np.uint8)
+        expect.append(bytes(M.compress(M.pt_add(phi(s, t), phi(s2, t2)))))
+    out = np.zeros((m, 32), np.uint8)
+    exc = np.zeros(m, np.uint8)
+    sim.sim_hash_to_curve_quartic(_p(r1[:m].copy()), _p(r2[:m].copy()), n_(m), _p(out), 0, _p(pairs), _p(exc))
+    assert exc.all()
+    assert [bytes(o) for o in out] == expect
 
 
 def test_doubling_variants_agree(sim, oracle):
@@ -573,7 +636,7 @@ def run(n, what):
     if what == "scalar_mul_base_w8": L.sim_scalar_mul_base(p(k), n_(n), p(out))
     if what == "sqrt_ratio_zeta": L.sim_sqrt_ratio_zeta(p(r0), p(k), n_(n), p(out), p(st))
     if what == "encode_to_curve": L.sim_encode_to_curve(p(r0), n_(n), p(enc), None)
-    if what == "hash_to_curve": L.sim_hash_to_curve(p(r0), p(k), n_(n), p(out))
+    if what == "hash_to_curve": L.sim_hash_to_curve_quartic(p(r0), p(k), n_(n), p(out), 0, None, None)
     if what == "decompress": L.sim_decompress(p(enc), n_(n), p(np.zeros((n, 16), np.uint64)), p(st))
     if what == "compress":
         x = np.zeros((n, 16), np.uint64); L.sim_decompress(p(enc), n_(n), p(x), p(st)); L.sim_op_counts(ctypes.byref(m), ctypes.byref(s))
