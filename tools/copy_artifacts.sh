@@ -1,0 +1,17 @@
+#!/bin/bash
+# Copies what tools/round_artifacts.sh produced (merged back by gpurun) into profiles/ under this round's names.
+# usage: tools/copy_artifacts.sh gpurun_out/r03/final3 r03
+F=$1; R=$2
+cp $F/pmc/pmc_traffic.json profiles/pmc_traffic.json
+sed -i "s#\"source\": \"$F/pmc/pmc_summary.csv\"#\"source\": \"profiles/${R}_pmc_summary.csv\"#" profiles/pmc_traffic.json
+cp $F/pmc/pmc_summary.csv profiles/${R}_pmc_summary.csv
+cp $F/pmc/kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
+tail -1 $F/pmc/bench_under_rocprof.log > profiles/${R}_bench_line_under_rocprof.json
+tail -1 $F/bench_line.json > profiles/${R}_bench_line.json
+grep -v "amdgpu.ids" $F/size_sweep.txt > profiles/${R}_size_sweep.txt
+cp $F/msm_kernel_breakdown.txt profiles/${R}_msm_kernel_breakdown.txt
+grep -v "^pass\|amdgpu.ids" "$F/pmc_ops_2^20.txt" > "profiles/${R}_pmc_ops_2^20.txt"
+cp $F/multigpu_selftest.txt profiles/${R}_multigpu_selftest_1gpu.txt
+grep -v "amdgpu.ids" $F/msm_skew.txt > profiles/${R}_msm_skew.txt
+grep -v "amdgpu.ids" $F/soak.txt > profiles/${R}_soak.txt
+tools/resource_usage.sh > profiles/${R}_resource_usage.txt 2>/dev/null
