@@ -50,8 +50,8 @@ constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a seri
 // 2^22-point MSM leaves 16 partials: eight per lane keeps 2 x the buckets busy instead of one lane per bucket walking
 // 15 dependent additions (883 workgroups of 4 waves on 768 places: 335 us for 2.2 M additions, against ~120 us of
 // issue time); the wide last level is for runs that hold most of the points (many equal scalars).
-__device__ __constant__ const int RED_G[3] = {8, 8, 32};
-constexpr int RED_HOST[3] = {8, 8, 32};
+struct RedSizes { int g[3]; };
+constexpr RedSizes RED_DEFAULT = {{8, 8, 32}};
 // A level runs only if some bucket still has more than this many partials; fewer are summed by the lane that finishes
 // the bucket (a level of its own for two or three leftovers -- the tail of the Poisson run lengths -- cost 27-56 us).
 constexpr uint32_t RED_SKIP = 4;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digit
 // Prefix sums of the sort, two small kernels over workgroups (window, 1024 buckets).
 // In: blockhist[w][s][b] = points of slice s in bucket b.  Out: blockhist[w][s][b] = points of the slices before s in
 // bucket b; offs[w][0..nb] = exclusive prefix of the bucket sizes (offs[w][nb] = total); segoff[l][w][0..nb],
-// l = 0..REDUCE_LEVELS-1 = the same for ceil(size / seg), ceil(that / RED_G[0]), ...: the number of seg-point segments per
+// l = 0..REDUCE_LEVELS-1 = the same for ceil(size / seg), ceil(that / red.g[0]), ...: the number of seg-point segments per
 // bucket, of groups of segments, ... (the levels of the bucket reduction).  k_msm_scan1 leaves prefixes local to its 1024 buckets
 // and the four totals of the workgroup in tot[w][chunk][]; k_msm_scan2 adds the totals of the chunks before.  (One
 // workgroup per window walking its buckets 1024 at a time took 0.12 ms at every size: 18 workgroups on 256 CUs.)
@@ -242,7 +242,7 @@ constexpr int REDUCE_LEVELS = 4;
 // lvlmax[l] (zeroed by the host before the launch) receives the largest number of level-(l+1) partials any bucket has:
 // a reduction level whose input leaves no bucket with more than RED_SKIP partials returns at once.
 __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, uint32_t* tot, int nb,
-                                                    int S, int W, int nchunk, int seg, uint32_t* lvlmax) {
+                                                    int S, int W, int nchunk, int seg, RedSizes red, uint32_t* lvlmax) {
   __shared__ uint32_t part[1 + REDUCE_LEVELS][1024];
   __shared__ uint32_t bmax[REDUCE_LEVELS];
   if (threadIdx.x < REDUCE_LEVELS) bmax[threadIdx.x] = 0;
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_
   uint32_t own[1 + REDUCE_LEVELS];
   own[0] = c;
   own[1] = (own[0] + (uint32_t)seg - 1) / (uint32_t)seg;
-  for (int l = 2; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + (uint32_t)RED_G[l - 2] - 1) / (uint32_t)RED_G[l - 2];
+  for (int l = 2; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + (uint32_t)red.g[l - 2] - 1) / (uint32_t)red.g[l - 2];
   for (int l = 0; l <= REDUCE_LEVELS; ++l) part[l][t] = own[l];
   __syncthreads();
   for (int l = 1; l <= REDUCE_LEVELS; ++l)
@@ -890,11 +890,13 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_bkt = carve((size_t)W * nb * PT_WORDS * 4);
   // further levels of the bucket reduction: groups of partials, then groups of those (never more than this many); every
   // level is launched and decides on the device whether it has anything to do (k_msm_scan1, lvlmax)
+  RedSizes red = RED_DEFAULT;
+  if (const char* e = getenv("D377_MSM_RED")) { int v = atoi(e); if (v >= 2 && v <= 64) red.g[0] = v; }   // developer override (sweeps)
   size_t max_g[REDUCE_LEVELS];
   size_t o_r[REDUCE_LEVELS];
   max_g[0] = max_segs; o_r[0] = o_par;
   for (int l = 1; l < REDUCE_LEVELS; ++l) {
-    max_g[l] = max_g[l - 1] / (size_t)RED_HOST[l - 1] + (size_t)W * nb;
+    max_g[l] = max_g[l - 1] / (size_t)red.g[l - 1] + (size_t)W * nb;
     o_r[l] = carve(max_g[l] * PT_WORDS * 4);
   }
   const size_t o_lvl = carve(256);
@@ -966,7 +968,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   uint32_t* tot = (uint32_t*)(m + o_tot);
   uint32_t* lvlmax = (uint32_t*)(m + o_lvl);
   HIP_TRY(hipMemsetAsync(lvlmax, 0, REDUCE_LEVELS * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, segoff, tot, nb, S, W, scan_chunks, seg, lvlmax);
+  hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, segoff, tot, nb, S, W, scan_chunks, seg, red, lvlmax);
   hipLaunchKernelGGL(k_msm_scan2, dim3(W * scan_chunks), dim3(1024), 0, s, offs, segoff, tot, nb, W, scan_chunks);
   hipLaunchKernelGGL(k_msm_place1, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
   hipLaunchKernelGGL(k_msm_place2, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
@@ -978,7 +980,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   for (int l = 1; l < REDUCE_LEVELS; ++l) {
     uint32_t* r = (uint32_t*)(m + o_r[l]);
     hipLaunchKernelGGL(k_msm_reduce, dim3(grid_of(d, max_g[l])), dim3(BLOCK), 0, s, lv.buf[l - 1], segoff + (size_t)(l - 1) * so_stride,
-                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, RED_HOST[l - 1], lvlmax + (l - 1));
+                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax + (l - 1));
     lv.buf[l] = r;
   }
   hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, lv, segoff, lvlmax, W, nb, bkt);

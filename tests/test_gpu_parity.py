@@ -337,6 +337,31 @@ def test_full_size_fixed_base_2_20(ctx, torch_mod, oracle):
     assert (fb[idx].cpu().numpy() == oracle.scalar_mul_base(k.numpy()[idx])).all()
 
 
+def test_full_size_hash_to_curve_two_routes_2_20(ctx, torch_mod, oracle):
+    """hash_to_curve at BASELINE size by two routes that share no formula after the maps: the kernel's (the two points
+    added on the Jacobi quartic, encoded without a square root) against the reference's own statement
+    (src/ark_curve/elligator.rs:67-71) spelt out with the Element entry points -- encode_to_curve_element twice, Edwards
+    addition, generic compression with its square root.  2^20 pairs, every byte; a sample against the oracle; and the
+    Element-returning form."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    n = 1 << 20
+    g = torch.Generator(device=dev).manual_seed(9311)
+    r1 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    r2 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    r2[:1000] = r1[:1000]                                # doublings on the quartic
+    r1[1000:1100] = 0                                    # the map of 0
+    r2[1100:1200] = 0
+    r1[1200:1300] = 0; r2[1200:1300] = 0
+    h = ctx.hash_to_curve(r1, r2)
+    want = ctx.compress(ctx.add(ctx.encode_to_curve_element(r1), ctx.encode_to_curve_element(r2)))
+    assert torch.equal(h, want)
+    assert torch.equal(ctx.compress(ctx.hash_to_curve_element(r1, r2)), want)
+    idx = np.unique(np.concatenate([np.arange(0, 1400, 7), np.arange(17, n, n // 301)]))
+    ti = torch.from_numpy(idx).to(dev)
+    assert (h[ti].cpu().numpy() == oracle.hash_to_curve(r1[ti].cpu().numpy(), r2[ti].cpu().numpy())).all()
+
+
 def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
     """The square-root-free compressor (curve.hpp `dcb_finish`; reference: src/ark_curve/encoding.rs:91-128) and the
     batched inversions work in chunks: one workgroup takes per_lane x 256 consecutive elements, per_lane = ceil(n /
