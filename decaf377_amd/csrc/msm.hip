@@ -50,11 +50,11 @@ constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a seri
 // 2^22-point MSM leaves 16 partials: eight per lane keeps 2 x the buckets busy instead of one lane per bucket walking
 // 15 dependent additions (883 workgroups of 4 waves on 768 places: 335 us for 2.2 M additions, against ~120 us of
 // issue time); the wide last level is for runs that hold most of the points (many equal scalars).
-struct RedSizes { int g[3]; };
-constexpr RedSizes RED_DEFAULT = {{8, 8, 32}};
-// A level runs only if some bucket still has more than this many partials; fewer are summed by the lane that finishes
-// the bucket (a level of its own for two or three leftovers -- the tail of the Poisson run lengths -- cost 27-56 us).
-constexpr uint32_t RED_SKIP = 4;
+// `skip`: a level runs only if some bucket still has more than this many partials; fewer are summed by the lane that
+// finishes the bucket (a level of its own for two or three leftovers -- the tail of the Poisson run lengths -- cost 27-56 us).
+// Segment length x skip threshold swept at 2^20 / 2^22 (16-64 x 4-16): everything within 2 %.
+struct RedSizes { int g[3]; uint32_t skip; };
+constexpr RedSizes RED_DEFAULT = {{8, 8, 32}, 4};
 // Points per lane in k_msm_segments (`seg`, a launch parameter): 8, 16 or 32 by batch size -- pick_seg() below.
 constexpr int MAX_SEG = 128;
 
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digit
 // workgroup per window walking its buckets 1024 at a time took 0.12 ms at every size: 18 workgroups on 256 CUs.)
 constexpr int REDUCE_LEVELS = 4;
 // lvlmax[l] (zeroed by the host before the launch) receives the largest number of level-(l+1) partials any bucket has:
-// a reduction level whose input leaves no bucket with more than RED_SKIP partials returns at once.
+// a reduction level whose input leaves no bucket with more than `skip` partials returns at once.
 __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, uint32_t* tot, int nb,
                                                     int S, int W, int nchunk, int seg, RedSizes red, uint32_t* lvlmax) {
   __shared__ uint32_t part[1 + REDUCE_LEVELS][1024];
@@ -519,8 +519,8 @@ k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, c
 // level cuts its partials by `red` instead of leaving them to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, int W, int nb, size_t max_groups, uint32_t* out,
-             int red, const uint32_t* in_max) {
-  if (*in_max <= RED_SKIP) return;                       // every bucket is down to a few partials: k_msm_buckets adds those itself
+             int red, const uint32_t* in_max, uint32_t skip) {
+  if (*in_max <= skip) return;                       // every bucket is down to a few partials: k_msm_buckets adds those itself
   const int len = nb + 1;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_groups; gi += (size_t)gridDim.x * BLOCK) {
     int w, b;
@@ -548,16 +548,16 @@ k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, 
 }
 
 // one lane per bucket: sum of what the last level that ran left of it (a few partials at most with random scalars).
-// Level l + 1 ran iff lvlmax[l - 1] > RED_SKIP; the levels that ran are a prefix.
+// Level l + 1 ran iff lvlmax[l - 1] > skip; the levels that ran are a prefix.
 struct MsmLevels {
   const uint32_t* buf[REDUCE_LEVELS];                     // partial sums after level 1 (segments), 2, ...
 };
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_buckets(MsmLevels lv, const uint32_t* segoff_all, const uint32_t* lvlmax, int W, int nb, uint32_t* buckets) {
+k_msm_buckets(MsmLevels lv, const uint32_t* segoff_all, const uint32_t* lvlmax, uint32_t skip, int W, int nb, uint32_t* buckets) {
   const int len = nb + 1;
   const size_t total = (size_t)W * nb;
   int last = 0;
-  while (last + 1 < REDUCE_LEVELS && lvlmax[last] > RED_SKIP) ++last;
+  while (last + 1 < REDUCE_LEVELS && lvlmax[last] > skip) ++last;
   const uint32_t* partial = lv.buf[last];
   const uint32_t* segoff = segoff_all + (size_t)last * W * len;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < total; gi += (size_t)gridDim.x * BLOCK) {
@@ -891,7 +891,8 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   // further levels of the bucket reduction: groups of partials, then groups of those (never more than this many); every
   // level is launched and decides on the device whether it has anything to do (k_msm_scan1, lvlmax)
   RedSizes red = RED_DEFAULT;
-  if (const char* e = getenv("D377_MSM_RED")) { int v = atoi(e); if (v >= 2 && v <= 64) red.g[0] = v; }   // developer override (sweeps)
+  if (const char* e = getenv("D377_MSM_RED")) { int v = atoi(e); if (v >= 2 && v <= 64) red.g[0] = v; }   // developer overrides (sweeps)
+  if (const char* e = getenv("D377_MSM_SKIP")) { int v = atoi(e); if (v >= 1 && v <= 64) red.skip = (uint32_t)v; }
   size_t max_g[REDUCE_LEVELS];
   size_t o_r[REDUCE_LEVELS];
   max_g[0] = max_segs; o_r[0] = o_par;
@@ -980,10 +981,10 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   for (int l = 1; l < REDUCE_LEVELS; ++l) {
     uint32_t* r = (uint32_t*)(m + o_r[l]);
     hipLaunchKernelGGL(k_msm_reduce, dim3(grid_of(d, max_g[l])), dim3(BLOCK), 0, s, lv.buf[l - 1], segoff + (size_t)(l - 1) * so_stride,
-                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax + (l - 1));
+                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax + (l - 1), red.skip);
     lv.buf[l] = r;
   }
-  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, lv, segoff, lvlmax, W, nb, bkt);
+  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, lv, segoff, lvlmax, red.skip, W, nb, bkt);
   const uint32_t* cur_in;
   if (tree) {
     uint32_t *nodes = (uint32_t*)(m + o_nodes), *sums = (uint32_t*)(m + o_sums);
