@@ -816,18 +816,19 @@ k_msm_combine(SqrtTables T, const uint64_t* xyzt, size_t m, uint8_t* enc_out, ui
 // ------------------------------------------------------------------------------ host side ---
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Window width.  Only widths that tile the 252 scalar bits exactly are used (4, 6, 7, 9, 12, 14):
+// Window width.  Only widths that tile the 252 scalar bits exactly are chosen (12, 14; the override also takes others):
 // then the top window is as wide as the others and, because scalars are < r < 2^251, its unsigned
 // digits spread over the same 2^(c-1) buckets as the signed digits of the other windows.  A ragged
 // top window (e.g. c = 16: 11 significant bits) would pile n / 2^11 points on each of a few
 // buckets and leave single lanes summing runs 16 times longer than everyone else's.
 int pick_window(size_t n) {
-  int lg = 0;
-  while (((size_t)1 << (lg + 1)) <= n && lg < 40) ++lg;     // floor(log2 n), 0 for n <= 1
-  static const int widths[6] = {4, 6, 7, 9, 12, 14};
-  int c = 4;
-  for (int k = 0; k < 6; ++k)
-    if (widths[k] <= lg - 4) c = widths[k];
+  // Measured on one MI355X (D377_MSM_WINDOW sweep, Elements, whole call), 4 / 6 / 7 / 9 / 12 bits: 2^8 points 608 / 551 /
+  // 556 / 543 / 544 us, 2^12: 657 / 607 / 599 / 578 / 577, 2^14: 739 / 683 / 671 / 622 / 587, 2^16: 1020 / 866 / 803 / 745 /
+  // 686; 12 against 14 bits: 2^18 977 / 1007, 2^19 1310 / 1331, 2^20 2055 / 1985 us.  Since the bucket sums are a tree of
+  // bit-sums (two kernels whose depth is the window width) a wide window costs little even when most of its buckets are
+  // empty, and fewer windows are fewer additions per point and fewer chains side by side (the Horner doublings are 252
+  // either way).  So: 12 bits below 2^20 points, 14 from there.
+  int c = n >= ((size_t)1 << 20) ? 14 : 12;
   const char* env = getenv("D377_MSM_WINDOW");                // developer override for tests
   if (env) { int v = atoi(env); if (v >= 4 && v <= 16) c = v; }   // >= 4: at most 63 windows (k_msm_final's table of cached sums)
   return c;
