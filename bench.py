@@ -120,7 +120,14 @@ def self_launch(args):
         th = threading.Thread(target=drain, daemon=True)
         th.start()
         live = set(range(args.gpus))
+        deadline = time.time() + float(os.environ.get("D377_BENCH_LAUNCH_TIMEOUT_S", "3600"))
         while live:
+            if time.time() > deadline:
+                sys.stderr.write("bench.py: ranks still running after the launch timeout; stopping them\n")
+                rc = rc or 124
+                for o in live:
+                    procs[o].kill()
+                break
             for r in list(live):
                 c = procs[r].poll()
                 if c is not None:

@@ -14,4 +14,6 @@ grep -v "^pass\|amdgpu.ids" "$F/pmc_ops_2^20.txt" > "profiles/${R}_pmc_ops_2^20.
 cp $F/multigpu_selftest.txt profiles/${R}_multigpu_selftest_1gpu.txt
 grep -v "amdgpu.ids" $F/msm_skew.txt > profiles/${R}_msm_skew.txt
 grep -v "amdgpu.ids" $F/soak.txt > profiles/${R}_soak.txt
+grep -v "amdgpu.ids" $F/host_path.txt > profiles/${R}_host_path.txt
+grep -v "amdgpu.ids" $F/hbm_priced_ops.txt > profiles/${R}_hbm_priced_ops.txt
 tools/resource_usage.sh > profiles/${R}_resource_usage.txt 2>/dev/null

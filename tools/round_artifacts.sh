@@ -22,6 +22,8 @@ echo "pmc ops done"
 timeout 900 python3 tools/multigpu_selftest.py --log2n 14 > "$out/multigpu_selftest.txt" 2>&1
 echo "selftest: $(tail -1 "$out/multigpu_selftest.txt")"
 timeout 600 python3 tools/msm_skew_bench.py > "$out/msm_skew.txt" 2>&1
+timeout 600 python3 tools/host_path_bench.py > "$out/host_path.txt" 2>&1
+timeout 600 python3 tools/hbm_ops_bench.py 22 > "$out/hbm_priced_ops.txt" 2>&1
 timeout 900 python3 tools/soak.py 22 3 > "$out/soak.txt" 2>&1
 echo "soak: $(grep -c bit-exact "$out/soak.txt") bit-exact, $(grep -c MISMATCH "$out/soak.txt") mismatches"
 rm -rf "$out/msmtrace" "$out"/pmc/pmc[0-9] "$out"/pmc/stats "$out"/pmc_ops20/pmc[0-9]
