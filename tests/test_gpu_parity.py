@@ -1284,6 +1284,33 @@ def test_bench_modes_and_rccl_single_rank():
     assert line["collective_ms"] > 0
 
 
+def test_bench_line_contract():
+    """The one JSON line of `python bench.py` (N = 1, small size so that the CPU baseline leg is short): every key of the
+    driver's contract, the `roofline` and `cpu_baseline` objects, this round's `ranks_seen` / `parity_sample_ok`, and a
+    `roofline_valu` for every extra that is one of BASELINE.json's configurations."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log2n", "16"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d_ = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "ranks_seen", "parity_sample_ok", "extra", "roofline_valu"):
+        assert k in d_, k
+    assert d_["n_gpus"] == 1 and d_["steps"] == 2 and d_["higher_is_better"] is True and d_["vs_baseline"] is None
+    assert d_["dtype"] == "u32" and d_["data"] == "synthetic" and "workload" in d_["config"] and "model" not in d_["config"]
+    assert d_["ranks_seen"] == 1 and d_["parity_sample_ok"] is True
+    rf = d_["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    cb = d_["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["matches_gpu_output"] is True and "sample" in cb
+    for name in ("roundtrip", "scalar_mul_base", "encode_to_curve", "sqrt_ratio_zeta", "decompress", "compress", "hash_to_curve"):
+        assert 0 < d_["extra"][name]["roofline_valu"]["frac"] < 1, name
+    assert abs(d_["value"] - (1 << 16) * 2 / (d_["ms_per_step"] * 2e-3)) / d_["value"] < 1e-6
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with NO launcher: the parent starts the two ranks itself before anything touches the
     GPU and relays rank 0's line.  Both ranks share GPU 0 and rendezvous over gloo (this box has one GPU); on a node
