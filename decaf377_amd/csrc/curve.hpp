@@ -752,6 +752,27 @@ D377_HD int fr_digit(const uint32_t digits[8], int i) {   // signed value of nib
 // X3 = E'F', Y3 = G'H', Z3 = F'G', T3 = E'H').
 struct gec { fe ypx, ymx, z2, kt; };      // cached extended point
 
+// ---- per-lane arithmetic of the four-lane group operations (quad_ops.hpp) -------------------------
+// Between its two rounds of products a lane of the quad forms ONE linear combination of the round-one products -- the
+// value its role contributes to round two -- and the second round's operands are quad permutations of those values (no
+// lane computes what another lane uses).  The arithmetic lives here, host-compilable, so that the bounds build walks
+// it (tests/host_sim: sim_quad_forms); the cross-lane moves are quad_ops.hpp's.
+// doubling: role 0: G' = A - B, 1: H' = A + B, 2: F' = A - B + C, 3: E.   u = (A, A, A, E), v = (B, B, B, *), c = (*, *, C, *)
+D377_HD fe gq_double_own(int role, const fe& u, const fe& v, const fe& c) {
+  const fe t2 = fe_select(role == 3, fe_zero(), fe_select(role == 1, v, fe_neg_nc(v)));
+  const fe t3 = fe_select(role == 2, c, fe_zero());
+  return fe_carry(fe_add(fe_add(u, t2), t3));
+}
+// addition, first round's own operand: role 0: Y - X, 1: Y + X, 2: T, 3: 2Z.   u = (Y, Y, T, Z), v = (X, X, *, Z)
+D377_HD fe gq_add_in_own(int role, const fe& u, const fe& v) {
+  const fe t2 = fe_select(role == 2, fe_zero(), fe_select(role == 0, fe_neg_nc(v), v));
+  return fe_carry(fe_add(u, t2));
+}
+// addition, between the rounds: u - v or u + v.   role 0: E = b - a, 1: H = b + a, 2: F = d -+ c, 3: G = d +- c
+D377_HD fe gq_add_own(bool sub, const fe& u, const fe& v) { return fe_carry(fe_add(u, fe_select(sub, fe_neg_nc(v), v))); }
+
+
+
 D377_HD ge ge_double_fast(const ge& p, bool with_t) {
   fe a = fe_sqr(p.x), b = fe_sqr(p.y);
   fe c = fe_sqr2x(p.z);                   // 2 Z^2 for the price of Z^2

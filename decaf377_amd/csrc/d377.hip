@@ -472,6 +472,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtT
 // per SIMD (launch(): small_max), where the other lanes would have idled anyway.
 constexpr int SMALL_THREADS = 64;                              // one wave per workgroup, 16 elements
 constexpr int SMALL_QUADS = SMALL_THREADS / 4;
+static_assert(GQ_TAB_ENTRIES == VB_ENTRIES, "the quad chain's table is the per-lane chain's: 0 .. 8 times P");
 struct OneDcbIO {                                              // the square-root-free compressor's records for a single element
   uint32_t st[4][8], parked_[8], out[8];
   __device__ __forceinline__ void put(int s, int, const uint32_t* w) { for (int k = 0; k < 8; ++k) st[s][k] = w[k]; }
@@ -511,33 +512,7 @@ k_scalar_mul_var_small(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar
       fr_half_words(k);                                        // [k]P = [2]([k/2 mod r]P): the encoding of a double needs no square root
     }
     fr_recode_signed16(k, dg);
-    // table: entry j = the cached slots of [j]P, each lane the slot it will multiply by
-    const fe id_slot = fe_pick(role, fe_const(FE_ONE), fe_const(FE_ONE), fe_zero(), fe_const(FE_ONE));
-    const fe v1 = gq_from_ge(g, role);
-    const fe s1 = gq_cached_slot(v1, role);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) { qtab[role * NL + i] = id_slot.l[i]; qtab[GQ_WORDS + role * NL + i] = s1.l[i]; }
-    __syncthreads();
-    fe acc = v1;
-#pragma unroll 1
-    for (int j = 2; j < VB_ENTRIES; ++j) {
-      acc = gq_add(acc, qtab + GQ_WORDS, role, false);         // [j]P = [j-1]P + P (the unified addition also doubles)
-      const fe sj = gq_cached_slot(acc, role);
-#pragma unroll
-      for (int i = 0; i < NL; ++i) qtab[j * GQ_WORDS + role * NL + i] = sj.l[i];
-    }
-    __syncthreads();
-    // signed 4-bit windows, most significant first: 63 x (4 doublings, 1 addition); four sign-folded doublings keep the sign
-    int d = fr_digit(dg, 63);                                  // 0 or 1
-    fe v = fe_select(d != 0, v1, gq_from_ge(ge_identity(), role));
-#pragma unroll 1
-    for (int i = 62; i >= 0; --i) {
-#pragma unroll 1
-      for (int j = 0; j < 4; ++j) v = gq_double_neg(v, role);
-      d = fr_digit(dg, i);
-      const bool neg = d < 0;
-      v = gq_add(v, qtab + (neg ? -d : d) * GQ_WORDS, role, neg);
-    }
+    const fe v = gq_scalar_mul_w4(gq_from_ge(g, role), dg, qtab, role);
     const ge r = gq_to_ge(v);
     D377_INVARIANT(T, r, bad == 0);
     if (ELEMENT) {

@@ -752,15 +752,40 @@ k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, uint32_t* sums)
   if (t == 0) pt_store_ext(sums + (size_t)w * PT_WORDS, r);
 }
 
+// The square-root power table of a 64-thread workgroup, one LDS column per lane
+struct Pow64 {
+  uint32_t* col;
+  __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
+  __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
+};
+// the square-root-free compressor's records for a single element
+struct OneIO {
+  uint32_t st[4][8], parked_[8], out[8];
+  __device__ __forceinline__ void put(int s, int, const uint32_t* w) { for (int k = 0; k < 8; ++k) st[s][k] = w[k]; }
+  __device__ __forceinline__ void get(int s, int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = st[s][k]; }
+  __device__ __forceinline__ void park(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) parked_[k] = w[k]; }
+  __device__ __forceinline__ void parked(int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = parked_[k]; }
+  __device__ __forceinline__ void emit(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) out[k] = w[k]; }
+};
+// r = sum (k_i / 2) P_i: the result is its double, whose encoding needs no square root (curve.hpp, "compression
+// without a square root") -- one element, so the inversion is not shared, but a divsteps inversion (~26 000
+// instructions) is still well under the ~67 000 of a square root on this one dependent chain.  Every lane of the
+// wave runs it; `first` writes.
+__device__ __forceinline__ void msm_emit_doubled(Pow64& pt, const ge& r, bool first, uint8_t* enc_out, uint64_t* xyzt_out) {
+  OneIO io;
+  dcb_put(io, 0, ge_dcb_from_half(r, false));
+  dcb_finish(pt, io, 1);
+  if (first) {
+    if (xyzt_out) store_ge_mont256(xyzt_out, 0, ge_double(r));
+    store32(enc_out, 0, io.out);
+  }
+}
+
 // Horner over the window sums S_w (lanes 0-3 of one wave), result as Element record and as encoding
 __global__ void __launch_bounds__(64, 1)
 k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, uint64_t* xyzt_out) {
   __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
-  struct Pow64 {                                   // the square-root power table, 64 columns
-    uint32_t* col;
-    __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
-    __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
-  } pt;
+  Pow64 pt;
   pt.col = lds_pow_ + threadIdx.x;
   if (blockIdx.x != 0) return;
   // cached forms of the window sums, one lane each (W <= 63), then the chain on every group of four lanes alike
@@ -779,24 +804,101 @@ k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, 
   }
   ge r = gq_to_ge(v);
   if (negated) r = ge_neg(r);
-  // r = sum (k_i / 2) P_i: the result is its double, whose encoding needs no square root (curve.hpp, "compression
-  // without a square root") -- one element, so the inversion is not shared, but a divsteps inversion (~26 000
-  // instructions) is still well under the ~67 000 of a square root on this one dependent chain
   (void)T;
-  struct OneIO {
-    uint32_t st[4][8], parked_[8], out[8];
-    __device__ __forceinline__ void put(int s, int, const uint32_t* w) { for (int k = 0; k < 8; ++k) st[s][k] = w[k]; }
-    __device__ __forceinline__ void get(int s, int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = st[s][k]; }
-    __device__ __forceinline__ void park(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) parked_[k] = w[k]; }
-    __device__ __forceinline__ void parked(int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = parked_[k]; }
-    __device__ __forceinline__ void emit(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) out[k] = w[k]; }
-  } io;
-  dcb_put(io, 0, ge_dcb_from_half(r, false));
-  dcb_finish(pt, io, 1);
-  if (threadIdx.x == 0) {
-    if (xyzt_out) store_ge_mont256(xyzt_out, 0, ge_double(r));
-    store32(enc_out, 0, io.out);
+  msm_emit_doubled(pt, r, threadIdx.x == 0, enc_out, xyzt_out);
+}
+
+// ---- small batches: no buckets -------------------------------------------------------------------------------------
+// Up to one quad of lanes per point and one wave per SIMD (n <= 4 x 16 x the CUs: 16384 on an MI355X) the bucket
+// method has nothing to share: its kernels wait on their own dependency chains (the tree of bit-sums, the Horner chains
+// of the windows, the 252 doublings of the tail: 0.55 ms whatever n) while most of the chip idles.  Here every quad
+// computes [k_i / 2]P_i by itself -- the same 252 doublings, all points at once -- the 16 quads of a wave add their
+// results up, and a second kernel sums the waves' partial results and encodes the double.  (Straus' interleaving would
+// share the doublings between the points of a quad, which saves work and no time while every point has a quad.)
+constexpr int MS_THREADS = 64, MS_QUADS = MS_THREADS / 4;      // k_msm_small: one wave per workgroup
+constexpr int MSS_THREADS = 512, MSS_QUADS = MSS_THREADS / 4;  // k_msm_small_sum: one workgroup
+
+__device__ __forceinline__ void gq_publish_slot(uint32_t* rec, const fe& v, int role) {
+  const fe sl = gq_cached_slot(v, role);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) rec[role * NL + i] = sl.l[i];
+}
+
+template <bool ENCODED>
+__global__ void __launch_bounds__(MS_THREADS)
+k_msm_small(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, uint32_t* partial, uint8_t* status) {
+  __shared__ uint32_t lds_pow_[ENCODED ? POW_TAB * NL * MS_THREADS : 1];
+  __shared__ uint32_t tab[MS_QUADS * GQ_TAB_ENTRIES * GQ_WORDS];
+  Pow64 pt;
+  pt.col = lds_pow_ + threadIdx.x;
+  const int role = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  const size_t e0 = (size_t)blockIdx.x * MS_QUADS + quad;
+  const bool active = e0 < n;
+  const size_t e = active ? e0 : n - 1;                          // idle quads redo the last point and contribute nothing
+  uint32_t k[8], dg[8];
+  load32(scalar32, e, k);
+  fr_reduce_words(k);
+  fr_half_words(k);                                              // the sum is formed with k/2 mod r and doubled at the end
+  fr_recode_signed16(k, dg);
+  ge g;
+  bool skip = !active;
+  if (ENCODED) {
+    uint32_t w[8];
+    load32(reinterpret_cast<const uint8_t*>(pts_in), e, w);
+    const uint32_t bad = ge_decompress(T, pt, w, &g);            // every lane of the quad: the same chain of squarings
+    if (active && role == 0) status[e] = (uint8_t)bad;
+    skip |= bad != 0;                                            // invalid points contribute nothing
+  } else {
+    g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), e);
+    skip |= fe_is_zero(g.z);                                     // a record with z = 0 is no group element
   }
+  const fe id = gq_from_ge(ge_identity(), role);
+  fe v = gq_scalar_mul_w4(gq_from_ge(g, role), dg, tab + quad * GQ_TAB_ENTRIES * GQ_WORDS, role);
+  v = fe_select(skip, id, v);
+  __syncthreads();                                               // the tables are done with: their area carries the exchange
+  // sum over the 16 quads: after the step of width s, quad q holds the sum of quads q .. q + 2s - 1 (cyclically)
+#pragma unroll 1
+  for (int step = 1; step < MS_QUADS; step <<= 1) {
+    gq_publish_slot(tab + quad * GQ_WORDS, v, role);
+    __syncthreads();
+    v = gq_add(v, tab + ((quad + step) & (MS_QUADS - 1)) * GQ_WORDS, role, false);
+    __syncthreads();
+  }
+  if (quad == 0) slot_store(partial + (size_t)blockIdx.x * PT_WORDS + role * SLOT, v);   // X, Y, Z, T: pt_store_ext's layout
+}
+
+// the sum of the m partial results (one quad per MSS_QUADS of them, then a tree over the quads) and its encoding
+__global__ void __launch_bounds__(MSS_THREADS)
+k_msm_small_sum(SqrtTables T, const uint32_t* partial, int m, uint8_t* enc_out, uint64_t* xyzt_out) {
+  __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
+  __shared__ uint32_t xrec[MSS_QUADS * GQ_WORDS];
+  const int role = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  const fe id = gq_from_ge(ge_identity(), role);
+  fe v = quad < m ? slot_load(partial + (size_t)quad * PT_WORDS + role * SLOT) : id;
+#pragma unroll 1
+  for (int base = MSS_QUADS; base < m; base += MSS_QUADS) {
+    const int j = base + quad;
+    const fe u = j < m ? slot_load(partial + (size_t)j * PT_WORDS + role * SLOT) : id;
+    gq_publish_slot(xrec + quad * GQ_WORDS, u, role);
+    __syncthreads();
+    v = gq_add(v, xrec + quad * GQ_WORDS, role, false);
+    __syncthreads();
+  }
+  // quad 0 gathers: after the step of width s it holds the sum of quads 0 .. 2s - 1 (quads past m hold the identity;
+  // what quads near the end pick up from the wrapped index never reaches quad 0)
+  const int live = m < MSS_QUADS ? m : MSS_QUADS;
+#pragma unroll 1
+  for (int step = 1; step < live; step <<= 1) {
+    gq_publish_slot(xrec + quad * GQ_WORDS, v, role);
+    __syncthreads();
+    v = gq_add(v, xrec + ((quad + step) & (MSS_QUADS - 1)) * GQ_WORDS, role, false);
+    __syncthreads();
+  }
+  if (threadIdx.x >= 64) return;                                 // wave 0 encodes (no barrier from here on)
+  Pow64 pt;
+  pt.col = lds_pow_ + threadIdx.x;
+  (void)T;
+  msm_emit_doubled(pt, gq_to_ge(v), threadIdx.x == 0, enc_out, xyzt_out);   // lanes 0-3 hold the total
 }
 
 // sum of m Element records (partial results of several GPUs / ranks), one lane
@@ -854,10 +956,57 @@ int grid_of(const DeviceState& d, size_t n) {
   return (int)blocks;
 }
 
+// The workspace: grown when a call needs more (never inside a stream capture), handed from stream to stream by its guard.
+// `held` releases it on every path out of the caller, error or not.
+struct MsmHeld {
+  ScratchGuard& g; hipStream_t s; bool held;
+  ~MsmHeld() { if (held) (void)g.release(s); }
+};
+int msm_reserve(DeviceState& d, hipStream_t s, size_t bytes, MsmHeld& held) {
+  int rc;
+  if (bytes > d.msm.cap) {
+    if (ScratchGuard::capturing(s))
+      return fail(D377_ERR_ARG, "%s", "msm: the workspace must grow, which cannot happen inside a stream capture -- run one MSM of this size before capturing");
+    if ((rc = d.msm.guard.drain())) return rc;          // a launch on another stream may still be using the old area
+    if (d.msm.mem) {
+      if (d.msm.guard.seen_capture) d.msm.retired.push_back(d.msm.mem);   // a captured graph may still point into it
+      else HIP_TRY(hipFree(d.msm.mem));
+    }
+    d.msm.mem = nullptr; d.msm.cap = 0;
+    HIP_TRY(hipMalloc(&d.msm.mem, bytes + bytes / 8));
+    d.msm.cap = bytes + bytes / 8;
+  }
+  if ((rc = d.msm.guard.acquire(s))) return rc;         // one workspace per device: queue behind its last user
+  held.held = true;
+  return D377_OK;
+}
+
+// Batches up to this many points skip the buckets (k_msm_small).  D377_MSM_SMALL_MAX: developer override (0 = never).
+size_t msm_small_max(const DeviceState& d) {
+  if (const char* e = getenv("D377_MSM_SMALL_MAX")) return (size_t)strtoull(e, nullptr, 10);
+  return (size_t)d.cus * 4 * MS_QUADS;
+}
+
+int msm_launch_small(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,
+                     uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
+  const size_t m = (n + MS_QUADS - 1) / MS_QUADS;
+  MsmHeld held{d.msm.guard, s, false};
+  int rc;
+  if ((rc = msm_reserve(d, s, m * PT_WORDS * 4, held))) return rc;
+  uint32_t* partial = (uint32_t*)d.msm.mem;
+  const SqrtTables T = d.tables();
+  if (encoded) hipLaunchKernelGGL(k_msm_small<true>, dim3((unsigned)m), dim3(MS_THREADS), 0, s, T, pts_in, scalars, n, partial, status);
+  else hipLaunchKernelGGL(k_msm_small<false>, dim3((unsigned)m), dim3(MS_THREADS), 0, s, T, pts_in, scalars, n, partial, status);
+  hipLaunchKernelGGL(k_msm_small_sum, dim3(1), dim3(MSS_THREADS), 0, s, T, partial, (int)m, enc_out, xyzt_out);
+  HIP_TRY(hipGetLastError());
+  return D377_OK;
+}
+
 // everything on device pointers, enqueued on `s`
 int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,
                uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
   if (n >= ((size_t)1 << 31)) return fail(D377_ERR_ARG, "%s", "msm: n must be below 2^31");
+  if (n && n <= msm_small_max(d) && n < ((size_t)1 << 24)) return msm_launch_small(d, s, encoded, pts_in, scalars, n, enc_out, xyzt_out, status);
   const int c = pick_window(n);
   const int W = (252 + c - 1) / c;
   const int nb = (1 << (c - 1)) + 1;                         // bucket indices 0 .. 2^(c-1)
@@ -916,24 +1065,8 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_nodes = carve(tree ? (size_t)W * ws_nblk * (WS_M + 1) * PT_WORDS * 4 : 0);
   const size_t o_sums = carve((size_t)W * PT_WORDS * 4);
   int rc;
-  if (off > d.msm.cap) {
-    if (ScratchGuard::capturing(s))
-      return fail(D377_ERR_ARG, "%s", "msm: the workspace must grow, which cannot happen inside a stream capture -- run one MSM of this size before capturing");
-    if ((rc = d.msm.guard.drain())) return rc;          // a launch on another stream may still be using the old area
-    if (d.msm.mem) {
-      if (d.msm.guard.seen_capture) d.msm.retired.push_back(d.msm.mem);   // a captured graph may still point into it
-      else HIP_TRY(hipFree(d.msm.mem));
-    }
-    d.msm.mem = nullptr; d.msm.cap = 0;
-    HIP_TRY(hipMalloc(&d.msm.mem, off + off / 8));
-    d.msm.cap = off + off / 8;
-  }
-  struct Held {                                          // hand-over event on every path out, error or not
-    ScratchGuard& g; hipStream_t s; bool held;
-    ~Held() { if (held) (void)g.release(s); }
-  } held{d.msm.guard, s, false};
-  if ((rc = d.msm.guard.acquire(s))) return rc;         // one workspace per device: queue behind its last user
-  held.held = true;
+  MsmHeld held{d.msm.guard, s, false};
+  if ((rc = msm_reserve(d, s, off, held))) return rc;
   uint8_t* m = d.msm.mem;
   uint32_t* pts = (uint32_t*)(m + o_pts);
   int16_t* dig = (int16_t*)(m + o_dig);

@@ -14,7 +14,8 @@ namespace d377 {
 // on different operands, no divergence.  The point lives DISTRIBUTED over the quad: lane r holds coordinate r (X, Y, Z,
 // T), which is exactly what lane r's second product produces, and a round's operands are fetched with DPP quad_perm
 // moves (one VALU instruction per limb, no LDS round trip).  (Round 2 kept the whole point in every lane and picked
-// operands with selects: ~660 instructions per doubling, 392 of them the two products; this form is ~540.)
+// operands with selects: ~660 instructions per doubling, 392 of them the two products; this form is ~545, and an
+// addition ~670.)
 // The other operand of an addition comes from memory in CACHED form -- (Y-X, Y+X, 2dT, Z), made once per point, in
 // parallel, before the chain starts -- so lane r just loads the slot it multiplies by; subtracting a point swaps two
 // slots and two sums, which is how the chains absorb the sign of the sign-folded doubling (-[2]P, curve.hpp
@@ -24,7 +25,7 @@ __device__ __forceinline__ fe fe_quad_perm(const fe& v) {       // lane r of eve
   fe r;
 #pragma unroll
   for (int i = 0; i < NL; ++i)
-    r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, false);
+    r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true);
   // Keep the moves as moves: hipcc's DPP combiner folds them into the additions and subtractions that consume them
   // (v_add_u32_dpp / v_subrev_u32_dpp whose destination is also their second source), and some of those folded
   // subtractions came back computed on the lane's OWN value instead of the permuted one (measured: limbs 0 and 1 of
@@ -42,7 +43,7 @@ __device__ __forceinline__ fe fe_pick(int role, const fe& a, const fe& b, const 
   }
   return r;
 }
-// -[2]P (same formulas and operand forms as ge_double_neg, whose bounds the host build checks)
+// -[2]P (the formulas of ge_double_neg; a lane forms only the value it contributes to the second round: curve.hpp gq_double_own)
 __device__ __forceinline__ fe gq_double_neg(const fe& v, int role) {
   const fe opa = fe_quad_perm<0, 1, 2, 0>(v);                   // X, Y, Z, X
   fe opb = fe_quad_perm<0, 1, 2, 1>(v);                         // X, Y, 2Z, 2Y
@@ -50,11 +51,8 @@ __device__ __forceinline__ fe gq_double_neg(const fe& v, int role) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) opb.l[i] <<= sh;
   const fe m1 = fe_mul(opa, opb);                               // A = X^2, B = Y^2, C = 2Z^2, E = 2XY
-  const fe a = fe_quad_perm<0, 0, 0, 0>(m1), b = fe_quad_perm<1, 1, 1, 1>(m1);
-  const fe h = fe_add(a, b), g = fe_sub(a, b);                  // H' = A + B (lazy), G' = A - B (carried)
-  const fe f = fe_add(g, fe_quad_perm<2, 2, 2, 2>(m1));         // F' = G' + C (lazy)
-  const fe e = fe_quad_perm<3, 3, 3, 3>(m1);
-  return fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));   // E F', G' H', F' G', E H'
+  const fe w = gq_double_own(role, fe_quad_perm<0, 0, 0, 3>(m1), fe_quad_perm<1, 1, 1, 1>(m1), fe_quad_perm<2, 2, 2, 2>(m1));   // G', H', F', E
+  return fe_mul(fe_quad_perm<3, 0, 2, 3>(w), fe_quad_perm<2, 1, 0, 1>(w));   // E F', G' H', F' G', E H'
 }
 // A point of a chain's other operands in cached form, four 9-word slots in LDS: slot 0 Y-X, 1 Y+X (both carried), 2 2dT, 3 Z
 constexpr int GQ_WORDS = 4 * NL;
@@ -66,20 +64,16 @@ __device__ __forceinline__ void gq_store_cached(uint32_t* rec, const ge& p) {
 // P + Q, or P - Q with neg_q (wave-uniform): src/min_curve/element.rs:291-322 with Q cached, as ge_add_cached
 __device__ __forceinline__ fe gq_add(const fe& v, const uint32_t* qrec, int role, bool neg_q) {
   // lane 0: (Yp - Xp)(Yq - Xq), lane 1: (Yp + Xp)(Yq + Xq), lane 2: Tp * 2dTq, lane 3: 2Zp * Zq
-  const fe x = fe_quad_perm<0, 0, 3, 2>(v);                     // X, X, T, Z
-  const fe y = fe_quad_perm<1, 1, 1, 1>(v);
-  const fe opa = fe_pick(role, fe_sub(y, x), fe_add(y, x), x, fe_add(x, x));
+  const fe opa = gq_add_in_own(role, fe_quad_perm<1, 1, 3, 2>(v), fe_quad_perm<0, 0, 3, 2>(v));
   const int slot = (role < 2 && neg_q) ? (role ^ 1) : role;     // -Q: Y-X and Y+X change places
   fe opb;
 #pragma unroll
   for (int i = 0; i < NL; ++i) opb.l[i] = qrec[slot * NL + i];
   const fe m1 = fe_mul(opa, opb);                               // a, b, c, d
-  const fe a = fe_quad_perm<0, 0, 0, 0>(m1), b = fe_quad_perm<1, 1, 1, 1>(m1);
-  const fe c = fe_quad_perm<2, 2, 2, 2>(m1), d = fe_quad_perm<3, 3, 3, 3>(m1);
-  const fe e = fe_sub(b, a), h = fe_add(b, a);
-  const fe dmc = fe_sub(d, c), dpc = fe_carry(fe_add(d, c));
-  const fe f = fe_select(neg_q, dpc, dmc), g = fe_select(neg_q, dmc, dpc);      // the sign of 2dT: F and G change places
-  return fe_mul(fe_pick(role, e, g, f, e), fe_pick(role, f, h, g, h));   // E F, G H, F G, E H
+  // E = b - a, H = b + a, F = d - c, G = d + c; the sign of 2dT (-Q) makes F and G change places
+  const bool sub = (role == 0) | ((role >= 2) & ((role == 2) != neg_q));   // (bitwise: no branches on a lane's role)
+  const fe w = gq_add_own(sub, fe_quad_perm<1, 1, 3, 3>(m1), fe_quad_perm<0, 0, 2, 2>(m1));   // E, H, F, G
+  return fe_mul(fe_quad_perm<0, 3, 2, 0>(w), fe_quad_perm<2, 1, 3, 1>(w));   // E F, G H, F G, E H
 }
 // a whole point (every lane the same copy) -> its distributed form, and back
 __device__ __forceinline__ fe gq_from_ge(const ge& p, int role) { return fe_pick(role, p.x, p.y, p.z, p.t); }
@@ -96,6 +90,39 @@ __device__ __forceinline__ fe gq_cached_slot(const fe& v, int role) {
   const fe x = fe_quad_perm<0, 0, 3, 2>(v);                     // X, X, T, Z
   const fe y = fe_quad_perm<1, 1, 1, 1>(v);
   return fe_pick(role, fe_sub(y, x), fe_carry(fe_add(y, x)), fe_mul(fe_const(FE_K), x), x);
+}
+
+// [k]P on a quad: signed 4-bit windows (fr_recode_signed16), most significant first -- 63 x (4 sign-folded doublings,
+// 1 addition) over a table of the cached slots of 0 .. 8 times P, GQ_TAB_ENTRIES x GQ_WORDS words of LDS that belong to
+// this quad.  `v1` is P in distributed form; every thread of the workgroup calls this together (two barriers).
+constexpr int GQ_TAB_ENTRIES = 9;
+__device__ __forceinline__ fe gq_scalar_mul_w4(const fe& v1, const uint32_t dg[8], uint32_t* qtab, int role) {
+  // table: entry j = the cached slots of [j]P, each lane the slot it will multiply by
+  const fe id_slot = fe_pick(role, fe_const(FE_ONE), fe_const(FE_ONE), fe_zero(), fe_const(FE_ONE));
+  const fe s1 = gq_cached_slot(v1, role);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { qtab[role * NL + i] = id_slot.l[i]; qtab[GQ_WORDS + role * NL + i] = s1.l[i]; }
+  __syncthreads();
+  fe acc = v1;
+#pragma unroll 1
+  for (int j = 2; j < GQ_TAB_ENTRIES; ++j) {
+    acc = gq_add(acc, qtab + GQ_WORDS, role, false);           // [j]P = [j-1]P + P (the unified addition also doubles)
+    const fe sj = gq_cached_slot(acc, role);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) qtab[j * GQ_WORDS + role * NL + i] = sj.l[i];
+  }
+  __syncthreads();
+  int d = fr_digit(dg, 63);                                    // 0 or 1
+  fe v = fe_select(d != 0, v1, gq_from_ge(ge_identity(), role));
+#pragma unroll 1
+  for (int i = 62; i >= 0; --i) {
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) v = gq_double_neg(v, role);    // four sign-folded doublings keep the sign
+    d = fr_digit(dg, i);
+    const bool neg = d < 0;
+    v = gq_add(v, qtab + (neg ? -d : d) * GQ_WORDS, role, neg);
+  }
+  return v;
 }
 
 }  // namespace d377

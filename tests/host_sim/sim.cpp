@@ -66,6 +66,45 @@ static void dcb_rounds(size_t n, uint32_t* out, bool finish, P0 phase0, P1 phase
   }
 }
 
+// The four-lane group operations (quad_ops.hpp) with the lanes emulated: a quad is an array of four values, a DPP
+// quad_perm an index permutation; the per-lane arithmetic is the device's own (curve.hpp gq_*_own), so the bounds build
+// proves the operand bounds of both rounds of products, chained (products feed the next operation).
+namespace {
+struct Quad { fe l[4]; };
+template <int P0, int P1, int P2, int P3> Quad qperm(const Quad& v) { return Quad{{v.l[P0], v.l[P1], v.l[P2], v.l[P3]}}; }
+Quad q_double_neg(const Quad& v) {
+  const Quad opa = qperm<0, 1, 2, 0>(v);
+  Quad opb = qperm<0, 1, 2, 1>(v), m1, w, r;
+  for (int role = 2; role < 4; ++role) opb.l[role] = fe_dbl(opb.l[role]);
+  for (int role = 0; role < 4; ++role) m1.l[role] = fe_mul(opa.l[role], opb.l[role]);
+  const Quad u = qperm<0, 0, 0, 3>(m1), b = qperm<1, 1, 1, 1>(m1), c = qperm<2, 2, 2, 2>(m1);
+  for (int role = 0; role < 4; ++role) w.l[role] = gq_double_own(role, u.l[role], b.l[role], c.l[role]);
+  const Quad oa = qperm<3, 0, 2, 3>(w), ob = qperm<2, 1, 0, 1>(w);
+  for (int role = 0; role < 4; ++role) r.l[role] = fe_mul(oa.l[role], ob.l[role]);
+  return r;
+}
+Quad q_cached(const ge& p) {                                 // gq_store_cached's record: Y-X, Y+X (both carried), 2dT, Z
+  return Quad{{fe_sub(p.y, p.x), fe_carry(fe_add(p.y, p.x)), fe_mul(fe_const(FE_K), p.t), p.z}};
+}
+Quad q_add(const Quad& v, const Quad& qrec, bool neg_q) {
+  const Quad u0 = qperm<1, 1, 3, 2>(v), v0 = qperm<0, 0, 3, 2>(v);
+  Quad m1, w, r;
+  for (int role = 0; role < 4; ++role) {
+    const int slot = (role < 2 && neg_q) ? (role ^ 1) : role;
+    m1.l[role] = fe_mul(gq_add_in_own(role, u0.l[role], v0.l[role]), qrec.l[slot]);
+  }
+  const Quad u = qperm<1, 1, 3, 3>(m1), b = qperm<0, 0, 2, 2>(m1);
+  for (int role = 0; role < 4; ++role) {
+    const bool sub = role == 0 || (role >= 2 && ((role == 2) != neg_q));
+    w.l[role] = gq_add_own(sub, u.l[role], b.l[role]);
+  }
+  const Quad oa = qperm<0, 3, 2, 0>(w), ob = qperm<2, 1, 3, 1>(w);
+  for (int role = 0; role < 4; ++role) r.l[role] = fe_mul(oa.l[role], ob.l[role]);
+  return r;
+}
+ge q_to_ge(const Quad& v) { ge g; g.x = v.l[0]; g.y = v.l[1]; g.z = v.l[2]; g.t = v.l[3]; return g; }
+}  // namespace
+
 extern "C" {
 int sim_init() {
   // same construction the init kernels perform on the device
@@ -192,6 +231,21 @@ void sim_double_variants(const uint32_t* xyzt, size_t n, uint32_t* ref, uint32_t
     ge_store256(ge_double(g), ref + 32 * i);
     ge_store256(ge_double_fast(g, true), fast + 32 * i);
     ge_store256(ge_double_neg(g, true), negd + 32 * i);      // -[2]P
+  }
+}
+// dbl4 = [4]P (two sign-folded doublings), sum = [4]P + Q, diff = [4]P - Q, chain = [2]([4]P + Q) - Q on the four-lane forms
+void sim_quad_forms(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* dbl4, uint32_t* sum, uint32_t* diff, uint32_t* chain) {
+  for (size_t i = 0; i < n; ++i) {
+    const ge a = ge_load256(p + 32 * i), b = ge_load256(q + 32 * i);
+    const Quad rec = q_cached(b);
+    const Quad d = q_double_neg(q_double_neg(Quad{{a.x, a.y, a.z, a.t}}));
+    ge_store256(q_to_ge(d), dbl4 + 32 * i);
+    const Quad s1 = q_add(d, rec, false);
+    ge_store256(q_to_ge(s1), sum + 32 * i);
+    ge_store256(q_to_ge(q_add(d, rec, true)), diff + 32 * i);
+    // -(2 s1) - (-Q) = -(2 s1 - Q): the chains' way of absorbing the doubling's sign
+    ge_store256(ge_neg(q_to_ge(q_add(q_double_neg(s1), rec, false))), chain + 32 * i);
+    (void)q_add(q_add(s1, rec, true), q_cached(q_to_ge(s1)), false);      // sums of sums (the trees), a sum as the cached operand
   }
 }
 // reference-form addition and negation (the API kernels k_add / k_neg / k_hash_to_curve use them)

@@ -488,6 +488,7 @@ L.sim_scalar_mul_var(p(enc), p(k), n_(n), p(out), p(st))
 L.sim_scalar_mul_base(p(k), n_(n), p(out))
 L.sim_double_variants(p(xyzt), n_(n), p(x2), p(a), p(b))
 L.sim_group_misc(p(xyzt), p(x2), n_(n), p(a), p(b))
+L.sim_quad_forms(p(xyzt), p(x2), n_(n), p(a), p(b), p(np.zeros((n, 16), np.uint64)), p(np.zeros((n, 16), np.uint64)))
 L.sim_decompress(p(enc), n_(n), p(x2), p(st)); L.sim_msm_bucket(p(x2), p(np.array([0, 1, 1, 0, 0, 1, 0, 1], np.uint8)), n_(n), p(a)); L.sim_msm_bucket(p(x2), p(np.ones(n, np.uint8)), n_(2), p(a)); L.sim_msm_bucket(p(x2), p(np.zeros(n, np.uint8)), n_(3), p(a))
 f = [np.zeros((n, 4), np.uint64) for _ in range(5)]
 fl = [np.zeros(n, np.uint8) for _ in range(3)]
@@ -609,6 +610,27 @@ def test_doubling_variants_agree(sim, oracle):
     back = oracle.neg_xyzt(negd)
     assert oracle.eq_xyzt(back, ref).all() and (oracle.compress(back) == oracle.compress(ref)).all()
     assert oracle.is_identity(oracle.add_xyzt(negd, ref)).all()
+
+
+def test_four_lane_forms_agree(sim, oracle):
+    """The doubling and the addition as the quads of lanes run them (quad_ops.hpp: one linear combination per lane between
+    the two rounds of products), lanes emulated on the host with the device's own per-lane arithmetic: [4]P, [4]P + Q,
+    [4]P - Q and a doubling-then-subtraction step of the chains, against the oracle."""
+    rng = np.random.default_rng(17)
+    n = 256
+    P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    Q = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    P[0] = oracle.identity_xyzt()
+    Q[1] = oracle.identity_xyzt()
+    Q[2] = oracle.double_xyzt(oracle.double_xyzt(P[2:3]))[0]          # [4]P - Q = identity
+    out = [np.zeros((n, 16), np.uint64) for _ in range(4)]
+    sim.sim_quad_forms(_p(P), _p(Q), n_(n), *[_p(o) for o in out])
+    p4 = oracle.double_xyzt(oracle.double_xyzt(P))
+    s1 = oracle.add_xyzt(p4, Q)
+    want = [p4, s1, oracle.add_xyzt(p4, oracle.neg_xyzt(Q)), oracle.add_xyzt(oracle.double_xyzt(s1), oracle.neg_xyzt(Q))]
+    for got, w in zip(out, want):
+        assert oracle.eq_xyzt(got, w).all() and (oracle.compress(got) == oracle.compress(w)).all()
+    assert oracle.is_identity(out[2][2:3]).all()
 
 
 def test_bench_mac_counts():

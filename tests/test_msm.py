@@ -48,9 +48,23 @@ def test_four_lane_group_operations_selftest():
     assert r.returncode == 0 and "GQ_SELFTEST_OK" in r.stdout, r.stdout + r.stderr
 
 
+
+@pytest.fixture(params=["buckets", "quads"])
+def route(request):
+    """Both routes of the MSM on the same inputs: the bucket method (every size; forced here for the small ones too) and
+    the one-quad-per-point kernel that small batches take by default (forced here for the larger test sizes too, where
+    its grid no longer fits the chip at once and the partial sums take several trips)."""
+    old = os.environ.get("D377_MSM_SMALL_MAX")
+    os.environ["D377_MSM_SMALL_MAX"] = "0" if request.param == "buckets" else "1000000"
+    yield request.param
+    if old is None:
+        del os.environ["D377_MSM_SMALL_MAX"]
+    else:
+        os.environ["D377_MSM_SMALL_MAX"] = old
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [0, 1, 2, 7, 64, 257, 1000, 5000])
-def test_msm_matches_oracle(ctx, oracle, n):
+@pytest.mark.parametrize("n", [0, 1, 2, 7, 15, 16, 17, 64, 257, 1000, 2049, 5000])
+def test_msm_matches_oracle(ctx, oracle, n, route):
     rng = np.random.default_rng(701 + n)
     r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
@@ -75,7 +89,7 @@ def test_msm_matches_oracle(ctx, oracle, n):
 
 
 @pytest.mark.gpu
-def test_msm_affine_and_projective_inputs_mixed(ctx, oracle):
+def test_msm_affine_and_projective_inputs_mixed(ctx, oracle, route):
     """Element inputs are normalised to affine records with one inversion per lane, which a wave skips when
     every Z it sees is the canonical 1.  Waves of affine-only points (decompress output), waves of projective
     ones and waves holding both, plus identities in both forms, give the oracle's sum; a record with Z = 0 (not
@@ -104,7 +118,7 @@ def test_msm_affine_and_projective_inputs_mixed(ctx, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [700, 5000, 70000])
-def test_msm_equal_and_few_distinct_scalars(ctx, oracle, n):
+def test_msm_equal_and_few_distinct_scalars(ctx, oracle, n, route):
     """Scalars that are all equal (coefficients 1, a common weight) or take a few values put most points of a window
     into one bucket: the bucket reduction has to stay a tree (k_msm_reduce levels), and the sum has to stay right.
     n = 70000 crosses into the third level."""
@@ -138,6 +152,7 @@ def test_msm_every_window_width(oracle, window):
     """Same inputs through different bucket widths (developer override) give the same bytes."""
     import decaf377_amd as d
     os.environ["D377_MSM_WINDOW"] = str(window)
+    os.environ["D377_MSM_SMALL_MAX"] = "0"                     # 3000 points would not reach the buckets otherwise
     try:
         c = d.Context([0])
         rng = np.random.default_rng(702)
@@ -152,6 +167,7 @@ def test_msm_every_window_width(oracle, window):
         c.close()
     finally:
         del os.environ["D377_MSM_WINDOW"]
+        del os.environ["D377_MSM_SMALL_MAX"]
 
 
 @pytest.mark.gpu
