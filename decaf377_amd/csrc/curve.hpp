@@ -757,11 +757,13 @@ struct gec { fe ypx, ymx, z2, kt; };      // cached extended point
 // value its role contributes to round two -- and the second round's operands are quad permutations of those values (no
 // lane computes what another lane uses).  The arithmetic lives here, host-compilable, so that the bounds build walks
 // it (tests/host_sim: sim_quad_forms); the cross-lane moves are quad_ops.hpp's.
-// doubling: role 0: G' = A - B, 1: H' = A + B, 2: F' = A - B + C, 3: E.   u = (A, A, A, E), v = (B, B, B, *), c = (*, *, C, *)
+// doubling: the first round gives A = X^2, B = Y^2, Z^2 and T Z (= X Y: the quad holds T, so lane 3 multiplies its own
+// coordinate like the others).  role 0: G' = A - B, 1: H' = A + B, 2: F' = A - B + 2 Z^2, 3: E = 2 T Z.
+// u = (A, A, A, TZ), v = (B, B, B, TZ), c = (*, *, Z^2, *)
 D377_HD fe gq_double_own(int role, const fe& u, const fe& v, const fe& c) {
-  const fe t2 = fe_select(role == 3, fe_zero(), fe_select(role == 1, v, fe_neg_nc(v)));
+  const fe t2 = fe_select((role & 1) != 0, v, fe_neg_nc(v));
   const fe t3 = fe_select(role == 2, c, fe_zero());
-  return fe_carry(fe_add(fe_add(u, t2), t3));
+  return fe_carry(fe_add(fe_add(u, t2), fe_dbl(t3)));
 }
 // addition, first round's own operand: role 0: Y - X, 1: Y + X, 2: T, 3: 2Z.   u = (Y, Y, T, Z), v = (X, X, *, Z)
 D377_HD fe gq_add_in_own(int role, const fe& u, const fe& v) {

@@ -21,6 +21,7 @@
 //   k_msm_wsum_*    sum_b b * B_b per window by a pairwise tree of bit-sums, then Horner over the bits on four lanes
 //                   (k_msm_chunks / k_msm_fold, the chunked running sums, remain for windows wider than 14 bits)
 //   k_msm_final     Horner over the windows (c doublings per window) on four lanes per point (quad_ops.hpp), the encoding
+//   k_msm_small(_sum)  batches of up to 4 x 16 x CUs points skip all of the above: one quad of lanes per point, see there
 //
 // Group-element outputs are canonical as encodings, so the result bytes equal the reference's
 // whatever the summation order (the scatter order is non-deterministic; the sum is not).

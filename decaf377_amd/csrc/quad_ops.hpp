@@ -9,13 +9,13 @@
 namespace d377 {
 
 // The Horner chains (over the bit-sums of a window, over the windows) are dependency chains whatever the batch size:
-// 252 doublings in the tail.  A doubling is two rounds of four independent field products (X^2, Y^2, 2Z^2, 2XY, then
+// 252 doublings in the tail.  A doubling is two rounds of four independent field products (X^2, Y^2, Z^2, TZ, then
 // EF, GH, FG, EH) and so is an addition, so four lanes each take one product per round -- the same instruction stream
 // on different operands, no divergence.  The point lives DISTRIBUTED over the quad: lane r holds coordinate r (X, Y, Z,
 // T), which is exactly what lane r's second product produces, and a round's operands are fetched with DPP quad_perm
 // moves (one VALU instruction per limb, no LDS round trip).  (Round 2 kept the whole point in every lane and picked
-// operands with selects: ~660 instructions per doubling, 392 of them the two products; this form is ~545, and an
-// addition ~670.)
+// operands with selects: ~660 instructions per doubling, 392 of them the two products; this form is ~510, and an
+// addition ~600.)
 // The other operand of an addition comes from memory in CACHED form -- (Y-X, Y+X, 2dT, Z), made once per point, in
 // parallel, before the chain starts -- so lane r just loads the slot it multiplies by; subtracting a point swaps two
 // slots and two sums, which is how the chains absorb the sign of the sign-folded doubling (-[2]P, curve.hpp
@@ -43,15 +43,11 @@ __device__ __forceinline__ fe fe_pick(int role, const fe& a, const fe& b, const 
   }
   return r;
 }
-// -[2]P (the formulas of ge_double_neg; a lane forms only the value it contributes to the second round: curve.hpp gq_double_own)
+// -[2]P (the formulas of ge_double_neg; a lane forms only the value it contributes to the second round: curve.hpp
+// gq_double_own).  E = 2XY is taken as 2TZ: every lane's first product has its own coordinate as one operand.
 __device__ __forceinline__ fe gq_double_neg(const fe& v, int role) {
-  const fe opa = fe_quad_perm<0, 1, 2, 0>(v);                   // X, Y, Z, X
-  fe opb = fe_quad_perm<0, 1, 2, 1>(v);                         // X, Y, 2Z, 2Y
-  const uint32_t sh = (uint32_t)role >> 1;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) opb.l[i] <<= sh;
-  const fe m1 = fe_mul(opa, opb);                               // A = X^2, B = Y^2, C = 2Z^2, E = 2XY
-  const fe w = gq_double_own(role, fe_quad_perm<0, 0, 0, 3>(m1), fe_quad_perm<1, 1, 1, 1>(m1), fe_quad_perm<2, 2, 2, 2>(m1));   // G', H', F', E
+  const fe m1 = fe_mul(v, fe_quad_perm<0, 1, 2, 2>(v));         // A = X^2, B = Y^2, Z^2, T Z
+  const fe w = gq_double_own(role, fe_quad_perm<0, 0, 0, 3>(m1), fe_quad_perm<1, 1, 1, 3>(m1), fe_quad_perm<2, 2, 2, 2>(m1));   // G', H', F', E
   return fe_mul(fe_quad_perm<3, 0, 2, 3>(w), fe_quad_perm<2, 1, 0, 1>(w));   // E F', G' H', F' G', E H'
 }
 // A point of a chain's other operands in cached form, four 9-word slots in LDS: slot 0 Y-X, 1 Y+X (both carried), 2 2dT, 3 Z

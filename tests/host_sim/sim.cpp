@@ -73,11 +73,10 @@ namespace {
 struct Quad { fe l[4]; };
 template <int P0, int P1, int P2, int P3> Quad qperm(const Quad& v) { return Quad{{v.l[P0], v.l[P1], v.l[P2], v.l[P3]}}; }
 Quad q_double_neg(const Quad& v) {
-  const Quad opa = qperm<0, 1, 2, 0>(v);
-  Quad opb = qperm<0, 1, 2, 1>(v), m1, w, r;
-  for (int role = 2; role < 4; ++role) opb.l[role] = fe_dbl(opb.l[role]);
-  for (int role = 0; role < 4; ++role) m1.l[role] = fe_mul(opa.l[role], opb.l[role]);
-  const Quad u = qperm<0, 0, 0, 3>(m1), b = qperm<1, 1, 1, 1>(m1), c = qperm<2, 2, 2, 2>(m1);
+  const Quad opb = qperm<0, 1, 2, 2>(v);
+  Quad m1, w, r;
+  for (int role = 0; role < 4; ++role) m1.l[role] = fe_mul(v.l[role], opb.l[role]);
+  const Quad u = qperm<0, 0, 0, 3>(m1), b = qperm<1, 1, 1, 3>(m1), c = qperm<2, 2, 2, 2>(m1);
   for (int role = 0; role < 4; ++role) w.l[role] = gq_double_own(role, u.l[role], b.l[role], c.l[role]);
   const Quad oa = qperm<3, 0, 2, 3>(w), ob = qperm<2, 1, 0, 1>(w);
   for (int role = 0; role < 4; ++role) r.l[role] = fe_mul(oa.l[role], ob.l[role]);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel microseconds of every MSM call in a rocprofv3 --kernel-trace CSV (a call ends with k_msm_final).  Dev tool.
+"""Per-kernel microseconds of every MSM call in a rocprofv3 --kernel-trace CSV (a call ends with k_msm_final, or with k_msm_small_sum on the small-batch route).  Dev tool.
 usage: tools/msm_breakdown.py <kernel_trace.csv> [labels...]   one output line per call; with labels, one label per call"""
 import collections
 import csv
@@ -17,7 +17,7 @@ for r in rows:
     if t0 is None:
         t0 = int(r["Start_Timestamp"])
     cur[short] = cur.get(short, 0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    if short == "k_msm_final":
+    if short in ("k_msm_final", "k_msm_small_sum"):
         cur["_span"] = (int(r["End_Timestamp"]) - t0) / 1e3
         calls.append(cur)
         cur, t0 = collections.OrderedDict(), None
