@@ -59,7 +59,16 @@ struct FixedTab {
   }
 };
 
-// Round storage of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish): [5 slots][DCB_K][lanes] 32-byte
+// Lane sets and elements per inversion are per kernel: every chunked kernel runs WAVES_PER_SIMD workgroups per CU with
+// DCB_K elements per lane, except the fixed-base multiplication (FB_SETS, FB_K: see k_scalar_mul_base).  The scratch
+// layout is sized for the largest of each and is the same for all of them.
+constexpr int DCB_KMAX = 16;
+constexpr int FB_SETS = 3, FB_K = 16;
+constexpr size_t FB_WIDE_MIN = (size_t)2 << 20;   // elements from which the fixed-base kernel takes FB_SETS / FB_K
+constexpr int DCB_SETS_MAX = FB_SETS > WAVES_PER_SIMD ? FB_SETS : WAVES_PER_SIMD;
+static_assert(DCB_K <= DCB_KMAX && FB_K <= DCB_KMAX, "the scratch layout has DCB_KMAX record rows per slot");
+
+// Round storage of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish): [5 slots][DCB_KMAX][lanes] 32-byte
 // records in global scratch, so that a wave reads and writes 2 KiB contiguous.  Slots 0..3: the denominators of the
 // round's square roots / their inverses, later the compressor's state; slot 4: prefix products.  The compressor
 // parks its prefix products in the output records of the elements they belong to.
@@ -77,17 +86,18 @@ struct FixedTab {
 // finishes.  Claims are atomic and nothing resets the pool between launches, so kernels from different streams
 // (a replayed hipGraph next to an eager call) can share the areas safely.
 struct DcbScratch {
-  uint8_t* rec;        // [DCB_SLOTS][DCB_K][nslots * BLOCK] 32-byte records
-  int* pool;           // nslots flags, 0 = free (cleared once, at context creation; every workgroup frees what it claimed)
-  int nslots;
-  int per_lane;        // elements per lane in a chunk, 1 .. DCB_K: smaller for small batches, so that the grid still fills the chip
+  uint8_t* rec;        // [DCB_SLOTS][DCB_KMAX][lanes] 32-byte records, lanes = all the lane sets of the device x BLOCK
+  int* pool;           // one flag per lane set, 0 = free (cleared once, at context creation; every workgroup frees what it claimed)
+  int nslots;          // the sets THIS kernel may claim: the first nslots (its resident workgroups: 2 or 3 per CU)
+  int per_lane;        // elements per lane in a chunk, 1 .. the kernel's K: smaller for small batches, so that the grid still fills the chip
+  int lanes;           // the layout's lane count: the same for every kernel, so a set is the same memory whoever claims it
 };
 struct DcbIO {
   uint8_t* scratch;
   uint8_t* out32;
   size_t nlanes, lane, base;            // lane of the claimed set; the chunk's j-th element of this lane is record base + j * BLOCK
   int slot, per_lane;
-  __device__ __forceinline__ size_t rec(int sl, int j) const { return (size_t)(sl * DCB_K + j) * nlanes + lane; }
+  __device__ __forceinline__ size_t rec(int sl, int j) const { return (size_t)(sl * DCB_KMAX + j) * nlanes + lane; }
   __device__ __forceinline__ void put(int sl, int j, const uint32_t w[8]) { store32(scratch, rec(sl, j), w); }
   __device__ __forceinline__ void get(int sl, int j, uint32_t w[8]) const { load32(scratch, rec(sl, j), w); }
   __device__ __forceinline__ void park(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * BLOCK, w); }
@@ -164,7 +174,7 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
 }
 #define D377_DCB_BEGIN(out_ptr)                                                                   \
   const int dcb_slot_ = dcb_claim(dcb);                                                           \
-  DcbIO io{dcb.rec, reinterpret_cast<uint8_t*>(out_ptr), (size_t)dcb.nslots * BLOCK,             \
+  DcbIO io{dcb.rec, reinterpret_cast<uint8_t*>(out_ptr), (size_t)dcb.lanes,                      \
            (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_, dcb.per_lane}
 #define D377_DCB_END() dcb_release(dcb, dcb_slot_)
 
@@ -416,7 +426,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
   D377_DCB_BEGIN(out32);
   GlobalTab tab;
   tab.base = scratch;
-  tab.nthreads = io.nlanes;
+  tab.nthreads = (size_t)dcb.nslots * BLOCK;            // the window tables exist for this kernel's sets only (vb_scratch)
   tab.tid = io.lane;
   dcb_rounds<1, true, false>(n, io, pt,
     [&](size_t i, int j) {
@@ -442,7 +452,10 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
   D377_DCB_END();
 }
 
-__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
+// Up to three workgroups per CU (168 VGPRs): this kernel's additions wait on table gathers from HBM (14 random 128-byte
+// records per element, L2 hit rate 0.25), which a third wave per SIMD hides a little better, and large batches share one
+// inversion among FB_K = 16 elements per lane instead of 8 (launch(): OP_MUL_BASE chooses per call).
+__global__ void __launch_bounds__(BLOCK, FB_SETS) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
                                                            const uint8_t* scalar32, size_t n, uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();                        // unused here (no square root): residency is capped by the launch's LDS padding
   D377_DCB_BEGIN(out32);
@@ -903,13 +916,14 @@ int check_residency(DeviceState& d) {
   fns[CK_ENCODE_WIDE] = reinterpret_cast<const void*>(k_encode_to_curve_wide);
   static const char* names[CK_COUNT] = {"k_sqrt_ratio_zeta", "k_encode_to_curve", "k_hash_to_curve", "k_scalar_mul_var",
                                         "k_scalar_mul_base", "k_scalar_mul_var_el", "k_map_to_element", "k_encode_to_curve_wide"};
-  const int pad = (160 * 1024) / (WAVES_PER_SIMD + 1) + 1024;
   const bool verbose = getenv("D377_DEBUG_RESIDENCY") != nullptr;
   for (int k = 0; k < CK_COUNT; ++k) {
     int nb = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[k], BLOCK, 0));
     d.chunk_lds[k] = 0;
-    if (nb > WAVES_PER_SIMD) {
+    const int sets = d.chunk_sets[k];
+    const int pad = (160 * 1024) / (sets + 1) + 1024;
+    if (nb > sets) {
       if (pad > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, pad));
       d.chunk_lds[k] = pad;
       const int before = nb;
@@ -919,8 +933,20 @@ int check_residency(DeviceState& d) {
       fprintf(stderr, "d377: %s: %d workgroups per CU\n", names[k], nb);
     }
     d.chunk_blocks[k] = nb;
-    if (nb < 1 || nb > WAVES_PER_SIMD)
+    if (nb < 1 || nb > sets)
       return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", names[k]);
+  }
+  // the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU, below FB_WIDE_MIN elements): its own padding
+  {
+    const int pad = (160 * 1024) / (WAVES_PER_SIMD + 1) + 1024;
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[CK_MUL_BASE], BLOCK, (size_t)pad));
+    if (verbose) fprintf(stderr, "d377: k_scalar_mul_base, narrow launch: %d workgroups per CU with %d bytes of LDS padding\n", nb, pad);
+    if (nb < 1 || nb > WAVES_PER_SIMD)
+      return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", "k_scalar_mul_base (narrow launch)");
+    d.fb_narrow_lds = pad;
+    if (pad > d.chunk_lds[CK_MUL_BASE] && pad > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(fns[CK_MUL_BASE], hipFuncAttributeMaxDynamicSharedMemorySize, pad));
   }
   return D377_OK;
 }
@@ -950,11 +976,15 @@ int init_device(DeviceState& d) {
   d.vb_blocks = d.cus * WAVES_PER_SIMD;        // exactly the resident blocks: 2 per CU
 
   HIP_TRY(hipMalloc(&d.vb_scratch, (size_t)d.vb_blocks * BLOCK * VB_ENTRIES * VB_ENTRY_WORDS * sizeof(uint32_t)));
-  // round records of the batched inversions: DCB_SLOTS x DCB_K 32-byte records per resident lane (160 MiB), and the
+  // round records of the batched inversions: DCB_SLOTS x DCB_KMAX 32-byte records per lane of every lane set (480 MiB), and the
   // pool of lane sets the workgroups claim
-  HIP_TRY(hipMalloc(&d.dcb_scratch, (size_t)d.vb_blocks * BLOCK * DCB_SLOTS * DCB_K * 32));
-  HIP_TRY(hipMalloc(&d.slot_pool, (size_t)d.vb_blocks * sizeof(int)));
-  HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.vb_blocks * sizeof(int), d.stream));      // every set free; workgroups free what they claim
+  for (int k = 0; k < CK_COUNT; ++k) { d.chunk_sets[k] = WAVES_PER_SIMD; d.chunk_k[k] = DCB_K; }
+  d.chunk_sets[CK_MUL_BASE] = FB_SETS;
+  d.chunk_k[CK_MUL_BASE] = FB_K;
+  d.dcb_sets = d.cus * DCB_SETS_MAX;
+  HIP_TRY(hipMalloc(&d.dcb_scratch, (size_t)d.dcb_sets * BLOCK * DCB_SLOTS * DCB_KMAX * 32));
+  HIP_TRY(hipMalloc(&d.slot_pool, (size_t)d.dcb_sets * sizeof(int)));
+  HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.dcb_sets * sizeof(int), d.stream));      // every set free; workgroups free what they claim
   if ((rc = check_residency(d))) return rc;
   uint32_t* keys = nullptr;
   int* coll = nullptr;
@@ -1010,13 +1040,19 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
   // kernels that work in chunks of DCB_K x 256 elements: one workgroup per chunk (oversubscribed on purpose, see
   // DcbScratch), each claiming one of the vb_blocks resident lane sets of the per-device scratch areas
   // DCB_K elements per lane when the batch is large enough to fill the resident lane sets that way, fewer otherwise
-  size_t per_lane = (n + (size_t)d.vb_blocks * BLOCK - 1) / ((size_t)d.vb_blocks * BLOCK);
-  if (per_lane > (size_t)DCB_K) per_lane = DCB_K;
-  if (per_lane < 1) per_lane = 1;
-  size_t nchunks = (n + per_lane * BLOCK - 1) / (per_lane * BLOCK);
-  if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
-  const int gv = (int)nchunks;
-  const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.vb_blocks, (int)per_lane};
+  int gv = 0;
+  DcbScratch dcb{};
+  auto chunks_of = [&](int sets, int kmax, int& grid, DcbScratch& sc) {
+    const size_t resident = (size_t)d.cus * (size_t)sets * BLOCK;
+    size_t per_lane = (n + resident - 1) / resident;
+    if (per_lane > (size_t)kmax) per_lane = (size_t)kmax;
+    if (per_lane < 1) per_lane = 1;
+    size_t nchunks = (n + per_lane * BLOCK - 1) / (per_lane * BLOCK);
+    if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
+    grid = (int)nchunks;
+    sc = DcbScratch{d.dcb_scratch, d.slot_pool, d.cus * sets, (int)per_lane, d.dcb_sets * BLOCK};
+  };
+  chunks_of(WAVES_PER_SIMD, DCB_K, gv, dcb);  // every chunked kernel but the fixed-base one
   GuardScope vb{d.vb_guard, s};            // released (event recorded) when this function returns, if it was acquired
   int rc;
   switch (op) {
@@ -1037,11 +1073,24 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     case OP_ROUNDTRIP:
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
       break;
-    case OP_MUL_BASE:
+    case OP_MUL_BASE: {
+      // Wide launch (3 workgroups per CU, 16 elements per inversion) from FB_WIDE_MIN elements, where the chunks come in
+      // several generations; below, the narrow one (2 per CU, 8 per inversion) tiles the chip exactly at the sizes that
+      // matter (2^20 elements = 512 chunks of 8 per lane on 512 places; on 768 places they are 683 of 6 per lane).
+      // Measured, one box, alternating (profiles/README.md), narrow / wide: 2^20 1.13 / 1.06, 2^21 1.14 / 1.17,
+      // 3 x 2^20 1.09-1.13 / 1.17-1.20, 2^22 1.08-1.13 / 1.19, 2^23 1.14 / 1.21 x 10^9 per s.
+      bool wide = n >= FB_WIDE_MIN;
+      int fk = wide ? FB_K : DCB_K;
+      if (const char* e = getenv("D377_FB_SETS")) wide = atoi(e) >= FB_SETS;                       // developer overrides (A/B)
+      if (const char* e = getenv("D377_FB_K")) { int v = atoi(e); if (v >= 1 && v <= DCB_KMAX) fk = v; }
+      int gb;
+      DcbScratch db;
+      chunks_of(wide ? FB_SETS : WAVES_PER_SIMD, fk, gb, db);
       if ((rc = vb.acquire())) return rc;
-      hipLaunchKernelGGL(k_scalar_mul_base, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_MUL_BASE], s, T, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0,
-                         dcb);
+      hipLaunchKernelGGL(k_scalar_mul_base, dim3(gb), dim3(BLOCK), wide ? d.chunk_lds[CK_MUL_BASE] : d.fb_narrow_lds, s, T, d.fbase,
+                         (const uint8_t*)in0, n, (uint8_t*)out0, db);
       break;
+    }
     case OP_MUL_VAR:
       if (n <= small_batch_max(d)) {                          // one element per quad of lanes, table in LDS: no scratch, no hand-over
         hipLaunchKernelGGL(k_scalar_mul_var_small<false>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, T,
@@ -1498,7 +1547,7 @@ int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int
     if (d.chunk_blocks[k] > mb) mb = d.chunk_blocks[k];
     if (d.chunk_lds[k] > pad) pad = d.chunk_lds[k];
   }
-  if (sets_per_cu) *sets_per_cu = d.cus ? d.vb_blocks / d.cus : 0;
+  if (sets_per_cu) *sets_per_cu = d.cus ? d.dcb_sets / d.cus : 0;
   if (max_blocks_per_cu) *max_blocks_per_cu = mb;
   if (lds_pad_bytes) *lds_pad_bytes = pad;
   return D377_OK;

@@ -65,7 +65,7 @@ struct MsmWorkspace {
 };
 
 // The kernels that work in chunks and claim a lane set of the per-device scratch areas (d377.hip: dcb_claim).  At most
-// WAVES_PER_SIMD workgroups of them may be resident per CU -- that is how many lane sets exist; d377_ctx_create checks
+// chunk_sets[k] workgroups of kernel k may be resident per CU -- that is how many lane sets it may claim; d377_ctx_create checks
 // each with hipOccupancyMaxActiveBlocksPerMultiprocessor and pads the launch's LDS allocation for a kernel whose
 // registers and own LDS would let more in (chunk_lds, bytes of dynamic LDS per launch).
 enum ChunkKernel { CK_SQRT, CK_ENCODE, CK_HASH, CK_MUL_VAR, CK_MUL_BASE, CK_MUL_VAR_EL, CK_MAP_EL, CK_ENCODE_WIDE, CK_COUNT };
@@ -75,6 +75,10 @@ struct DeviceState {
   int cus = 0;
   int chunk_lds[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
   int chunk_blocks[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};     // resident workgroups per CU with that padding (occupancy query)
+  int chunk_sets[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};       // lane sets per CU the kernel may claim = the residency it is launched for
+  int chunk_k[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};          // elements per lane per shared inversion
+  int fb_narrow_lds = 0;                 // LDS padding of the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU)
+  int dcb_sets = 0;                      // lane sets of the round-record area and its pool (the largest chunk_sets x CUs)
   uint32_t* gtab = nullptr;
   uint8_t* s_lookup = nullptr;
   uint32_t* fbase = nullptr;

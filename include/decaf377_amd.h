@@ -78,16 +78,17 @@ const char* d377_last_error(void);
 
 /* Builds the read-only device tables (Sarkar square-root tables of
  * src/ark_curve/invsqrt.rs:14-66, fixed-base table of Element::GENERATOR) once per device
- * and allocates the per-device scratch (about 0.7 GB of HBM per device: window tables, the records of the
- * batched inversions, the 264 MB fixed-base comb).  device_ids == NULL, n_dev == 0 -> device 0. */
+ * and allocates the per-device scratch (about 1.0 GB of HBM per device: window tables, the records of the
+ * batched inversions, the 235 MB fixed-base comb).  device_ids == NULL, n_dev == 0 -> device 0. */
 int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out);
 void d377_ctx_destroy(d377_ctx* ctx);
 int d377_ctx_num_devices(const d377_ctx* ctx);
 int d377_ctx_device_id(const d377_ctx* ctx, int dev);
-/* The lane-set scratch areas hold `sets_per_cu` sets per compute unit; d377_ctx_create asks the runtime
+/* The lane-set scratch areas hold `sets_per_cu` sets per compute unit (3: the fixed-base kernel claims among all of
+ * them, the other kernels among the first 2 per CU); d377_ctx_create asks the runtime
  * (hipOccupancyMaxActiveBlocksPerMultiprocessor) how many workgroups of each kernel that claims a set can be resident
- * per CU, pads a kernel's launch with dynamic LDS when its registers alone would admit more, and fails with
- * D377_ERR_INIT if one still exceeds the sets.  Reports the numbers it settled on: the largest residency over those
+ * per CU, pads a kernel's launch with dynamic LDS when its registers alone would admit more than the sets it may claim,
+ * and fails with D377_ERR_INIT if one still exceeds them.  Reports the numbers it settled on: the largest residency over those
  * kernels (<= sets_per_cu) and the largest LDS padding in use (0 when none was needed).  Any pointer may be NULL. */
 int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int* max_blocks_per_cu, int* lds_pad_bytes);
 /* Debug builds (-DD377_CHECK_INVARIANTS, the counterpart of the reference's debug assertions in

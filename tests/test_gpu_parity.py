@@ -337,6 +337,43 @@ def test_full_size_fixed_base_2_20(ctx, torch_mod, oracle):
     assert (fb[idx].cpu().numpy() == oracle.scalar_mul_base(k.numpy()[idx])).all()
 
 
+def test_fixed_base_launch_shapes_agree(ctx, torch_mod, oracle):
+    """The fixed-base kernel is launched narrow (2 workgroups per CU, 8 elements per shared inversion) below 2^21
+    elements and wide (3 per CU, 16 per inversion) from there.  Every shape -- forced through the developer overrides at
+    a ragged size, and the default on both sides of the threshold -- gives the same bytes, a sample of them the oracle's,
+    and the wide launch (where the third lane set of the scratch areas is used) also in place."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(2291)
+    n = 16 * 196608 // 5 + 77
+    k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    want = ctx.scalar_mul_base(k)
+    idx = np.unique(np.concatenate([np.arange(40), np.arange(n - 300, n), np.arange(17, n, n // 61)]))
+    assert (want[torch.from_numpy(idx).to(dev)].cpu().numpy() == oracle.scalar_mul_base(k[torch.from_numpy(idx).to(dev)].cpu().numpy())).all()
+    try:
+        for sets, kk in ((3, 16), (3, 8), (2, 16), (3, 5), (2, 1)):
+            os.environ["D377_FB_SETS"], os.environ["D377_FB_K"] = str(sets), str(kk)
+            assert torch.equal(ctx.scalar_mul_base(k), want), (sets, kk)
+            k2 = k.clone()
+            ctx.scalar_mul_base(k2, outs=[k2])
+            assert torch.equal(k2, want), (sets, kk)
+    finally:
+        os.environ.pop("D377_FB_SETS", None)
+        os.environ.pop("D377_FB_K", None)
+    # the default above the threshold against the narrow launch forced at the same size
+    n = (3 << 20) + 4099
+    k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    wide = ctx.scalar_mul_base(k)
+    try:
+        os.environ["D377_FB_SETS"], os.environ["D377_FB_K"] = "2", "8"
+        assert torch.equal(ctx.scalar_mul_base(k), wide)
+    finally:
+        os.environ.pop("D377_FB_SETS", None)
+        os.environ.pop("D377_FB_K", None)
+    ti = torch.from_numpy(np.arange(5, n, n // 53)).to(dev)
+    assert (wide[ti].cpu().numpy() == oracle.scalar_mul_base(k[ti].cpu().numpy())).all()
+
+
 def test_full_size_hash_to_curve_two_routes_2_20(ctx, torch_mod, oracle):
     """hash_to_curve at BASELINE size by two routes that share no formula after the maps: the kernel's (the two points
     added on the Jacobi quartic, encoded without a square root) against the reference's own statement
@@ -451,8 +488,8 @@ def test_chunk_residency_is_checked(ctx):
     claims a set.  d377_ctx_create verifies that with the occupancy query (and pads the launch's LDS where registers
     alone would admit more) instead of trusting what the compiler happened to allocate; the numbers are reported."""
     sets, blocks, pad = ctx.chunk_residency()
-    assert sets == 2 and 1 <= blocks <= sets
-    assert pad in (0, (160 * 1024) // 3 + 1024)
+    assert sets == 3 and 1 <= blocks <= sets          # 3: the fixed-base kernel; every other chunked kernel is held to 2
+    assert pad in (0, (160 * 1024) // 3 + 1024, (160 * 1024) // 4 + 1024)
 
 
 def test_graph_replay_overlaps_eager_calls(ctx, oracle, torch_mod):
