@@ -401,6 +401,31 @@ def main():
         if msm_w:
             extra["msm_2^20"]["roofline_valu"] = valu_view(msm_w * MSM_MACS_PER_ADDITION, ne, ker)
             extra["msm_2^20"]["roofline_valu"]["note"] = "one 7-product mixed addition per point and window (18 windows); whole call"
+        if n >= (1 << 22):                                  # BASELINE config 5 at its full size: Elements decoded once, outside the timing
+            n22 = 1 << 22
+            pm22, _ = ctx.decompress(points[:n22])
+            ker, _ = time_op(torch, lambda: ctx.msm(pm22, scalars[:n22]), 3, 1)
+            extra["msm_2^22"] = {"n": n22, "ms": ker, "per_sec": n22 / (ker * 1e-3),
+                                 "roofline_valu": valu_view(18 * MSM_MACS_PER_ADDITION, n22, ker)}
+            o22 = torch.empty((n22, 32), dtype=torch.uint8, device=dev)
+            ker, _ = time_op(torch, lambda: ctx.scalar_mul_base(scalars[:n22], outs=[o22]), 3, 1)
+            extra["scalar_mul_base_2^22"] = {"n": n22, "kernel_ms": ker, "per_sec": n22 / (ker * 1e-3),
+                                             # wide launch from 2^21 elements: one inversion per 16 elements, not 8
+                                             "roofline_valu": valu_view(KERNEL_MACS["scalar_mul_base"] - DIVSTEP_MACS_PER_INVERSION / 16.0, n22, ker)}
+            del pm22, o22
+        # small batches: a call lasts as long as one element's dependency chain (one quad of lanes per element / point)
+        ns = 1 << 12
+        small = {}
+        for name, fn in [
+            ("msm", lambda: ctx.msm(pm[:ns], scalars[:ns])),
+            ("msm_encoded", lambda: ctx.msm(enc1[:ns], scalars[:ns])),
+            ("scalar_mul_var", lambda: ctx.scalar_mul_var(enc1[:ns], scalars[:ns], outs=[o1[:ns], s1[:ns]])),
+            ("scalar_mul_var_element", lambda: ctx.scalar_mul_var_element(pm[:ns], scalars[:ns])),
+            ("scalar_mul_base", lambda: ctx.scalar_mul_base(scalars[:ns], outs=[o1[:ns]])),
+        ]:
+            ker, _ = time_op(torch, fn, 5, 2)
+            small[name] = ker
+        extra["small_batch_2^12_ms_per_call"] = small
         aff = torch.empty((ne, 8), dtype=torch.int64, device=dev)
         ker, _ = time_op(torch, lambda: ctx.to_affine(pm, outs=[aff]), 3, 1)
         extra["to_affine"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}

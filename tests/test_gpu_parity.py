@@ -1346,6 +1346,8 @@ def test_bench_line_contract():
     for name in ("roundtrip", "scalar_mul_base", "encode_to_curve", "sqrt_ratio_zeta", "decompress", "compress", "hash_to_curve"):
         assert 0 < d_["extra"][name]["roofline_valu"]["frac"] < 1, name
     assert abs(d_["value"] - (1 << 16) * 2 / (d_["ms_per_step"] * 2e-3)) / d_["value"] < 1e-6
+    small = d_["extra"]["small_batch_2^12_ms_per_call"]
+    assert set(small) == {"msm", "msm_encoded", "scalar_mul_var", "scalar_mul_var_element", "scalar_mul_base"} and all(0 < v < 5 for v in small.values())
 
 
 def test_bench_self_launches_its_ranks():
