@@ -871,12 +871,15 @@ int d377::debug_device_delay_ms() {
 
 namespace {
 
-// Batches up to this many elements take the quad-per-element kernel (k_scalar_mul_var_small): one wave of 16 quads per
-// SIMD.  Beyond it the quads would queue behind each other and one lane per element is the better use of the chip.
+// Batches up to this many elements take the quad-per-element kernel (k_scalar_mul_var_small).  One wave of 16 quads per
+// SIMD is 16 x 4 x CUs elements (16 384); the kernel still wins a little beyond that: the Element form (20 KiB of LDS per
+// wave: seven waves per CU) runs 28 672 elements in one generation, two waves sharing most SIMDs -- 0.60 ms against 0.88
+// with one lane per element -- and the Encoding form (39 KiB: four waves per CU) two generations of 16 384 in 1.02 ms
+// against 1.08.  Beyond those sizes one lane per element is the better use of the chip (measured, profiles/README.md).
 // D377_SMALL_MAX: developer override (0 switches the small-batch kernel off).
-size_t small_batch_max(const DeviceState& d) {
+size_t small_batch_max(const DeviceState& d, bool element_form) {
   if (const char* e = getenv("D377_SMALL_MAX")) return (size_t)strtoull(e, nullptr, 10);
-  return (size_t)d.cus * 4 * SMALL_QUADS;
+  return (size_t)d.cus * SMALL_QUADS * (element_form ? 7 : 8);
 }
 
 int grid_for(const DeviceState& d, size_t n) {
@@ -1092,7 +1095,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     }
     case OP_MUL_VAR:
-      if (n <= small_batch_max(d)) {                          // one element per quad of lanes, table in LDS: no scratch, no hand-over
+      if (n <= small_batch_max(d, false)) {                   // one element per quad of lanes, table in LDS: no scratch, no hand-over
         hipLaunchKernelGGL(k_scalar_mul_var_small<false>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, T,
                            (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0, (uint8_t*)out1);
         break;
@@ -1164,7 +1167,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_MUL_VAR_EL: {
-      if (n <= small_batch_max(d)) {
+      if (n <= small_batch_max(d, true)) {
         hipLaunchKernelGGL(k_scalar_mul_var_small<true>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, T,
                            (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0, (uint8_t*)nullptr);
         break;

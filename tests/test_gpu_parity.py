@@ -440,17 +440,18 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
 
 
 def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
-    """Batches that cannot fill the chip with one lane per element (n <= 4 x 16 quads per CU) run one element per QUAD of
+    """Batches that cannot fill the chip with one lane per element (up to 7 or 8 x 16 quads per CU) run one element per QUAD of
     lanes (d377.hip k_scalar_mul_var_small, quad_ops.hpp).  Same bytes as the one-lane-per-element kernel (forced with
     D377_SMALL_MAX=0) at sizes around every edge of the quad kernel's grid -- invalid encodings, zero and extreme
     scalars included -- and as the oracle; likewise the Element form (records in, records out)."""
     torch = torch_mod
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(4401)
-    small_max = torch.cuda.get_device_properties(0).multi_processor_count * 4 * 16
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    one_gen, el_max, enc_max = cus * 4 * 16, cus * 7 * 16, cus * 8 * 16       # one wave per SIMD; the two forms' thresholds
     old = os.environ.pop("D377_SMALL_MAX", None)
     try:
-        for n in (1, 3, 16, 17, 1000, small_max - 1, small_max, small_max + 1):
+        for n in (1, 3, 16, 17, 1000, one_gen - 1, one_gen + 1, el_max, el_max + 1, enc_max, enc_max + 1):
             enc = oracle.encode_to_curve(rng.integers(0, 256, (min(n, 2048), 32), dtype=np.uint8))
             enc = np.tile(enc, ((n + enc.shape[0] - 1) // enc.shape[0], 1))[:n].copy()
             k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
