@@ -816,11 +816,16 @@ __global__ void __launch_bounds__(BLOCK) k_fr_from_wide(const uint8_t* in, int l
   }
 }
 __global__ void __launch_bounds__(BLOCK) k_neg(const uint64_t* p, size_t n, uint64_t* out) {
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+  D377_RECORD_TILES(rec0) {
     uint32_t a[32], r[32];
-    load_record128(p, i, a);
-    if (ge_neg_words(a, r)) store_record128(out, i, r);
-    else store_ge_mont256(out, i, ge_neg(load_ge_mont256(p, i)));     // a non-canonical record: reduce it the long way
+    wave_load_records128(p, rec0, n, tile, lane, a);
+    if (!ge_neg_words(a, r)) {                            // a non-canonical record: reduce it the long way
+      ge g;
+      g.x = fe_from_mont256_words(a); g.y = fe_from_mont256_words(a + 8); g.z = fe_from_mont256_words(a + 16); g.t = fe_from_mont256_words(a + 24);
+      g = ge_neg(g);
+      fe_to_mont256_words(g.x, r); fe_to_mont256_words(g.y, r + 8); fe_to_mont256_words(g.z, r + 16); fe_to_mont256_words(g.t, r + 24);
+    }
+    wave_store_records128(out, rec0, n, tile, lane, r);
   }
 }
 // Element::is_identity: x == 0 (src/min_curve/element.rs:113-117)
@@ -831,6 +836,9 @@ __global__ void __launch_bounds__(BLOCK) k_is_identity(const uint64_t* p, size_t
 // add / double / eq / neg read the records without converting them (curve.hpp, "records used without conversion"):
 // these kernels move 256-384 bytes per element and the eight conversion products were most of their time.
 // negate != 0: Element - Element = self + other.neg() (src/min_curve/ops.rs:43-49)
+// (k_neg moves its records through LDS, coalesced -- device_util.hpp, wave_load_records128 -- and gained 25 %; these two
+// execute ~3 000 instructions per element, the exact reference coordinates cost 11-12 products, and the same change left
+// them where they were: 0.43 and 0.53-0.56 ms per 2^22 elements either way.)
 __global__ void __launch_bounds__(BLOCK) k_add(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out, int negate) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t a[32], b[32];
