@@ -432,12 +432,37 @@ D377_HD ge ge_from_raw_words(const uint32_t w[32]) {
   g.x = fe_from_words(w); g.y = fe_from_words(w + 8); g.z = fe_from_words(w + 16); g.t = fe_from_words(w + 24);
   return g;
 }
-// result of ge_add / ge_double on raw operands (coordinates scaled by 2^-20) -> the reference's words
-D377_HD void ge_raw4_to_words(const ge& g, uint32_t w[32]) {
-  fe_scaled_to_mont256_words(g.x, FE_RAW4_TO_MONT256, w);
-  fe_scaled_to_mont256_words(g.y, FE_RAW4_TO_MONT256, w + 8);
-  fe_scaled_to_mont256_words(g.z, FE_RAW4_TO_MONT256, w + 16);
-  fe_scaled_to_mont256_words(g.t, FE_RAW4_TO_MONT256, w + 24);
+// The results of ge_add / ge_double on raw operands are scaled by 2^-20; the reference's words come out of the formulas'
+// last stage: X3 = E F, Y3 = G H, Z3 = F G, T3 = E H each hold exactly one of E, G, so scaling those two carries the
+// power of two into all four coordinates -- two products, not one per coordinate.
+D377_HD void ge_raw_efgh_to_words(const fe& e, const fe& f, const fe& g, const fe& h, uint32_t w[32]) {
+  // (strict: es, gs below ~1.3 q keep the four products below 2q for the single conditional subtraction)
+  const fe es = fe_mul_strict(e, fe_const(FE_RAW4_TO_MONT256)), gs = fe_mul_strict(g, fe_const(FE_RAW4_TO_MONT256));
+  fe_to_words(fe_reduce_once(fe_mul_strict(es, f)), w);
+  fe_to_words(fe_reduce_once(fe_mul_strict(gs, h)), w + 8);
+  fe_to_words(fe_reduce_once(fe_mul_strict(gs, f)), w + 16);
+  fe_to_words(fe_reduce_once(fe_mul_strict(es, h)), w + 24);
+}
+// P + Q, or P - Q (ge_add / ge_sub_pts above, one instruction stream for both), raw records in, the reference's words out
+D377_HD void ge_add_raw_words(const uint32_t pw[32], const uint32_t qw[32], bool negate, uint32_t w[32]) {
+  const ge p = ge_from_raw_words(pw), q = ge_from_raw_words(qw);
+  const fe qm = fe_sub(q.y, q.x), qp = fe_carry(fe_add(q.y, q.x));
+  const fe a = fe_mul(fe_sub(p.y, p.x), fe_select(negate, qp, qm));
+  const fe b = fe_mul(fe_add(p.y, p.x), fe_select(negate, qm, qp));
+  const fe c = fe_mul(fe_mul(fe_const(FE_K), p.t), q.t);
+  const fe d = fe_mul(fe_dbl(p.z), q.z);
+  const fe dmc = fe_sub(d, c), dpc = fe_carry(fe_add(d, c));
+  ge_raw_efgh_to_words(fe_sub(b, a), fe_select(negate, dpc, dmc), fe_select(negate, dmc, dpc), fe_add(b, a), w);
+}
+// [2]P (ge_double above) likewise
+D377_HD void ge_double_raw_words(const uint32_t pw[32], uint32_t w[32]) {
+  const ge p = ge_from_raw_words(pw);
+  const fe a = fe_sqr(p.x), b = fe_sqr(p.y);
+  const fe c = fe_dbl(fe_sqr(p.z));
+  const fe ab = fe_add(a, b);
+  const fe e = fe_sub(fe_sqr(fe_add(p.x, p.y)), ab);
+  const fe g = fe_sub(b, a);
+  ge_raw_efgh_to_words(e, fe_sub(g, c), g, fe_neg(ab), w);
 }
 // decaf equality x1 * y2 == x2 * y1 (src/min_curve/element.rs:334-340): both sides carry the same scale
 D377_HD bool ge_eq_raw_words(const uint32_t p[32], const uint32_t q[32]) {
@@ -451,6 +476,31 @@ D377_HD bool ge_neg_words(const uint32_t p[32], uint32_t out[32]) {
   ok = fq_neg_words(p + 24, out + 24) && ok;
   return ok && !words_geq(p + 8, FQ_MODULUS_W_LIT) && !words_geq(p + 16, FQ_MODULUS_W_LIT);
 }
+// ---- normalize_batch (to_affine) on raw records ------------------------------------------------------------------
+// Montgomery's trick on the z's as they lie in memory (each scaled by 2^-5, see above): the prefix products collect a
+// power of two per factor, and it cancels again in  1 / z_k = inverse_k * prefix_(k-1)  up to one 2^5 -- which, with the
+// change of radix, is a single constant multiplied into the lane's inverse once (FE_TO_MONT256).  Per element: one product
+// on the way up, four on the way down (1/z_k, the next inverse, x / z, y / z), no conversion of x, y or z.
+// A coordinate that is zero mod q (any of its 256-bit spellings) is no group element's z: flagged, kept out of the product.
+D377_HD fe affine_raw_z(const uint32_t zw[8], bool* zero) {
+  uint32_t nz = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) nz |= zw[k];
+  bool z0 = nz == 0;
+  if (!z0 && words_geq(zw, FQ_MODULUS_W_LIT)) z0 = fe_is_zero(fe_from_mont256_words(zw));   // a non-canonical string: the long way
+  *zero = z0;
+  return fe_select(z0, fe_const(FE_ONE), fe_from_words(zw));
+}
+// x / z and y / z as the reference's words; zi = the scaled 1 / z of this element
+D377_HD void affine_raw_finish(const fe& zi, const uint32_t xw[8], const uint32_t yw[8], bool zero, uint32_t out[16]) {
+  fe_to_words(fe_reduce_once(fe_mul_strict(fe_from_words(xw), zi)), out);
+  fe_to_words(fe_reduce_once(fe_mul_strict(fe_from_words(yw), zi)), out + 8);
+  if (zero) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+  }
+}
+
 D377_HD ge ge_select(bool c, const ge& a, const ge& b) {
   ge r;
   r.x = fe_select(c, a.x, b.x); r.y = fe_select(c, a.y, b.y);

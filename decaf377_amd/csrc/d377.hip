@@ -670,43 +670,56 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve_wide(
 // shared by the lane's ~32 elements, against one inversion per element before.  A zero z (not a group
 // element; Fq::inverse returns None there) yields a zero record and is kept out of the product.
 constexpr int AFFINE_PER_LANE = 32;
-__device__ __forceinline__ fe load_z_or_one(const uint64_t* xyzt, size_t i, bool* was_zero) {
-  uint32_t w[8];
-  load32(reinterpret_cast<const uint8_t*>(xyzt), 4 * i + 2, w);
-  const fe z = fe_from_mont256_words(w);
-  *was_zero = fe_is_zero(z);
-  return fe_select(*was_zero, fe_const(FE_ONE), z);
-}
+// (The records are used as they lie in memory -- curve.hpp, "normalize_batch on raw records": 5 products per element
+// instead of 12, 0.62 -> see profiles/README.md.)
 __global__ void __launch_bounds__(BLOCK) k_to_affine(const uint64_t* xyzt, size_t n, uint64_t* xy) {
   const size_t T = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (t >= n) return;
+  const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
+  uint8_t* o = reinterpret_cast<uint8_t*>(xy);
   uint32_t* slots = reinterpret_cast<uint32_t*>(xy);       // 16 words per element
+  // Both walks are one dependent chain of products per lane with a handful of waves per SIMD: the next element's words
+  // are requested before the current element's products start, so the chain does not wait for memory at every step.
   fe p = fe_const(FE_ONE);
   size_t last = t;
+  uint32_t zn[8];
+  load32(b, 4 * t + 2, zn);
   for (size_t i = t; i < n; i += T) {
+    uint32_t zw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) zw[k] = zn[k];
+    if (i + T < n) load32(b, 4 * (i + T) + 2, zn);
     bool zz;
-    const fe z = load_z_or_one(xyzt, i, &zz);
+    const fe z = affine_raw_z(zw, &zz);
     slot_store(slots + 16 * i, p);                          // product of this lane's earlier z's
     p = fe_mul(p, z);
     last = i;
   }
-  fe inv = fe_invert(p);
+  fe inv = fe_mul(fe_invert(p), fe_const(FE_TO_MONT256));
+  uint32_t xn[8], yn[8];
+  load32(b, 4 * last + 2, zn);
+  load32(b, 4 * last + 0, xn);
+  load32(b, 4 * last + 1, yn);
+  fe pn = slot_load(slots + 16 * last);
   for (size_t i = last;; i -= T) {
+    uint32_t zw[8], xw[8], yw[8], w[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { zw[k] = zn[k]; xw[k] = xn[k]; yw[k] = yn[k]; }
+    const fe pre = pn;
+    if (i != t) {                                           // the element below, while this one is worked on
+      const size_t j = i - T;
+      load32(b, 4 * j + 2, zn);
+      load32(b, 4 * j + 0, xn);
+      load32(b, 4 * j + 1, yn);
+      pn = slot_load(slots + 16 * j);
+    }
     bool zz;
-    const fe z = load_z_or_one(xyzt, i, &zz);
-    const fe zi = fe_mul(inv, slot_load(slots + 16 * i));   // 1 / z_i
+    const fe z = affine_raw_z(zw, &zz);
+    const fe zi = fe_mul(inv, pre);                         // (scaled) 1 / z_i
     inv = fe_mul(inv, z);
-    const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
-    uint8_t* o = reinterpret_cast<uint8_t*>(xy);
-    uint32_t w[8];
-    load32(b, 4 * i + 0, w);
-    const fe x = fe_from_mont256_words(w);
-    load32(b, 4 * i + 1, w);
-    const fe y = fe_from_mont256_words(w);
-    fe_to_mont256_words(fe_mul(x, zi), w);
-    if (zz) store32_zero(o, 2 * i); else store32(o, 2 * i, w);
-    fe_to_mont256_words(fe_mul(y, zi), w);
-    if (zz) store32_zero(o, 2 * i + 1); else store32(o, 2 * i + 1, w);
+    affine_raw_finish(zi, xw, yw, zz, w);
+    store32(o, 2 * i, w);
+    store32(o, 2 * i + 1, w + 8);
     if (i == t) break;
   }
 }
@@ -836,25 +849,26 @@ __global__ void __launch_bounds__(BLOCK) k_is_identity(const uint64_t* p, size_t
 // add / double / eq / neg read the records without converting them (curve.hpp, "records used without conversion"):
 // these kernels move 256-384 bytes per element and the eight conversion products were most of their time.
 // negate != 0: Element - Element = self + other.neg() (src/min_curve/ops.rs:43-49)
-// (k_neg moves its records through LDS, coalesced -- device_util.hpp, wave_load_records128 -- and gained 25 %; these two
-// execute ~3 000 instructions per element, the exact reference coordinates cost 11-12 products, and the same change left
-// them where they were: 0.43 and 0.53-0.56 ms per 2^22 elements either way.)
+// k_add and k_neg move their records through LDS, coalesced (device_util.hpp, wave_load_records128): same box, 2^22 records,
+// neg 0.25 -> 0.20 ms, add 0.49-0.52 -> 0.46 ms; the doubling (one input stream, ~2 500 instructions per element) is bound by
+// its instructions and stays on plain loads (0.32 ms either way).  The reference's exact coordinates cost 11 products for
+// an addition and 10 for a doubling (curve.hpp, ge_raw_efgh_to_words; 13 and 12 with one scaling product per coordinate:
+// 0.53 and 0.43 ms).
 __global__ void __launch_bounds__(BLOCK) k_add(const uint64_t* p, const uint64_t* q, size_t n, uint64_t* out, int negate) {
-  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t a[32], b[32];
-    load_record128(p, i, a);
-    load_record128(q, i, b);
-    const ge gp = ge_from_raw_words(a), gq = ge_from_raw_words(b);
-    ge_raw4_to_words(negate ? ge_sub_pts(gp, gq) : ge_add(gp, gq), a);
-    store_record128(out, i, a);
+  D377_RECORD_TILES(rec0) {
+    uint32_t a[32], b[32], r[32];
+    wave_load_records128(p, rec0, n, tile, lane, a);
+    wave_load_records128(q, rec0, n, tile, lane, b);
+    ge_add_raw_words(a, b, negate != 0, r);
+    wave_store_records128(out, rec0, n, tile, lane, r);
   }
 }
 __global__ void __launch_bounds__(BLOCK) k_double(const uint64_t* p, size_t n, uint64_t* out) {
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-    uint32_t a[32];
+    uint32_t a[32], r[32];
     load_record128(p, i, a);
-    ge_raw4_to_words(ge_double(ge_from_raw_words(a)), a);
-    store_record128(out, i, a);
+    ge_double_raw_words(a, r);
+    store_record128(out, i, r);
   }
 }
 // decaf equality: x1 * y2 == x2 * y1  (src/min_curve/element.rs:334-340)

@@ -263,8 +263,8 @@ void sim_raw_forms(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* sum
   for (size_t i = 0; i < n; ++i) {
     const uint32_t* a = p + 32 * i;
     const uint32_t* b = q + 32 * i;
-    ge_raw4_to_words(ge_add(ge_from_raw_words(a), ge_from_raw_words(b)), sum + 32 * i);
-    ge_raw4_to_words(ge_double(ge_from_raw_words(a)), dbl + 32 * i);
+    ge_add_raw_words(a, b, false, sum + 32 * i);
+    ge_double_raw_words(a, dbl + 32 * i);
     neg_ok[i] = ge_neg_words(a, neg + 32 * i) ? 1 : 0;
     eq[i] = ge_eq_raw_words(a, b) ? 1 : 0;
     // field ops on the X words of the two records
@@ -298,7 +298,26 @@ void sim_msm_bucket(const uint32_t* xyzt, const uint8_t* negs, size_t n, uint32_
 // Element - Element as k_add does it with negate = 1
 void sim_raw_ge_sub(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* out) {
   for (size_t i = 0; i < n; ++i) {
-    ge_raw4_to_words(ge_sub_pts(ge_from_raw_words(p + 32 * i), ge_from_raw_words(q + 32 * i)), out + 32 * i);
+    ge_add_raw_words(p + 32 * i, q + 32 * i, true, out + 32 * i);
+  }
+}
+// normalize_batch as one lane of k_to_affine walks it: all n records share one inversion
+void sim_to_affine_raw(const uint32_t* xyzt, size_t n, uint32_t* xy) {
+  std::vector<fe> prefix(n);
+  fe p = fe_const(FE_ONE);
+  for (size_t i = 0; i < n; ++i) {
+    bool zz;
+    const fe z = affine_raw_z(xyzt + 32 * i + 16, &zz);
+    prefix[i] = p;
+    p = fe_mul(p, z);
+  }
+  fe inv = fe_mul(fe_invert(p), fe_const(FE_TO_MONT256));
+  for (size_t i = n; i-- > 0;) {
+    bool zz;
+    const fe z = affine_raw_z(xyzt + 32 * i + 16, &zz);
+    const fe zi = fe_mul(inv, prefix[i]);
+    inv = fe_mul(inv, z);
+    affine_raw_finish(zi, xyzt + 32 * i, xyzt + 32 * i + 8, zz, xy + 16 * i);
   }
 }
 // Fq inverse three ways on Montgomery-256 words: divsteps (fe_invert, what the kernels use), the x^(q-2) ladder and the

@@ -489,6 +489,7 @@ L.sim_scalar_mul_base(p(k), n_(n), p(out))
 L.sim_double_variants(p(xyzt), n_(n), p(x2), p(a), p(b))
 L.sim_group_misc(p(xyzt), p(x2), n_(n), p(a), p(b))
 L.sim_quad_forms(p(xyzt), p(x2), n_(n), p(a), p(b), p(np.zeros((n, 16), np.uint64)), p(np.zeros((n, 16), np.uint64)))
+L.sim_to_affine_raw(p(xyzt), n_(n), p(np.zeros((n, 8), np.uint64))); L.sim_to_affine_raw(p(np.full((n, 16), 0xFFFFFFFFFFFFFFFF, np.uint64)), n_(n), p(np.zeros((n, 8), np.uint64)))
 L.sim_decompress(p(enc), n_(n), p(x2), p(st)); L.sim_msm_bucket(p(x2), p(np.array([0, 1, 1, 0, 0, 1, 0, 1], np.uint8)), n_(n), p(a)); L.sim_msm_bucket(p(x2), p(np.ones(n, np.uint8)), n_(2), p(a)); L.sim_msm_bucket(p(x2), p(np.zeros(n, np.uint8)), n_(3), p(a))
 f = [np.zeros((n, 4), np.uint64) for _ in range(5)]
 fl = [np.zeros(n, np.uint8) for _ in range(3)]
@@ -631,6 +632,31 @@ def test_four_lane_forms_agree(sim, oracle):
     for got, w in zip(out, want):
         assert oracle.eq_xyzt(got, w).all() and (oracle.compress(got) == oracle.compress(w)).all()
     assert oracle.is_identity(out[2][2:3]).all()
+
+
+def test_to_affine_on_raw_records(sim, oracle):
+    """normalize_batch as k_to_affine computes it -- Montgomery's trick on the records as they lie in memory, the power of
+    two of the skipped conversions folded into the lane's one inverse -- against the oracle's x / z, y / z; a record with
+    z = 0 (in its canonical and in a non-canonical spelling: q itself) gives a zero record and leaves the others intact;
+    a non-canonical but non-zero z (z + q) gives the same affine point as z."""
+    rng = np.random.default_rng(18)
+    n = 64
+    P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    want = oracle.to_affine(P)
+    got = np.zeros((n, 8), np.uint64)
+    sim.sim_to_affine_raw(_p(P), n_(n), _p(got))
+    assert (got == want).all()
+    def words(v):
+        return np.frombuffer(int(v).to_bytes(32, "little"), np.uint64)
+    bad = P.copy()
+    bad[3, 8:12] = 0
+    bad[7, 8:12] = words(Q)                                   # zero mod q, spelled q
+    z9 = int.from_bytes(P[9, 8:12].tobytes(), "little")
+    bad[9, 8:12] = words(z9 + Q)                              # the same z, not canonical
+    sim.sim_to_affine_raw(_p(bad), n_(n), _p(got))
+    keep = np.ones(n, bool)
+    keep[[3, 7]] = False
+    assert (got[keep] == want[keep]).all() and not got[3].any() and not got[7].any()
 
 
 def test_bench_mac_counts():
