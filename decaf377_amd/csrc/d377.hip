@@ -373,9 +373,18 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtT
 // sum, so the encoding needs no third square root (curve.hpp, ge_dcb_from_jacobi_sum): 1.8e8 -> 2.5e8 /s at 2^20.  A pair
 // that hits the addition law's exceptional case (s1 s2 = +-1) goes the reference's way, Edwards addition and generic
 // compression, and enters the batch as a finished encoding; the branch is taken by a wave only if one of its lanes needs it.
+// (Out of line, and handed nothing but the pair's index: it maps both inputs again, in the reference's inversion-free form.
+// References to the caller's (s, t) values would put those in scratch memory for EVERY element -- 144 bytes of stores per
+// element on the hot path, which is what the first version did -- to save four square roots on a route no known input
+// takes.  What the compiler still spills is live state around the call, inside the branch.)
 template <class PT>
-__device__ __noinline__ void hash_exceptional_pair(const SqrtTables& T, PT& pt, const fe& s1, const fe& t1, const fe& s2, const fe& t2,
-                                                   uint32_t w[8]) {
+__device__ __noinline__ void hash_exceptional_pair(SqrtTables T, PT pt, const uint8_t* r1, const uint8_t* r2, size_t i, uint32_t w[8]) {
+  uint32_t a[8];
+  fe s1, t1, s2, t2, unused = fe_zero();
+  load32(r1, i, a);
+  ge_elligator_st(T, pt, fe_from_words_mod_order(a), &s1, &t1, &unused, false);
+  load32(r2, i, a);
+  ge_elligator_st(T, pt, fe_from_words_mod_order(a), &s2, &t2, &unused, false);
   ge_compress(T, pt, ge_add(ge_from_jacobi_st(s1, t1), ge_from_jacobi_st(s2, t2)), w);
 }
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTables T, const uint8_t* r1, const uint8_t* r2,
@@ -408,8 +417,9 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTab
                                                    // the GPU suite runs it (no input pair is known that takes it by itself)
 #endif
       if (__any(exceptional)) {
-        hash_exceptional_pair(T, pt, s1, t1, s2, t2, w);
-        const dcb_state se = dcb_from_encoding_words(w);
+        uint32_t we[8];
+        hash_exceptional_pair(T, pt, r1, r2, i, we);
+        const dcb_state se = dcb_from_encoding_words(we);
         st.p = fe_select(exceptional, se.p, st.p); st.w = fe_select(exceptional, se.w, st.w);
         st.n0 = fe_select(exceptional, se.n0, st.n0); st.n1 = fe_select(exceptional, se.n1, st.n1);
       }
