@@ -147,6 +147,48 @@ def test_msm_equal_and_few_distinct_scalars(ctx, oracle, n, route):
 
 
 @pytest.mark.gpu
+def test_msm_on_elements_from_every_producer(ctx, oracle):
+    """The small-batch route reads an Element's T (each quad runs the extended-coordinate chain on the record as given); the
+    bucket route rebuilds it from X, Y, Z.  Elements as every Element-producing entry point of this library leaves them --
+    Z = 1 or not, whatever representative the schedule produced -- must give the same sum on both routes, and that sum must
+    be the one of their encodings (the Encoding-input form, and the oracle on a prefix)."""
+    rng = np.random.default_rng(707)
+    n = 1500
+    k1, k2, kk = (rng.integers(0, 256, (n, 32), dtype=np.uint8) for _ in range(3))
+    base = ctx.scalar_mul_base_element(k1)
+    prod = {
+        "scalar_mul_base_element": base,
+        "scalar_mul_var_element": ctx.scalar_mul_var_element(base, k2),
+        "encode_to_curve_element": ctx.encode_to_curve_element(k1),
+        "hash_to_curve_element": ctx.hash_to_curve_element(k1, k2),
+        "decompress": ctx.decompress(ctx.scalar_mul_base(k2))[0],
+    }
+    prod["add"] = ctx.add(prod["scalar_mul_var_element"], prod["encode_to_curve_element"])
+    prod["sub"] = ctx.sub(prod["hash_to_curve_element"], base)
+    prod["double"] = ctx.double(prod["add"])
+    prod["neg"] = ctx.neg(prod["double"])
+    old = os.environ.get("D377_MSM_SMALL_MAX")
+    try:
+        for name, P in prod.items():
+            os.environ["D377_MSM_SMALL_MAX"] = "1000000"
+            quads = ctx.msm(P, kk)
+            os.environ["D377_MSM_SMALL_MAX"] = "0"
+            buckets = ctx.msm(P, kk)
+            assert bytes(quads[0]) == bytes(buckets[0]), name
+            assert bytes(ctx.compress(quads[1].reshape(1, 16))[0]) == bytes(quads[0]), name
+            encs = ctx.compress(P)
+            assert bytes(ctx.msm(encs, kk)[0]) == bytes(quads[0]), name
+            os.environ["D377_MSM_SMALL_MAX"] = "1000000"
+            assert bytes(ctx.msm(encs, kk)[0]) == bytes(quads[0]), name
+            assert bytes(ctx.msm(P[:40], kk[:40])[0]) == bytes(oracle.msm(np.asarray(P[:40]), kk[:40])[0]), name
+    finally:
+        if old is None:
+            os.environ.pop("D377_MSM_SMALL_MAX", None)
+        else:
+            os.environ["D377_MSM_SMALL_MAX"] = old
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("window", [4, 5, 6, 7, 9, 12, 14, 16])
 def test_msm_every_window_width(oracle, window):
     """Same inputs through different bucket widths (developer override) give the same bytes."""
