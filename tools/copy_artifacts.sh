@@ -16,4 +16,5 @@ grep -v "amdgpu.ids" $F/msm_skew.txt > profiles/${R}_msm_skew.txt
 grep -v "amdgpu.ids" $F/soak.txt > profiles/${R}_soak.txt
 grep -v "amdgpu.ids" $F/host_path.txt > profiles/${R}_host_path.txt
 grep -v "amdgpu.ids" $F/hbm_priced_ops.txt > profiles/${R}_hbm_priced_ops.txt
+[ -f $F/route_stress.txt ] && grep -v "amdgpu.ids" $F/route_stress.txt > profiles/${R}_route_stress.txt
 tools/resource_usage.sh > profiles/${R}_resource_usage.txt 2>/dev/null

@@ -26,5 +26,7 @@ timeout 600 python3 tools/host_path_bench.py > "$out/host_path.txt" 2>&1
 timeout 600 python3 tools/hbm_ops_bench.py 22 > "$out/hbm_priced_ops.txt" 2>&1
 timeout 900 python3 tools/soak.py 22 3 > "$out/soak.txt" 2>&1
 echo "soak: $(grep -c bit-exact "$out/soak.txt") bit-exact, $(grep -c MISMATCH "$out/soak.txt") mismatches"
+timeout 600 python3 tools/route_stress.py 200 5 > "$out/route_stress.txt" 2>&1
+echo "route stress: $(tail -1 "$out/route_stress.txt")"
 rm -rf "$out/msmtrace" "$out"/pmc/pmc[0-9] "$out"/pmc/stats "$out"/pmc_ops20/pmc[0-9]
 echo done

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the size-dependent routes: every operation that picks a kernel or a launch shape by batch size
+is run at random sizes around its thresholds on both routes (developer overrides force the other one) and the bytes are
+compared; a sample of each result also goes to the oracle.  Test infrastructure (the oracle is the checker).
+  variable base (Encodings / Elements):  one quad of lanes per element  |  one lane per element      D377_SMALL_MAX
+  MSM (Elements / Encodings):            one quad per point, no buckets |  Pippenger                  D377_MSM_SMALL_MAX
+  fixed base:                            2 workgroups per CU, K = 8     |  3 per CU, K = 16           D377_FB_SETS / D377_FB_K
+usage: python tools/route_stress.py [rounds=40] [seed=1]   -> summary lines, exit 1 on any mismatch"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import decaf377_amd as d  # noqa: E402
+from _oracle import Oracle  # noqa: E402
+
+
+class Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update({k: str(v) for k, v in self.kv.items()})
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    orc = Oracle(native=True)
+    ctx = d.Context([0])
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rnd = lambda n: torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    one_gen = cus * 64
+    bad = 0
+    nmax = 5 * one_gen
+    r0, k = rnd(nmax), rnd(nmax)
+    enc_all = ctx.encode_to_curve(r0)
+    enc_all[3::97, 31] |= 0x80                                     # invalid encodings sprinkled in
+    valid_all = ctx.encode_to_curve(rnd(nmax))
+    P_all, _ = ctx.decompress(valid_all)
+
+    def sizes(lo, hi, marks):
+        s = [int(v) for v in rng.integers(lo, hi, rounds)]
+        for m in marks:
+            s += [m - 1, m, m + 1]
+        return sorted(set(v for v in s if v >= 1))
+
+    # variable base, both forms
+    cnt = 0
+    for n in sizes(1, 3 * one_gen, [16, one_gen, 7 * cus * 16, 8 * cus * 16]):
+        with Env(D377_SMALL_MAX=10**9):
+            q = ctx.scalar_mul_var(enc_all[:n], k[:n])
+            qe = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
+        with Env(D377_SMALL_MAX=0):
+            l = ctx.scalar_mul_var(enc_all[:n], k[:n])
+            le_ = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
+        ok = torch.equal(q[0], l[0]) and torch.equal(q[1], l[1]) and torch.equal(qe, le_)
+        sel = np.unique(rng.integers(0, n, 6))
+        o, st = orc.scalar_mul_var(enc_all[:n][sel].cpu().numpy(), k[:n][sel].cpu().numpy())
+        ok = ok and (q[0][sel].cpu().numpy() == o).all() and (q[1][sel].cpu().numpy() == st).all()
+        bad += 0 if ok else 1
+        cnt += 1
+        if not ok:
+            print("MISMATCH variable base n = %d" % n, flush=True)
+    print("variable base: %d sizes in [1, %d], quads == lanes == oracle sample: %s" % (cnt, 3 * one_gen, "ok" if not bad else "FAILED"), flush=True)
+
+    # MSM, both input forms
+    bad0, cnt = bad, 0
+    for n in sizes(1, 5 * one_gen, [16, 17, 128 * 16, one_gen]):
+        with Env(D377_MSM_SMALL_MAX=10**9):
+            a = bytes(ctx.msm(P_all[:n], k[:n])[0])
+            ae = ctx.msm(enc_all[:n], k[:n])
+        with Env(D377_MSM_SMALL_MAX=0):
+            b = bytes(ctx.msm(P_all[:n], k[:n])[0])
+            be = ctx.msm(enc_all[:n], k[:n])
+        ok = a == b and bytes(ae[0]) == bytes(be[0]) and torch.equal(torch.as_tensor(ae[2]), torch.as_tensor(be[2]))
+        if n <= 300:
+            ok = ok and a == bytes(orc.msm(P_all[:n].cpu().numpy(), k[:n].cpu().numpy())[0])
+        bad += 0 if ok else 1
+        cnt += 1
+        if not ok:
+            print("MISMATCH msm n = %d" % n, flush=True)
+    print("msm: %d sizes in [1, %d], quads == buckets (Elements and Encodings, statuses too), oracle below 300 points: %s"
+          % (cnt, 5 * one_gen, "ok" if bad == bad0 else "FAILED"), flush=True)
+
+    # fixed base around the wide-launch threshold (and small sizes)
+    bad0, cnt = bad, 0
+    big = rnd((2 << 20) + 70000)
+    for n in sizes(1, 200000, []) [: rounds // 2] + sizes((2 << 20) - 60000, (2 << 20) + 60000, [2 << 20])[: rounds // 2 + 3]:
+        with Env(D377_FB_SETS=2, D377_FB_K=8):
+            a = ctx.scalar_mul_base(big[:n])
+        with Env(D377_FB_SETS=3, D377_FB_K=16):
+            b = ctx.scalar_mul_base(big[:n])
+        c = ctx.scalar_mul_base(big[:n])
+        ok = torch.equal(a, b) and torch.equal(a, c)
+        sel = np.unique(rng.integers(0, n, 6))
+        ok = ok and (a[sel].cpu().numpy() == orc.scalar_mul_base(big[:n][sel].cpu().numpy())).all()
+        bad += 0 if ok else 1
+        cnt += 1
+        if not ok:
+            print("MISMATCH fixed base n = %d" % n, flush=True)
+    print("fixed base: %d sizes (small, and around 2^21), narrow == wide == default == oracle sample: %s" % (cnt, "ok" if bad == bad0 else "FAILED"), flush=True)
+    print("ROUTE_STRESS_%s" % ("OK" if bad == 0 else "FAILED"))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
