@@ -168,9 +168,12 @@ int d377_batch_to_affine(d377_ctx* ctx, const uint64_t* xyzt, size_t n, uint64_t
 
 /* Element::vartime_multiscalar_mul(scalars, points) = sum_i scalar_i * point_i
  *                                                 src/ark_curve/element/projective.rs:99-117
- * (a fold of scalar multiplications in the reference; a Pippenger bucket MSM here).  The sum is
- * returned as its canonical Encoding (enc32_out, 32 bytes) and, if xyzt_out != NULL, as one
- * Element record (some extended representative of the same group element).
+ * (a fold of scalar multiplications in the reference; here a Pippenger bucket MSM, and for batches small enough to
+ * give every point four lanes -- up to 64 per compute unit, 16384 on an MI355X -- one scalar multiplication per point
+ * followed by a tree sum).  The sum is returned as its canonical Encoding (enc32_out, 32 bytes) and, if xyzt_out !=
+ * NULL, as one Element record (some extended representative of the same group element).  Element records are read
+ * as the extended coordinates they are (T Z = X Y, as every Element the reference or this library produces has
+ * them); a record with Z = 0 is no group element and counts as the identity.
  * d377_msm takes in-memory Elements; d377_msm_encoded takes Encodings, reports invalid ones in
  * status[] and leaves them out of the sum.  n < 2^31.  With a multi-GPU context each device sums a
  * contiguous slice and the partial sums are added on the first device. */
