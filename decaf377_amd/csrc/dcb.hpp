@@ -1,0 +1,132 @@
+// dcb.hpp -- the chunked kernels' shared machinery (device only): lane sets of the per-device scratch areas claimed by
+// workgroups, the round records of the batched inversions, and the walk of a workgroup through its chunks.
+// Used by the batch kernels of d377.hip and by the MSM's decoding pass (msm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "curve.hpp"
+#include "device_util.hpp"
+
+namespace d377 {
+
+// Lane sets and elements per inversion are per kernel: every chunked kernel runs WAVES_PER_SIMD workgroups per CU with
+// DCB_K elements per lane, except the fixed-base multiplication (FB_SETS, FB_K: see k_scalar_mul_base).  The scratch
+// layout is sized for the largest of each and is the same for all of them.
+constexpr int DCB_KMAX = 16;
+constexpr int FB_SETS = 3, FB_K = 16;
+constexpr size_t FB_WIDE_MIN = (size_t)2 << 20;   // elements from which the fixed-base kernel takes FB_SETS / FB_K
+constexpr int DCB_SETS_MAX = FB_SETS > WAVES_PER_SIMD ? FB_SETS : WAVES_PER_SIMD;
+static_assert(DCB_K <= DCB_KMAX && FB_K <= DCB_KMAX, "the scratch layout has DCB_KMAX record rows per slot");
+
+// Round storage of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish): [5 slots][DCB_KMAX][lanes] 32-byte
+// records in global scratch, so that a wave reads and writes 2 KiB contiguous.  Slots 0..3: the denominators of the
+// round's square roots / their inverses, later the compressor's state; slot 4: prefix products.  The compressor
+// parks its prefix products in the output records of the elements they belong to.
+//
+// The areas (these records, the variable-base window tables) exist once per RESIDENT lane -- 2 workgroups per CU --
+// but the grid is oversubscribed: a workgroup takes one chunk of DCB_K x 256 consecutive elements (DCB_K per lane)
+// and there are as many workgroups as chunks.  Measured at 2^22 variable-base elements: 64.2 ms with exactly the
+// resident workgroups walking 32 elements per lane each, 61.4 ms with four generations of workgroups of 8 per lane,
+// although the latter pays four times as many inversions (profiles/README.md).  A workgroup therefore claims one of
+// the area's `nslots` lane sets when it starts (an atomic on a small pool) and frees it when it is done.  The launch
+// configuration keeps at most `nslots` workgroups of these kernels resident (d377_ctx_create checks it with the
+// occupancy query and pads a kernel's LDS allocation when its registers alone would let more in: chunk_kernels
+// below), so a free set normally exists; should residency ever exceed the sets -- two such kernels from different
+// streams sharing a CU -- the extra workgroup sleeps and retries until a holder, which never waits on anything,
+// finishes.  Claims are atomic and nothing resets the pool between launches, so kernels from different streams
+// (a replayed hipGraph next to an eager call) can share the areas safely.
+struct DcbScratch {
+  uint8_t* rec;        // [DCB_SLOTS][DCB_KMAX][lanes] 32-byte records, lanes = all the lane sets of the device x BLOCK
+  int* pool;           // one flag per lane set, 0 = free (cleared once, at context creation; every workgroup frees what it claimed)
+  int nslots;          // the sets THIS kernel may claim: the first nslots (its resident workgroups: 2 or 3 per CU)
+  int per_lane;        // elements per lane in a chunk, 1 .. the kernel's K: smaller for small batches, so that the grid still fills the chip
+  int lanes;           // the layout's lane count: the same for every kernel, so a set is the same memory whoever claims it
+};
+struct DcbIO {
+  uint8_t* scratch;
+  uint8_t* out32;
+  size_t nlanes, lane, base;            // lane of the claimed set; the chunk's j-th element of this lane is record base + j * BLOCK
+  int slot, per_lane;
+  __device__ __forceinline__ size_t rec(int sl, int j) const { return (size_t)(sl * DCB_KMAX + j) * nlanes + lane; }
+  __device__ __forceinline__ void put(int sl, int j, const uint32_t w[8]) { store32(scratch, rec(sl, j), w); }
+  __device__ __forceinline__ void get(int sl, int j, uint32_t w[8]) const { load32(scratch, rec(sl, j), w); }
+  __device__ __forceinline__ void park(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * BLOCK, w); }
+  __device__ __forceinline__ void parked(int j, uint32_t w[8]) const { load32(out32, base + (size_t)j * BLOCK, w); }
+  __device__ __forceinline__ void emit(int j, const uint32_t w[8]) { store32(out32, base + (size_t)j * BLOCK, w); }
+};
+constexpr int DCB_SLOTS = 5;
+
+__device__ __forceinline__ int dcb_claim(const DcbScratch& sc) {
+  __shared__ int s_slot;
+  if (threadIdx.x == 0) {
+    int s = (int)(blockIdx.x % (unsigned)sc.nslots);
+    int tries = 0;
+    while (atomicCAS(&sc.pool[s], 0, 1) != 0) {
+      s = s + 1 == sc.nslots ? 0 : s + 1;
+      if (++tries >= sc.nslots) { __builtin_amdgcn_s_sleep(32); tries = 0; }    // a whole lap without a free set: back off
+    }
+    s_slot = s;
+  }
+  __syncthreads();
+  return s_slot;
+}
+__device__ __forceinline__ void dcb_release(const DcbScratch& sc, int slot) {
+  __syncthreads();                       // every lane of the workgroup is done with the set
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicExch(&sc.pool[slot], 0);
+  }
+}
+
+// A workgroup's walk through its chunks (normally one): phase 0 leaves the denominators of the chunk's square roots
+// in records 0 .. NINV-1, they are inverted together (one divsteps inversion per lane), phase 1 does the element's
+// work with those inverses, and when the operation ends in an encoding of a point whose isogeny preimage it knows
+// (FINISH) the square-root-free compressor closes the chunk.
+// phase1(i, j, inv, have): inv[s] = the eight words of 1 / (denominator s of element j) (fe_from_words makes them a field
+// element) when `have`; otherwise there are no inverses this launch: take the square roots in the reference's
+// inversion-free form.
+// A shared inversion costs ~26 000 instructions per lane plus 4 products per element; the chain it replaces in each
+// square root (den^(2^47-1), 46 S + 9 M) ~9 500: with fewer than DCB_ASSIST_MIN elements per lane the inversion loses,
+// and at those batch sizes (n <= 2 x the resident lanes) its latency is the whole call.  SMALL_OK = false keeps a
+// kernel on the always-assisted form (k_scalar_mul_var: its codegen is left exactly as it was measured).
+constexpr int DCB_ASSIST_MIN = 3;
+template <int NINV, bool FINISH, bool SMALL_OK = true, class PT, class P0, class P1>
+__device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1) {
+  constexpr int NW = NINV > 0 ? NINV : 1;
+  const int per_lane = io.per_lane;
+  const bool assist = NINV > 0 && (!SMALL_OK || per_lane >= DCB_ASSIST_MIN);      // uniform over the launch
+  const size_t CHUNK = (size_t)per_lane * BLOCK;
+  for (size_t chunk = blockIdx.x; chunk * CHUNK < n; chunk += gridDim.x) {
+    io.base = chunk * CHUNK + threadIdx.x;
+    int cnt = 0;
+#pragma unroll 1
+    for (int j = 0; j < per_lane; ++j) {
+      const size_t i = io.base + (size_t)j * BLOCK;
+      if (i >= n) break;
+      if (assist) phase0(i, j);
+      cnt = j + 1;
+    }
+    if (assist) {
+#pragma unroll 1
+      for (int sl = 0; sl < NINV; ++sl) dcb_invert_slot(io, sl, cnt);
+    }
+#pragma unroll 1
+    for (int j = 0; j < cnt; ++j) {
+      uint32_t cur[NW][8] = {};
+      if (assist) {
+#pragma unroll
+        for (int sl = 0; sl < NINV; ++sl) io.get(sl, j, cur[sl]);
+      }
+      phase1(io.base + (size_t)j * BLOCK, j, cur, assist);
+    }
+    if (FINISH) dcb_finish(pt, io, cnt);
+  }
+}
+#define D377_DCB_BEGIN(out_ptr)                                                                   \
+  const int dcb_slot_ = dcb_claim(dcb);                                                           \
+  DcbIO io{dcb.rec, reinterpret_cast<uint8_t*>(out_ptr), (size_t)dcb.lanes,                      \
+           (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_, dcb.per_lane}
+#define D377_DCB_END() dcb_release(dcb, dcb_slot_)
+
+}  // namespace d377

@@ -54,6 +54,17 @@ struct ScratchGuard {
   int drain() { if (used) HIP_TRY(hipEventSynchronize(ev)); return D377_OK; }   // before freeing the area
 };
 
+// Holds a scratch area for one launch: queues the launch behind the area's last user and records the hand-over event
+// on EVERY path out of the launch once the area has been acquired -- also when a later step of the launch fails, so
+// that the next user on another stream still queues behind whatever was enqueued.
+struct GuardScope {
+  ScratchGuard& g;
+  hipStream_t s;
+  bool held = false;
+  int acquire() { int rc = g.acquire(s); held = rc == D377_OK; return rc; }
+  ~GuardScope() { if (held) (void)g.release(s); }
+};
+
 // workspace of the multi-scalar multiplication (msm.hip), grow-only.  Once an MSM has been captured into a hipGraph the
 // graph holds pointers into the workspace it saw: from then on a workspace that is outgrown is retired (kept until the
 // context is destroyed) instead of freed, so a replay never touches freed memory.
@@ -68,7 +79,7 @@ struct MsmWorkspace {
 // chunk_sets[k] workgroups of kernel k may be resident per CU -- that is how many lane sets it may claim; d377_ctx_create checks
 // each with hipOccupancyMaxActiveBlocksPerMultiprocessor and pads the launch's LDS allocation for a kernel whose
 // registers and own LDS would let more in (chunk_lds, bytes of dynamic LDS per launch).
-enum ChunkKernel { CK_SQRT, CK_ENCODE, CK_HASH, CK_MUL_VAR, CK_MUL_BASE, CK_MUL_VAR_EL, CK_MAP_EL, CK_ENCODE_WIDE, CK_COUNT };
+enum ChunkKernel { CK_SQRT, CK_ENCODE, CK_HASH, CK_MUL_VAR, CK_MUL_BASE, CK_MUL_VAR_EL, CK_MAP_EL, CK_ENCODE_WIDE, CK_DECOMPRESS, CK_COUNT };
 
 struct DeviceState {
   int id = -1;
@@ -78,6 +89,7 @@ struct DeviceState {
   int chunk_sets[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};       // lane sets per CU the kernel may claim = the residency it is launched for
   int chunk_k[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};          // elements per lane per shared inversion
   int fb_narrow_lds = 0;                 // LDS padding of the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU)
+  int msm_enc_chunked = -1;              // msm.hip: may the chunked decoding pass run (its residency matches the lane sets)?  -1 = not asked yet
   int dcb_sets = 0;                      // lane sets of the round-record area and its pool (the largest chunk_sets x CUs)
   uint32_t* gtab = nullptr;
   uint8_t* s_lookup = nullptr;

@@ -374,6 +374,46 @@ def test_fixed_base_launch_shapes_agree(ctx, torch_mod, oracle):
     assert (wide[ti].cpu().numpy() == oracle.scalar_mul_base(k[ti].cpu().numpy())).all()
 
 
+def test_batched_inverse_decoding_from_2_21(ctx, torch_mod, oracle):
+    """From 2^21 elements `decompress` and the decoding pass of the Encoding-input MSM run in chunks with the square roots'
+    denominators inverted together (k_decompress_chunked, k_msm_prepare_enc_chunked).  Same bytes and statuses as the
+    one-lane-per-element kernels forced at the same size (developer overrides), invalid encodings of every kind sprinkled
+    in, a sample equal to the oracle's; ragged size, so that the last chunk is partial."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9107)
+    n = (1 << 21) + 4321
+    enc = ctx.encode_to_curve(torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g))
+    enc[7::1013, 31] |= 0x40                                      # top bits set
+    enc[11::2003, 0] |= 1                                         # negative s
+    enc[13::4001] = torch.randint(0, 256, enc[13::4001].shape, dtype=torch.uint8, device=dev, generator=g)   # raw strings
+    enc[17::5003] = 0                                             # the identity
+    k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    try:
+        P, st = ctx.decompress(enc)
+        m = ctx.msm(enc, k)
+        os.environ["D377_DECOMPRESS_CHUNKED_MIN"] = str(1 << 40)
+        os.environ["D377_MSM_ENC_CHUNKED_MIN"] = str(1 << 40)
+        P0, st0 = ctx.decompress(enc)
+        m0 = ctx.msm(enc, k)
+    finally:
+        os.environ.pop("D377_DECOMPRESS_CHUNKED_MIN", None)
+        os.environ.pop("D377_MSM_ENC_CHUNKED_MIN", None)
+    assert torch.equal(P, P0) and torch.equal(st, st0) and 0 < int(st.sum().item()) < n // 100
+    assert bytes(m[0]) == bytes(m0[0]) and torch.equal(torch.as_tensor(m[2]), torch.as_tensor(m0[2])) and torch.equal(torch.as_tensor(m[2]), st)
+    idx = np.unique(np.concatenate([np.arange(40), np.arange(7, n, 1013)[:20], np.arange(13, n, 4001)[:20], np.arange(n - 40, n)]))
+    ti = torch.from_numpy(idx).to(dev)
+    o_P, o_st = oracle.decompress(enc[ti].cpu().numpy())
+    assert (P[ti].cpu().numpy().view(np.uint64) == o_P).all() and (st[ti].cpu().numpy() == o_st).all()
+    # the sum itself: against the MSM of the decoded Elements with the invalid ones left out (zero scalars)
+    k2 = k.clone()
+    k2[st != 0] = 0
+    Pz = P.clone()
+    ident = torch.from_numpy(oracle.identity_xyzt().view(np.int64)).to(dev)
+    Pz[st != 0] = ident
+    assert bytes(ctx.msm(Pz, k2)[0]) == bytes(m[0])
+
+
 def test_full_size_hash_to_curve_two_routes_2_20(ctx, torch_mod, oracle):
     """hash_to_curve at BASELINE size by two routes that share no formula after the maps: the kernel's (the two points
     added on the Jacobi quartic, encoded without a square root) against the reference's own statement
