@@ -24,15 +24,15 @@ static_assert(DCB_K <= DCB_KMAX && FB_K <= DCB_KMAX, "the scratch layout has DCB
 // round's square roots / their inverses, later the compressor's state; slot 4: prefix products.  The compressor
 // parks its prefix products in the output records of the elements they belong to.
 //
-// The areas (these records, the variable-base window tables) exist once per RESIDENT lane -- 2 workgroups per CU --
-// but the grid is oversubscribed: a workgroup takes one chunk of DCB_K x 256 consecutive elements (DCB_K per lane)
+// The areas (these records, the variable-base window tables) exist once per RESIDENT lane -- 2 workgroups per CU, 3 for
+// the fixed-base kernel's wide launch -- but the grid is oversubscribed: a workgroup takes one chunk of DCB_K x 256 consecutive elements (DCB_K per lane)
 // and there are as many workgroups as chunks.  Measured at 2^22 variable-base elements: 64.2 ms with exactly the
 // resident workgroups walking 32 elements per lane each, 61.4 ms with four generations of workgroups of 8 per lane,
 // although the latter pays four times as many inversions (profiles/README.md).  A workgroup therefore claims one of
 // the area's `nslots` lane sets when it starts (an atomic on a small pool) and frees it when it is done.  The launch
 // configuration keeps at most `nslots` workgroups of these kernels resident (d377_ctx_create checks it with the
-// occupancy query and pads a kernel's LDS allocation when its registers alone would let more in: chunk_kernels
-// below), so a free set normally exists; should residency ever exceed the sets -- two such kernels from different
+// occupancy query and pads a kernel's LDS allocation when its registers alone would let more in: d377.hip
+// check_residency; msm.hip asks the same question for its decoding pass before it uses it), so a free set normally exists; should residency ever exceed the sets -- two such kernels from different
 // streams sharing a CU -- the extra workgroup sleeps and retries until a holder, which never waits on anything,
 // finishes.  Claims are atomic and nothing resets the pool between launches, so kernels from different streams
 // (a replayed hipGraph next to an eager call) can share the areas safely.
