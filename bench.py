@@ -30,6 +30,18 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def csrc_sha256():
+    """Identity of the kernel sources (the same hash tools/pmc_summarize.py stores in profiles/pmc_traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "decaf377_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 sys.path.insert(0, ROOT)
 
 # algorithmic bytes and reference-algorithm work per unit (SURVEY.md section 8d, DESIGN.md section 5)
@@ -328,8 +340,12 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            pmc = json.load(open(tpath)).get("k_scalar_mul_var") or {}
-            if pmc.get("elements") == n:
+            rec = json.load(open(tpath))
+            pmc = rec.get("k_scalar_mul_var") or {}
+            if rec.get("_sources", {}).get("csrc_sha256") != csrc_sha256():
+                # counters of other kernels than the ones that just ran are not replayed
+                pmc, traffic_source = {}, "stale: profiles/pmc_traffic.json was collected on different kernel sources (tools/collect_pmc.sh)"
+            elif pmc.get("elements") == n:
                 traffic = pmc["hbm_bytes_per_launch"]     # PMC counters of separate rocprofv3 passes, not of this run
                 traffic_source = "profiles/pmc_traffic.json (" + pmc.get("source", "rocprofv3 --pmc passes") + ")"
         except Exception:

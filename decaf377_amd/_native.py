@@ -29,7 +29,7 @@ EXPORTS = [
     "d377_batch_roundtrip_dev", "d377_batch_scalar_mul_base_dev", "d377_batch_scalar_mul_var_dev",
     "d377_batch_encode_to_curve_dev", "d377_batch_hash_to_curve_dev",
     "d377_batch_sqrt_ratio_zeta_ex", "d377_batch_sqrt_ratio_zeta_ex_dev", "d377_batch_sharded_dev",
-    "d377_ctx_invariant_failures", "d377_ctx_chunk_residency",
+    "d377_ctx_invariant_failures", "d377_ctx_chunk_residency", "d377_ctx_set_tuning", "d377_ctx_get_tuning",
     "d377_batch_scalar_mul_var_element", "d377_batch_scalar_mul_base_element", "d377_batch_compress_to_field",
     "d377_batch_encode_to_curve_element", "d377_batch_hash_to_curve_element",
     "d377_batch_scalar_mul_var_element_dev", "d377_batch_scalar_mul_base_element_dev", "d377_batch_compress_to_field_dev",
@@ -77,6 +77,10 @@ def load():
     lib.d377_ctx_invariant_failures.restype = i32
     lib.d377_ctx_chunk_residency.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.d377_ctx_chunk_residency.restype = i32
+    lib.d377_ctx_set_tuning.argtypes = [vp, i32, ctypes.c_int64]
+    lib.d377_ctx_set_tuning.restype = i32
+    lib.d377_ctx_get_tuning.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int64)]
+    lib.d377_ctx_get_tuning.restype = i32
     host = {
         "d377_batch_sqrt_ratio_zeta": [vp, vp, vp, sz, vp, vp],
         "d377_batch_decompress": [vp, vp, sz, vp, vp],

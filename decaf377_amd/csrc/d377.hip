@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtT
 // elements the chunked grid has no more workgroups than fit at once, the wide grid keeps the issue port fuller, and
 // they finish no sooner (measured, profiles/README.md).  From 2^21 elements -- several generations of chunks -- the
 // decompression does gain (5-8 %: k_decompress_chunked below); the compression gains 1-4 % and stays as it is.
-constexpr size_t DECOMPRESS_CHUNKED_MIN = (size_t)2 << 20;
+constexpr int DECOMPRESS_CHUNKED_GENERATIONS = 2;   // batches of at least this many generations of full chunks (x DCB_K x the resident lanes)
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
                                                       uint64_t* xyzt, uint8_t* status) {
   D377_POW_LDS();
@@ -821,10 +821,9 @@ namespace {
 // wave: seven waves per CU) runs 28 672 elements in one generation, two waves sharing most SIMDs -- 0.60 ms against 0.88
 // with one lane per element -- and the Encoding form (39 KiB: four waves per CU) two generations of 16 384 in 1.02 ms
 // against 1.08.  Beyond those sizes one lane per element is the better use of the chip (measured, profiles/README.md).
-// D377_SMALL_MAX: developer override (0 switches the small-batch kernel off).
+// D377_TUNE_SMALL_MAX: developer override (0 switches the small-batch kernel off).
 size_t small_batch_max(const DeviceState& d, bool element_form) {
-  if (const char* e = getenv("D377_SMALL_MAX")) return (size_t)strtoull(e, nullptr, 10);
-  return (size_t)d.cus * SMALL_QUADS * (element_form ? 7 : 8);
+  return (size_t)d.tuned(D377_TUNE_SMALL_MAX, (long long)d.cus * SMALL_QUADS * (element_form ? 7 : 8));
 }
 
 int grid_for(const DeviceState& d, size_t n) {
@@ -886,7 +885,7 @@ int check_residency(DeviceState& d) {
     if (nb < 1 || nb > sets)
       return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", names[k]);
   }
-  // the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU, below FB_WIDE_MIN elements): its own padding
+  // the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU, below FB_WIDE_GENERATIONS generations of full chunks): its own padding
   {
     const int pad = (160 * 1024) / (WAVES_PER_SIMD + 1) + 1024;
     int nb = 0;
@@ -986,6 +985,8 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     size_t per_lane = (n + resident - 1) / resident;
     if (per_lane > (size_t)kmax) per_lane = (size_t)kmax;
     if (per_lane < 1) per_lane = 1;
+    if (d.is_tuned(D377_TUNE_CHUNK_PER_LANE) && (long long)kmax >= d.tuned(D377_TUNE_CHUNK_PER_LANE, 1))
+      per_lane = (size_t)d.tuned(D377_TUNE_CHUNK_PER_LANE, 1);             // developer override (sweeps)
     size_t nchunks = (n + per_lane * BLOCK - 1) / (per_lane * BLOCK);
     if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
     grid = (int)nchunks;
@@ -1006,8 +1007,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     case OP_DECOMPRESS: {
       // several generations of chunks: the batched-inverse form (one box, alternating: 2^20 1.93-1.97 against 1.99 ms,
       // 2^21 3.76-3.90 against 4.14-4.18, 2^22 7.71-7.78 against 8.19, 2^23 15.2-15.6 against 16.5); below, the wide grid
-      size_t chunked_min = DECOMPRESS_CHUNKED_MIN;
-      if (const char* e = getenv("D377_DECOMPRESS_CHUNKED_MIN")) chunked_min = (size_t)strtoull(e, nullptr, 10);   // developer override (A/B)
+      // (the threshold is DECOMPRESS_CHUNKED_GENERATIONS full chunks per resident lane set: 2^21 elements on 256 CUs)
+      const size_t chunked_min = (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN,
+                                                 (long long)(d.resident_lanes() * DCB_K * DECOMPRESS_CHUNKED_GENERATIONS));
       if (n >= chunked_min) {
         if ((rc = vb.acquire())) return rc;
         hipLaunchKernelGGL(k_decompress_chunked, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_DECOMPRESS], s, T, (const uint8_t*)in0, n, (uint64_t*)out0,
@@ -1024,15 +1026,15 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
       break;
     case OP_MUL_BASE: {
-      // Wide launch (3 workgroups per CU, 16 elements per inversion) from FB_WIDE_MIN elements, where the chunks come in
+      // Wide launch (3 workgroups per CU, 16 elements per inversion) from FB_WIDE_GENERATIONS x DCB_K elements per resident lane (2^21 on 256 CUs), where the chunks come in
       // several generations; below, the narrow one (2 per CU, 8 per inversion) tiles the chip exactly at the sizes that
       // matter (2^20 elements = 512 chunks of 8 per lane on 512 places; on 768 places they are 683 of 6 per lane).
       // Measured, one box, alternating (profiles/README.md), narrow / wide: 2^20 1.13 / 1.06, 2^21 1.14 / 1.17,
       // 3 x 2^20 1.09-1.13 / 1.17-1.20, 2^22 1.08-1.13 / 1.19, 2^23 1.14 / 1.21 x 10^9 per s.
-      bool wide = n >= FB_WIDE_MIN;
-      int fk = wide ? FB_K : DCB_K;
-      if (const char* e = getenv("D377_FB_SETS")) wide = atoi(e) >= FB_SETS;                       // developer overrides (A/B)
-      if (const char* e = getenv("D377_FB_K")) { int v = atoi(e); if (v >= 1 && v <= DCB_KMAX) fk = v; }
+      // (FB_WIDE_GENERATIONS x DCB_K elements per resident lane: 2^21 on 256 CUs)
+      bool wide = n >= d.resident_lanes() * DCB_K * FB_WIDE_GENERATIONS;
+      if (d.is_tuned(D377_TUNE_FB_WIDE)) wide = d.tuned(D377_TUNE_FB_WIDE, 0) != 0;               // developer overrides (A/B)
+      const int fk = (int)d.tuned(D377_TUNE_FB_K, wide ? FB_K : DCB_K);
       int gb;
       DcbScratch db;
       chunks_of(wide ? FB_SETS : WAVES_PER_SIMD, fk, gb, db);
@@ -1084,10 +1086,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       // ~AFFINE_PER_LANE elements per lane so that one inversion serves many, but never fewer lanes than one
       // wave per SIMD.  Measured (tools/affine_bench.py, 2^20 elements): 0.28 / 0.40 / 0.65 / 1.14 ms at 1 / 2 / 4 / 8
       // blocks per CU -- every extra lane is an extra 380-operation inversion -- against 2.7 ms for one inversion
-      // per element.  D377_AFFINE_BLOCKS_PER_CU is a developer override for that sweep.
+      // per element.  D377_TUNE_AFFINE_BLOCKS_PER_CU is a developer override for that sweep.
       size_t lanes = (n + AFFINE_PER_LANE - 1) / AFFINE_PER_LANE;
-      size_t fill = (size_t)d.cus * BLOCK;
-      if (const char* e = getenv("D377_AFFINE_BLOCKS_PER_CU")) fill = (size_t)d.cus * (size_t)(atoi(e) > 0 ? atoi(e) : 1) * BLOCK;
+      const size_t fill = (size_t)d.cus * (size_t)d.tuned(D377_TUNE_AFFINE_BLOCKS_PER_CU, 1) * BLOCK;
       if (lanes < fill) lanes = fill < n ? fill : n;
       const int ga = (int)((lanes + BLOCK - 1) / BLOCK);
       hipLaunchKernelGGL(k_to_affine, dim3(ga), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
@@ -1441,6 +1442,7 @@ int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out) {
   ctx->devs.resize(ids.size());
   for (size_t k = 0; k < ids.size(); ++k) {
     ctx->devs[k].id = ids[k];
+    ctx->devs[k].tune = &ctx->tune;
     int rc = init_device(ctx->devs[k]);
     if (rc != D377_OK) {
       char saved[sizeof d377_g_err];
@@ -1488,6 +1490,41 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count) {
   *count = 0;
   return D377_OK;                             // not a checking build
 #endif
+}
+// key -> [lo, hi] of the values d377_ctx_set_tuning accepts (besides D377_TUNE_DEFAULT)
+static bool tuning_range(int key, long long* lo, long long* hi) {
+  const long long big = (long long)1 << 62;
+  switch (key) {
+    case D377_TUNE_SMALL_MAX: case D377_TUNE_MSM_SMALL_MAX: case D377_TUNE_DECOMPRESS_CHUNKED_MIN:
+    case D377_TUNE_MSM_ENC_CHUNKED_MIN: *lo = 0; *hi = big; return true;
+    case D377_TUNE_FB_WIDE: case D377_TUNE_MSM_CHUNKED_SUMS: *lo = 0; *hi = 1; return true;
+    case D377_TUNE_FB_K: *lo = 1; *hi = DCB_KMAX; return true;
+    case D377_TUNE_AFFINE_BLOCKS_PER_CU: *lo = 1; *hi = 64; return true;
+    case D377_TUNE_MSM_WINDOW: *lo = 4; *hi = 16; return true;
+    case D377_TUNE_MSM_SEG: *lo = 1; *hi = 128; return true;
+    case D377_TUNE_MSM_SLICES: *lo = 1; *hi = 4096; return true;
+    case D377_TUNE_MSM_RED: *lo = 2; *hi = 64; return true;
+    case D377_TUNE_MSM_SKIP: *lo = 1; *hi = 64; return true;
+    case D377_TUNE_CHUNK_PER_LANE: *lo = 1; *hi = DCB_K; return true;
+  }
+  return false;
+}
+int d377_ctx_set_tuning(d377_ctx* ctx, int key, int64_t value) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  long long lo, hi;
+  if (!tuning_range(key, &lo, &hi)) return fail(D377_ERR_ARG, "%s", "unknown D377_TUNE_* key");
+  if (value != D377_TUNE_DEFAULT && (value < lo || value > hi)) return fail(D377_ERR_ARG, "%s", "tuning value outside the key's range");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->tune.v[key] = value;
+  return D377_OK;
+}
+int d377_ctx_get_tuning(d377_ctx* ctx, int key, int64_t* value) {
+  if (!ctx || !value) return fail(D377_ERR_ARG, "%s", "null argument");
+  long long lo, hi;
+  if (!tuning_range(key, &lo, &hi)) return fail(D377_ERR_ARG, "%s", "unknown D377_TUNE_* key");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  *value = ctx->tune.v[key];
+  return D377_OK;
 }
 int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int* max_blocks_per_cu, int* lds_pad_bytes) {
   if (!ctx || dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "bad context or device index");

@@ -15,7 +15,7 @@ namespace d377 {
 // layout is sized for the largest of each and is the same for all of them.
 constexpr int DCB_KMAX = 16;
 constexpr int FB_SETS = 3, FB_K = 16;
-constexpr size_t FB_WIDE_MIN = (size_t)2 << 20;   // elements from which the fixed-base kernel takes FB_SETS / FB_K
+constexpr int FB_WIDE_GENERATIONS = 2;            // generations of full narrow chunks from which the fixed-base kernel takes FB_SETS / FB_K
 constexpr int DCB_SETS_MAX = FB_SETS > WAVES_PER_SIMD ? FB_SETS : WAVES_PER_SIMD;
 static_assert(DCB_K <= DCB_KMAX && FB_K <= DCB_KMAX, "the scratch layout has DCB_KMAX record rows per slot");
 

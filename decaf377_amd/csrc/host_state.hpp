@@ -9,6 +9,7 @@
 
 #include "../../include/decaf377_amd.h"
 #include "curve.hpp"
+#include "device_util.hpp"
 
 extern thread_local char d377_g_err[512];
 
@@ -79,6 +80,14 @@ struct MsmWorkspace {
 // chunk_sets[k] workgroups of kernel k may be resident per CU -- that is how many lane sets it may claim; d377_ctx_create checks
 // each with hipOccupancyMaxActiveBlocksPerMultiprocessor and pads the launch's LDS allocation for a kernel whose
 // registers and own LDS would let more in (chunk_lds, bytes of dynamic LDS per launch).
+// Developer tuning (d377_ctx_set_tuning): one value per D377_TUNE_* key, D377_TUNE_DEFAULT = the built-in rule.  Lives in
+// the context, written and read under d377_ctx::mu (every launch path holds it); nothing on a call path reads the
+// process environment.
+struct Tuning {
+  int64_t v[D377_TUNE_COUNT];
+  Tuning() { for (int k = 0; k < D377_TUNE_COUNT; ++k) v[k] = D377_TUNE_DEFAULT; }
+};
+
 enum ChunkKernel { CK_SQRT, CK_ENCODE, CK_HASH, CK_MUL_VAR, CK_MUL_BASE, CK_MUL_VAR_EL, CK_MAP_EL, CK_ENCODE_WIDE, CK_DECOMPRESS, CK_COUNT };
 
 struct DeviceState {
@@ -114,6 +123,13 @@ struct DeviceState {
   size_t shard_cap[4] = {0, 0, 0, 0};
   hipEvent_t ev_shard = nullptr;
   MsmWorkspace msm;
+  const Tuning* tune = nullptr;          // the owning context's overrides
+  // the override for `key`, or `dflt` when the built-in rule is in force
+  long long tuned(int key, long long dflt) const { return (tune && tune->v[key] >= 0) ? tune->v[key] : dflt; }
+  bool is_tuned(int key) const { return tune && tune->v[key] >= 0; }
+  // lanes the chunked kernels keep resident (WAVES_PER_SIMD workgroups of BLOCK lanes per CU): the unit the batch-size
+  // thresholds of the launch rules are written in, so that they follow the device's CU count
+  size_t resident_lanes() const { return (size_t)cus * WAVES_PER_SIMD * BLOCK; }
   SqrtTables tables() const { return SqrtTables{gtab, s_lookup, inv_fail}; }
 };
 
@@ -164,4 +180,5 @@ int debug_device_delay_ms();
 struct d377_ctx {
   std::vector<d377::DeviceState> devs;
   std::mutex mu;
+  d377::Tuning tune;
 };

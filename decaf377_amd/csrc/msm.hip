@@ -120,7 +120,7 @@ k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, s
 // The same in chunks with the square roots' denominators inverted together (dcb.hpp; as k_scalar_mul_var and
 // k_decompress_chunked decode their points): 5-8 % fewer cycles per decompression once the chunks come in several
 // generations, which is where msm_launch uses it.
-constexpr size_t MSM_ENC_CHUNKED_MIN = (size_t)2 << 20;
+constexpr int MSM_ENC_CHUNKED_GENERATIONS = 2;      // from this many generations of full chunks (x DCB_K x the resident lanes: 2^21 points on 256 CUs)
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, int c, int W,
                           uint32_t* pts, int16_t* digits, uint8_t* status, DcbScratch dcb) {
@@ -961,29 +961,25 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // digits spread over the same 2^(c-1) buckets as the signed digits of the other windows.  A ragged
 // top window (e.g. c = 16: 11 significant bits) would pile n / 2^11 points on each of a few
 // buckets and leave single lanes summing runs 16 times longer than everyone else's.
-int pick_window(size_t n) {
-  // Measured on one MI355X (D377_MSM_WINDOW sweep, Elements, whole call), 4 / 6 / 7 / 9 / 12 bits: 2^8 points 608 / 551 /
+int pick_window(const DeviceState& d, size_t n) {
+  // Measured on one MI355X (D377_TUNE_MSM_WINDOW sweep, Elements, whole call), 4 / 6 / 7 / 9 / 12 bits: 2^8 points 608 / 551 /
   // 556 / 543 / 544 us, 2^12: 657 / 607 / 599 / 578 / 577, 2^14: 739 / 683 / 671 / 622 / 587, 2^16: 1020 / 866 / 803 / 745 /
   // 686; 12 against 14 bits: 2^18 977 / 1007, 2^19 1310 / 1331, 2^20 2055 / 1985 us.  Since the bucket sums are a tree of
   // bit-sums (two kernels whose depth is the window width) a wide window costs little even when most of its buckets are
   // empty, and fewer windows are fewer additions per point and fewer chains side by side (the Horner doublings are 252
   // either way).  So: 12 bits below 2^20 points, 14 from there.
-  int c = n >= ((size_t)1 << 20) ? 14 : 12;
-  const char* env = getenv("D377_MSM_WINDOW");                // developer override for tests
-  if (env) { int v = atoi(env); if (v >= 4 && v <= 16) c = v; }   // >= 4: at most 63 windows (k_msm_final's table of cached sums)
-  return c;
+  const int c = n >= ((size_t)1 << 20) ? 14 : 12;
+  return (int)d.tuned(D377_TUNE_MSM_WINDOW, c);              // developer override: 4 .. 16 (>= 4: at most 63 windows, k_msm_final's table of cached sums)
 }
 
-// Points per segment lane.  Measured on one MI355X (D377_MSM_SEG sweep, whole MSM, Elements): 2^20 points 2.12 / 2.15 /
+// Points per segment lane.  Measured on one MI355X (D377_TUNE_MSM_SEG sweep, whole MSM, Elements): 2^20 points 2.12 / 2.15 /
 // 2.26 / 2.64 ms and 2^22 points 6.70 / 6.62 / 6.71 / 6.97 ms with 16 / 32 / 64 / 128 -- once a group of one partial is
 // copied instead of added to the identity, more and shorter segments cost little afterwards and balance the last
 // generation of lanes better.  Small batches take 8: the longest serial chain is what such a call waits for.
 int pick_seg(const DeviceState& d, size_t n, int W) {
-  (void)d;
   const size_t adds = n * (size_t)W;
-  int seg = adds >= ((size_t)1 << 26) ? 32 : adds >= ((size_t)1 << 22) ? 16 : 8;
-  if (const char* e = getenv("D377_MSM_SEG")) { int v = atoi(e); if (v >= 1 && v <= MAX_SEG) seg = v; }   // developer override (sweeps)
-  return seg;
+  const int seg = adds >= ((size_t)1 << 26) ? 32 : adds >= ((size_t)1 << 22) ? 16 : 8;
+  return (int)d.tuned(D377_TUNE_MSM_SEG, seg);               // developer override (sweeps): 1 .. MAX_SEG
 }
 
 int grid_of(const DeviceState& d, size_t n) {
@@ -1019,11 +1015,8 @@ int msm_reserve(DeviceState& d, hipStream_t s, size_t bytes, MsmHeld& held) {
   return D377_OK;
 }
 
-// Batches up to this many points skip the buckets (k_msm_small).  D377_MSM_SMALL_MAX: developer override (0 = never).
-size_t msm_small_max(const DeviceState& d) {
-  if (const char* e = getenv("D377_MSM_SMALL_MAX")) return (size_t)strtoull(e, nullptr, 10);
-  return (size_t)d.cus * 4 * MS_QUADS;
-}
+// Batches up to this many points skip the buckets (k_msm_small).  D377_TUNE_MSM_SMALL_MAX: developer override (0 = never).
+size_t msm_small_max(const DeviceState& d) { return (size_t)d.tuned(D377_TUNE_MSM_SMALL_MAX, (long long)d.cus * 4 * MS_QUADS); }
 
 int msm_launch_small(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,
                      uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
@@ -1045,7 +1038,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
                uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
   if (n >= ((size_t)1 << 31)) return fail(D377_ERR_ARG, "%s", "msm: n must be below 2^31");
   if (n && n <= msm_small_max(d) && n < ((size_t)1 << 24)) return msm_launch_small(d, s, encoded, pts_in, scalars, n, enc_out, xyzt_out, status);
-  const int c = pick_window(n);
+  const int c = pick_window(d, n);
   const int W = (252 + c - 1) / c;
   const int nb = (1 << (c - 1)) + 1;                         // bucket indices 0 .. 2^(c-1)
   const int nchunks = (nb - 1 + CHUNK - 1) / CHUNK;
@@ -1055,8 +1048,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   // slices per window of the counting sort: enough workgroups to cover the chip, never less than 8192 points each
   // (W * S <= the 2 workgroups of 1024 threads a CU holds: with one more slice per window, 18 x 29 = 522 workgroups on 512
   // places, the count and level-1 placement kernels ran a second generation for ten workgroups)
-  int S = (int)((size_t)2 * d.cus / (size_t)W);
-  if (const char* e = getenv("D377_MSM_SLICES")) { int v = atoi(e); if (v >= 1 && v <= 4096) S = v; }   // developer override (sweeps)
+  int S = (int)d.tuned(D377_TUNE_MSM_SLICES, (long long)((size_t)2 * d.cus / (size_t)W));   // developer override (sweeps): 1 .. 4096
   if ((size_t)S > (n + 8191) / 8192) S = (int)((n + 8191) / 8192);
   if (S < 1) S = 1;
   const size_t per = (n + (size_t)S - 1) / (size_t)S;
@@ -1079,8 +1071,8 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   // further levels of the bucket reduction: groups of partials, then groups of those (never more than this many); every
   // level is launched and decides on the device whether it has anything to do (k_msm_scan1, lvlmax)
   RedSizes red = RED_DEFAULT;
-  if (const char* e = getenv("D377_MSM_RED")) { int v = atoi(e); if (v >= 2 && v <= 64) red.g[0] = v; }   // developer overrides (sweeps)
-  if (const char* e = getenv("D377_MSM_SKIP")) { int v = atoi(e); if (v >= 1 && v <= 64) red.skip = (uint32_t)v; }
+  red.g[0] = (int)d.tuned(D377_TUNE_MSM_RED, red.g[0]);       // developer overrides (sweeps): 2 .. 64, 1 .. 64
+  red.skip = (uint32_t)d.tuned(D377_TUNE_MSM_SKIP, red.skip);
   size_t max_g[REDUCE_LEVELS];
   size_t o_r[REDUCE_LEVELS];
   max_g[0] = max_segs; o_r[0] = o_par;
@@ -1097,7 +1089,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_f1 = carve((size_t)W * m2 * PT_WORDS * 4);
   // weighted bucket sums by the pairwise tree (c <= 14: every width pick_window chooses); wider windows -- developer
   // override only -- keep the chunked running sums
-  const bool tree = c <= 14 && getenv("D377_MSM_CHUNKED") == nullptr;
+  const bool tree = c <= 14 && d.tuned(D377_TUNE_MSM_CHUNKED_SUMS, 0) == 0;
   const int ws_m = c < WS_M ? c : WS_M;                      // >= 2: window widths start at 2
   const int ws_nblk = (nb + (1 << ws_m) - 1) >> ws_m;
   const size_t o_nodes = carve(tree ? (size_t)W * ws_nblk * (WS_M + 1) * PT_WORDS * 4 : 0);
@@ -1122,8 +1114,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
 
   if (n) {
     if (encoded) {
-      size_t chunked_min = MSM_ENC_CHUNKED_MIN;
-      if (const char* e = getenv("D377_MSM_ENC_CHUNKED_MIN")) chunked_min = (size_t)strtoull(e, nullptr, 10);   // developer override (A/B)
+      const size_t chunked_min = (size_t)d.tuned(D377_TUNE_MSM_ENC_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_K * MSM_ENC_CHUNKED_GENERATIONS));
       if (n >= chunked_min && d.msm_enc_chunked < 0) {
         // the chunked kernel claims lane sets of the scratch areas: only if its residency matches them (as d377_ctx_create
         // checks for the kernels of d377.hip); otherwise the wide kernel stays

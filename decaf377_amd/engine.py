@@ -43,6 +43,10 @@ FQM = ((4,), "u64")          # Fq as 4 Montgomery limbs
 AFF = ((8,), "u64")          # affine x, y
 FLAG = ((), "u8")            # one status / flag byte per element
 SQRT_ROOT = {"ark": 0, "arkworks": 0, "min_curve": 1}
+# D377_TUNE_* keys of d377_ctx_set_tuning (include/decaf377_amd.h, "Developer interface")
+TUNE_KEYS = {"small_max": 0, "decompress_chunked_min": 1, "fb_wide": 2, "fb_k": 3, "affine_blocks_per_cu": 4, "msm_window": 5,
+             "msm_seg": 6, "msm_small_max": 7, "msm_slices": 8, "msm_red": 9, "msm_skip": 10, "msm_chunked_sums": 11,
+             "msm_enc_chunked_min": 12, "chunk_per_lane": 13}
 SHARD_OPS = {"sqrt_ratio_zeta": 0, "decompress": 1, "compress": 2, "roundtrip": 3, "scalar_mul_base": 4,
              "scalar_mul_var": 5, "encode_to_curve": 6, "hash_to_curve": 7, "scalar_mul_var_element": 8,
              "scalar_mul_base_element": 9}
@@ -95,6 +99,33 @@ class Context:
         a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         _native.check(self._lib.d377_ctx_chunk_residency(self._h, dev, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return int(a.value), int(b.value), int(c.value)
+
+    def set_tuning(self, key, value=None):
+        """d377_ctx_set_tuning: developer override of one launch rule (TUNE_KEYS); value None restores the built-in rule."""
+        _native.check(self._lib.d377_ctx_set_tuning(self._h, TUNE_KEYS[key], -1 if value is None else int(value)))
+
+    def get_tuning(self, key):
+        v = ctypes.c_int64(0)
+        _native.check(self._lib.d377_ctx_get_tuning(self._h, TUNE_KEYS[key], ctypes.byref(v)))
+        return None if v.value < 0 else int(v.value)
+
+    def tuning(self, **kv):
+        """Context manager: the given overrides for the calls made inside, the previous values afterwards."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self):
+                self.old = {k: ctx.get_tuning(k) for k in kv}
+                for k, v in kv.items():
+                    ctx.set_tuning(k, v)
+                return ctx
+
+            def __exit__(self, *exc):
+                for k, v in self.old.items():
+                    ctx.set_tuning(k, v)
+                return False
+
+        return _Scope()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

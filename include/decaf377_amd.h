@@ -98,6 +98,45 @@ int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int
  * checks are compiled in, 0 (and *count = 0) in a normal build, negative on error. */
 int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
 
+/* Developer interface: launch-rule overrides.  The library picks kernels, chunk shapes and MSM parameters from the
+ * batch size and the device's CU count; these keys replace one rule each for A/B measurements and for tests that force
+ * a route over sizes that would not take it (every route gives the same bytes).  Values are validated, stored in the
+ * context, and read under its mutex by every later call on it (calls already enqueued keep what they were launched
+ * with); D377_TUNE_DEFAULT restores the built-in rule.  Nothing in the library reads the process environment on a call
+ * path (D377_DEBUG_* diagnostics at context creation and in the multi-device test hook aside).
+ *   SMALL_MAX              scalar_mul_var[_element]: batches up to this many elements take the quad-per-element kernel (0 = never)
+ *   DECOMPRESS_CHUNKED_MIN decompress: batches from this many elements decode with shared inversions
+ *   FB_WIDE                scalar_mul_base: 0 = narrow launch (2 workgroups per CU), 1 = wide (3 per CU) at every size
+ *   FB_K                   scalar_mul_base: elements per lane per shared inversion, 1..16
+ *   AFFINE_BLOCKS_PER_CU   to_affine: workgroups per CU that share the batch, >= 1
+ *   MSM_WINDOW             msm: window width in bits, 4..16
+ *   MSM_SEG                msm: points per segment lane, 1..128
+ *   MSM_SMALL_MAX          msm: batches up to this many points skip the buckets (0 = never)
+ *   MSM_SLICES             msm: slices per window of the counting sort, 1..4096
+ *   MSM_RED / MSM_SKIP     msm: group size of the second reduction level (2..64) / leftovers a bucket lane sums itself (1..64)
+ *   MSM_CHUNKED_SUMS       msm: 1 = weighted bucket sums by chunked running sums instead of the tree of bit-sums
+ *   MSM_ENC_CHUNKED_MIN    msm_encoded: batches from this many points decode with shared inversions
+ *   CHUNK_PER_LANE         chunked kernels (sqrt_ratio_zeta, encode_to_curve[_wide], hash_to_curve, scalar_mul_var): elements per lane per chunk, 1..8
+ * Returns D377_ERR_ARG for an unknown key or a value outside its range. */
+#define D377_TUNE_SMALL_MAX 0
+#define D377_TUNE_DECOMPRESS_CHUNKED_MIN 1
+#define D377_TUNE_FB_WIDE 2
+#define D377_TUNE_FB_K 3
+#define D377_TUNE_AFFINE_BLOCKS_PER_CU 4
+#define D377_TUNE_MSM_WINDOW 5
+#define D377_TUNE_MSM_SEG 6
+#define D377_TUNE_MSM_SMALL_MAX 7
+#define D377_TUNE_MSM_SLICES 8
+#define D377_TUNE_MSM_RED 9
+#define D377_TUNE_MSM_SKIP 10
+#define D377_TUNE_MSM_CHUNKED_SUMS 11
+#define D377_TUNE_MSM_ENC_CHUNKED_MIN 12
+#define D377_TUNE_CHUNK_PER_LANE 13
+#define D377_TUNE_COUNT 14
+#define D377_TUNE_DEFAULT (-1)
+int d377_ctx_set_tuning(d377_ctx* ctx, int key, int64_t value);
+int d377_ctx_get_tuning(d377_ctx* ctx, int key, int64_t* value);
+
 /* Fq::sqrt_ratio_zeta(num, den) -> (was_square, root)        src/ark_curve/invsqrt.rs:75-166
  * num32/den32: 32-byte strings reduced mod q like Fq::from_le_bytes_mod_order.
  * The crate's two backends return different roots (same flag, root negated about half the time):

@@ -350,26 +350,19 @@ def test_fixed_base_launch_shapes_agree(ctx, torch_mod, oracle):
     want = ctx.scalar_mul_base(k)
     idx = np.unique(np.concatenate([np.arange(40), np.arange(n - 300, n), np.arange(17, n, n // 61)]))
     assert (want[torch.from_numpy(idx).to(dev)].cpu().numpy() == oracle.scalar_mul_base(k[torch.from_numpy(idx).to(dev)].cpu().numpy())).all()
-    try:
-        for sets, kk in ((3, 16), (3, 8), (2, 16), (3, 5), (2, 1)):
-            os.environ["D377_FB_SETS"], os.environ["D377_FB_K"] = str(sets), str(kk)
+    for sets, kk in ((3, 16), (3, 8), (2, 16), (3, 5), (2, 1)):
+        with ctx.tuning(fb_wide=int(sets == 3), fb_k=kk):
             assert torch.equal(ctx.scalar_mul_base(k), want), (sets, kk)
             k2 = k.clone()
             ctx.scalar_mul_base(k2, outs=[k2])
             assert torch.equal(k2, want), (sets, kk)
-    finally:
-        os.environ.pop("D377_FB_SETS", None)
-        os.environ.pop("D377_FB_K", None)
+    assert ctx.get_tuning("fb_wide") is None and ctx.get_tuning("fb_k") is None
     # the default above the threshold against the narrow launch forced at the same size
     n = (3 << 20) + 4099
     k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
     wide = ctx.scalar_mul_base(k)
-    try:
-        os.environ["D377_FB_SETS"], os.environ["D377_FB_K"] = "2", "8"
+    with ctx.tuning(fb_wide=0, fb_k=8):
         assert torch.equal(ctx.scalar_mul_base(k), wide)
-    finally:
-        os.environ.pop("D377_FB_SETS", None)
-        os.environ.pop("D377_FB_K", None)
     ti = torch.from_numpy(np.arange(5, n, n // 53)).to(dev)
     assert (wide[ti].cpu().numpy() == oracle.scalar_mul_base(k[ti].cpu().numpy())).all()
 
@@ -389,16 +382,11 @@ def test_batched_inverse_decoding_from_2_21(ctx, torch_mod, oracle):
     enc[13::4001] = torch.randint(0, 256, enc[13::4001].shape, dtype=torch.uint8, device=dev, generator=g)   # raw strings
     enc[17::5003] = 0                                             # the identity
     k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
-    try:
-        P, st = ctx.decompress(enc)
-        m = ctx.msm(enc, k)
-        os.environ["D377_DECOMPRESS_CHUNKED_MIN"] = str(1 << 40)
-        os.environ["D377_MSM_ENC_CHUNKED_MIN"] = str(1 << 40)
+    P, st = ctx.decompress(enc)
+    m = ctx.msm(enc, k)
+    with ctx.tuning(decompress_chunked_min=1 << 40, msm_enc_chunked_min=1 << 40):
         P0, st0 = ctx.decompress(enc)
         m0 = ctx.msm(enc, k)
-    finally:
-        os.environ.pop("D377_DECOMPRESS_CHUNKED_MIN", None)
-        os.environ.pop("D377_MSM_ENC_CHUNKED_MIN", None)
     assert torch.equal(P, P0) and torch.equal(st, st0) and 0 < int(st.sum().item()) < n // 100
     assert bytes(m[0]) == bytes(m0[0]) and torch.equal(torch.as_tensor(m[2]), torch.as_tensor(m0[2])) and torch.equal(torch.as_tensor(m[2]), st)
     idx = np.unique(np.concatenate([np.arange(40), np.arange(7, n, 1013)[:20], np.arange(13, n, 4001)[:20], np.arange(n - 40, n)]))
@@ -482,15 +470,14 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
 def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
     """Batches that cannot fill the chip with one lane per element (up to 7 or 8 x 16 quads per CU) run one element per QUAD of
     lanes (d377.hip k_scalar_mul_var_small, quad_ops.hpp).  Same bytes as the one-lane-per-element kernel (forced with
-    D377_SMALL_MAX=0) at sizes around every edge of the quad kernel's grid -- invalid encodings, zero and extreme
+    the small_max tuning key) at sizes around every edge of the quad kernel's grid -- invalid encodings, zero and extreme
     scalars included -- and as the oracle; likewise the Element form (records in, records out)."""
     torch = torch_mod
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(4401)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     one_gen, el_max, enc_max = cus * 4 * 16, cus * 7 * 16, cus * 8 * 16       # one wave per SIMD; the two forms' thresholds
-    old = os.environ.pop("D377_SMALL_MAX", None)
-    try:
+    if True:
         for n in (1, 3, 16, 17, 1000, one_gen - 1, one_gen + 1, el_max, el_max + 1, enc_max, enc_max + 1):
             enc = oracle.encode_to_curve(rng.integers(0, 256, (min(n, 2048), 32), dtype=np.uint8))
             enc = np.tile(enc, ((n + enc.shape[0] - 1) // enc.shape[0], 1))[:n].copy()
@@ -499,10 +486,9 @@ def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
             for i, v in enumerate([0, 1, 2, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1][:n]):
                 k[i] = ibytes(v)
             te, tk = torch.from_numpy(enc).to(dev), torch.from_numpy(k).to(dev)
-            os.environ.pop("D377_SMALL_MAX", None)
             out_q, st_q = ctx.scalar_mul_var(te, tk)
-            os.environ["D377_SMALL_MAX"] = "0"
-            out_l, st_l = ctx.scalar_mul_var(te, tk)
+            with ctx.tuning(small_max=0):
+                out_l, st_l = ctx.scalar_mul_var(te, tk)
             assert torch.equal(out_q, out_l) and torch.equal(st_q, st_l), n
             sel = np.unique(np.concatenate([np.arange(min(n, 24)), np.arange(max(0, n - 24), n)]))
             o_out, o_st = oracle.scalar_mul_var(enc[sel], k[sel])
@@ -511,17 +497,12 @@ def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
             valid = torch.from_numpy(oracle.encode_to_curve(rng.integers(0, 256, (min(n, 512), 32), dtype=np.uint8))).to(dev)
             valid = valid.repeat((n + valid.shape[0] - 1) // valid.shape[0], 1)[:n].contiguous()
             P, _ = ctx.decompress(valid)
-            os.environ.pop("D377_SMALL_MAX", None)
             e_q = ctx.compress(ctx.scalar_mul_var_element(P, tk))
-            os.environ["D377_SMALL_MAX"] = "0"
-            e_l = ctx.compress(ctx.scalar_mul_var_element(P, tk))
+            with ctx.tuning(small_max=0):
+                e_l = ctx.compress(ctx.scalar_mul_var_element(P, tk))
             assert torch.equal(e_q, e_l), n
             want, _ = ctx.scalar_mul_var(valid, tk)
             assert torch.equal(e_q, want), n
-    finally:
-        os.environ.pop("D377_SMALL_MAX", None)
-        if old is not None:
-            os.environ["D377_SMALL_MAX"] = old
 
 
 def test_chunk_residency_is_checked(ctx):

@@ -50,17 +50,12 @@ def test_four_lane_group_operations_selftest():
 
 
 @pytest.fixture(params=["buckets", "quads"])
-def route(request):
+def route(request, ctx):
     """Both routes of the MSM on the same inputs: the bucket method (every size; forced here for the small ones too) and
     the one-quad-per-point kernel that small batches take by default (forced here for the larger test sizes too, where
     its grid no longer fits the chip at once and the partial sums take several trips)."""
-    old = os.environ.get("D377_MSM_SMALL_MAX")
-    os.environ["D377_MSM_SMALL_MAX"] = "0" if request.param == "buckets" else "1000000"
-    yield request.param
-    if old is None:
-        del os.environ["D377_MSM_SMALL_MAX"]
-    else:
-        os.environ["D377_MSM_SMALL_MAX"] = old
+    with ctx.tuning(msm_small_max=0 if request.param == "buckets" else 1000000):
+        yield request.param
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [0, 1, 2, 7, 15, 16, 17, 64, 257, 1000, 2049, 5000])
@@ -167,36 +162,26 @@ def test_msm_on_elements_from_every_producer(ctx, oracle):
     prod["sub"] = ctx.sub(prod["hash_to_curve_element"], base)
     prod["double"] = ctx.double(prod["add"])
     prod["neg"] = ctx.neg(prod["double"])
-    old = os.environ.get("D377_MSM_SMALL_MAX")
-    try:
-        for name, P in prod.items():
-            os.environ["D377_MSM_SMALL_MAX"] = "1000000"
+    for name, P in prod.items():
+        with ctx.tuning(msm_small_max=1000000):
             quads = ctx.msm(P, kk)
-            os.environ["D377_MSM_SMALL_MAX"] = "0"
+        with ctx.tuning(msm_small_max=0):
             buckets = ctx.msm(P, kk)
             assert bytes(quads[0]) == bytes(buckets[0]), name
             assert bytes(ctx.compress(quads[1].reshape(1, 16))[0]) == bytes(quads[0]), name
             encs = ctx.compress(P)
             assert bytes(ctx.msm(encs, kk)[0]) == bytes(quads[0]), name
-            os.environ["D377_MSM_SMALL_MAX"] = "1000000"
+        with ctx.tuning(msm_small_max=1000000):
             assert bytes(ctx.msm(encs, kk)[0]) == bytes(quads[0]), name
             assert bytes(ctx.msm(P[:40], kk[:40])[0]) == bytes(oracle.msm(np.asarray(P[:40]), kk[:40])[0]), name
-    finally:
-        if old is None:
-            os.environ.pop("D377_MSM_SMALL_MAX", None)
-        else:
-            os.environ["D377_MSM_SMALL_MAX"] = old
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("window", [4, 5, 6, 7, 9, 12, 14, 16])
-def test_msm_every_window_width(oracle, window):
+def test_msm_every_window_width(ctx, oracle, window):
     """Same inputs through different bucket widths (developer override) give the same bytes."""
-    import decaf377_amd as d
-    os.environ["D377_MSM_WINDOW"] = str(window)
-    os.environ["D377_MSM_SMALL_MAX"] = "0"                     # 3000 points would not reach the buckets otherwise
-    try:
-        c = d.Context([0])
+    c = ctx
+    with ctx.tuning(msm_window=window, msm_small_max=0):       # 3000 points would not reach the buckets otherwise
         rng = np.random.default_rng(702)
         n = 3000
         P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
@@ -206,10 +191,6 @@ def test_msm_every_window_width(oracle, window):
         k[2] = np.frombuffer(int("8" * 62, 16).to_bytes(32, "little"), np.uint8)
         enc, _, _ = c.msm(P, k)
         assert bytes(enc) == bytes(oracle.msm(P, k)[0])
-        c.close()
-    finally:
-        del os.environ["D377_MSM_WINDOW"]
-        del os.environ["D377_MSM_SMALL_MAX"]
 
 
 @pytest.mark.gpu

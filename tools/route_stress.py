@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the size-dependent routes: every operation that picks a kernel or a launch shape by batch size
-is run at random sizes around its thresholds on both routes (developer overrides force the other one) and the bytes are
+is run at random sizes around its thresholds on both routes (d377_ctx_set_tuning forces the other one) and the bytes are
 compared; a sample of each result also goes to the oracle.  Test infrastructure (the oracle is the checker).
-  variable base (Encodings / Elements):  one quad of lanes per element  |  one lane per element      D377_SMALL_MAX
-  MSM (Elements / Encodings):            one quad per point, no buckets |  Pippenger                  D377_MSM_SMALL_MAX
-  fixed base:                            2 workgroups per CU, K = 8     |  3 per CU, K = 16           D377_FB_SETS / D377_FB_K
+  variable base (Encodings / Elements):  one quad of lanes per element  |  one lane per element      small_max
+  MSM (Elements / Encodings):            one quad per point, no buckets |  Pippenger                  msm_small_max
+  fixed base:                            2 workgroups per CU, K = 8     |  3 per CU, K = 16           fb_wide / fb_k
 usage: python tools/route_stress.py [rounds=40] [seed=1]   -> summary lines, exit 1 on any mismatch"""
 import os
 import sys
@@ -17,22 +17,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 import decaf377_amd as d  # noqa: E402
 from _oracle import Oracle  # noqa: E402
-
-
-class Env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update({k: str(v) for k, v in self.kv.items()})
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def main():
@@ -63,10 +47,10 @@ def main():
     # variable base, both forms
     cnt = 0
     for n in sizes(1, 3 * one_gen, [16, one_gen, 7 * cus * 16, 8 * cus * 16]):
-        with Env(D377_SMALL_MAX=10**9):
+        with ctx.tuning(small_max=10**9):
             q = ctx.scalar_mul_var(enc_all[:n], k[:n])
             qe = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
-        with Env(D377_SMALL_MAX=0):
+        with ctx.tuning(small_max=0):
             l = ctx.scalar_mul_var(enc_all[:n], k[:n])
             le_ = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
         ok = torch.equal(q[0], l[0]) and torch.equal(q[1], l[1]) and torch.equal(qe, le_)
@@ -82,10 +66,10 @@ def main():
     # MSM, both input forms
     bad0, cnt = bad, 0
     for n in sizes(1, 5 * one_gen, [16, 17, 128 * 16, one_gen]):
-        with Env(D377_MSM_SMALL_MAX=10**9):
+        with ctx.tuning(msm_small_max=10**9):
             a = bytes(ctx.msm(P_all[:n], k[:n])[0])
             ae = ctx.msm(enc_all[:n], k[:n])
-        with Env(D377_MSM_SMALL_MAX=0):
+        with ctx.tuning(msm_small_max=0):
             b = bytes(ctx.msm(P_all[:n], k[:n])[0])
             be = ctx.msm(enc_all[:n], k[:n])
         ok = a == b and bytes(ae[0]) == bytes(be[0]) and torch.equal(torch.as_tensor(ae[2]), torch.as_tensor(be[2]))
@@ -102,9 +86,9 @@ def main():
     bad0, cnt = bad, 0
     big = rnd((2 << 20) + 70000)
     for n in sizes(1, 200000, []) [: rounds // 2] + sizes((2 << 20) - 60000, (2 << 20) + 60000, [2 << 20])[: rounds // 2 + 3]:
-        with Env(D377_FB_SETS=2, D377_FB_K=8):
+        with ctx.tuning(fb_wide=0, fb_k=8):
             a = ctx.scalar_mul_base(big[:n])
-        with Env(D377_FB_SETS=3, D377_FB_K=16):
+        with ctx.tuning(fb_wide=1, fb_k=16):
             b = ctx.scalar_mul_base(big[:n])
         c = ctx.scalar_mul_base(big[:n])
         ok = torch.equal(a, b) and torch.equal(a, c)
