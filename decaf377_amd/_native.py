@@ -30,6 +30,7 @@ EXPORTS = [
     "d377_batch_encode_to_curve_dev", "d377_batch_hash_to_curve_dev",
     "d377_batch_sqrt_ratio_zeta_ex", "d377_batch_sqrt_ratio_zeta_ex_dev", "d377_batch_sharded_dev",
     "d377_ctx_invariant_failures", "d377_ctx_chunk_residency", "d377_ctx_set_tuning", "d377_ctx_get_tuning",
+    "d377_ctx_health", "d377_ctx_reset_scratch", "d377_debug_poison_pool", "d377_ctx_peer_access",
     "d377_batch_scalar_mul_var_element", "d377_batch_scalar_mul_base_element", "d377_batch_compress_to_field",
     "d377_batch_encode_to_curve_element", "d377_batch_hash_to_curve_element",
     "d377_batch_scalar_mul_var_element_dev", "d377_batch_scalar_mul_base_element_dev", "d377_batch_compress_to_field_dev",
@@ -73,10 +74,18 @@ def load():
     lib.d377_ctx_destroy.restype = None
     lib.d377_ctx_num_devices.argtypes = [vp]
     lib.d377_ctx_device_id.argtypes = [vp, i32]
+    lib.d377_ctx_peer_access.argtypes = [vp, i32, i32]
+    lib.d377_ctx_peer_access.restype = i32
     lib.d377_ctx_invariant_failures.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
     lib.d377_ctx_invariant_failures.restype = i32
     lib.d377_ctx_chunk_residency.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.d377_ctx_chunk_residency.restype = i32
+    lib.d377_ctx_health.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.d377_ctx_health.restype = i32
+    lib.d377_ctx_reset_scratch.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    lib.d377_ctx_reset_scratch.restype = i32
+    lib.d377_debug_poison_pool.argtypes = [vp, i32, i32]
+    lib.d377_debug_poison_pool.restype = i32
     lib.d377_ctx_set_tuning.argtypes = [vp, i32, ctypes.c_int64]
     lib.d377_ctx_set_tuning.restype = i32
     lib.d377_ctx_get_tuning.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int64)]

@@ -475,6 +475,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var_el(con
                                                                              uint64_t* out, uint32_t* scratch, DcbScratch dcb) {
   // chunked like the kernels above (one workgroup per per_lane x 256 elements, a claimed set of window tables)
   const int slot = dcb_claim(dcb);
+  if (slot < 0) return;
   GlobalTab tab;
   tab.base = scratch;
   tab.nthreads = (size_t)dcb.nslots * BLOCK;
@@ -806,6 +807,13 @@ __global__ void __launch_bounds__(BLOCK) k_eq(const uint64_t* p, const uint64_t*
   }
 }
 
+// d377_ctx_reset_scratch: frees the lane sets whose tickets the host found unchanged (leaked by a launch that died)
+__global__ void k_pool_release(int* pool, const int* idx, const int* ticket, int m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) atomicCAS(&pool[idx[i]], ticket[i], 0);
+}
+constexpr int RESET_WAIT_MS = 1500;
+
 // ------------------------------------------------------------------------------ host side ---
 }  // namespace
 
@@ -934,6 +942,8 @@ int init_device(DeviceState& d) {
   HIP_TRY(hipMalloc(&d.dcb_scratch, (size_t)d.dcb_sets * BLOCK * DCB_SLOTS * DCB_KMAX * 32));
   HIP_TRY(hipMalloc(&d.slot_pool, (size_t)d.dcb_sets * sizeof(int)));
   HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.dcb_sets * sizeof(int), d.stream));      // every set free; workgroups free what they claim
+  HIP_TRY(hipMalloc(&d.pool_health, 4 * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(d.pool_health, 0, 4 * sizeof(uint32_t), d.stream));
   if ((rc = check_residency(d))) return rc;
   uint32_t* keys = nullptr;
   int* coll = nullptr;
@@ -952,7 +962,7 @@ void free_device(DeviceState& d) {
   if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
   (void)d.vb_guard.drain();
   (void)d.msm.guard.drain();
-  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.inv_fail);
+  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.pool_health); (void)hipFree(d.inv_fail);
   for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); (void)hipFree(d.shard[i]); }
   for (int i = 0; i < 2; ++i) {
     if (d.ev_in[i]) (void)hipEventDestroy(d.ev_in[i]);
@@ -980,17 +990,31 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
   // DCB_K elements per lane when the batch is large enough to fill the resident lane sets that way, fewer otherwise
   int gv = 0;
   DcbScratch dcb{};
+  // The batch in rounds of BLOCK elements over the `places` workgroups that are resident at once (cus x sets).  Up to
+  // kmax rounds per place everything runs in ONE generation, and the rounds are dealt out as evenly as they go: every
+  // workgroup takes rounds / places of them and the first rounds % places workgroups one more (DcbScratch::extra).
+  // (Chunks of ceil(n / resident lanes) elements per lane for everybody left a batch just above k x the resident lanes
+  // with fewer workgroups of k + 1 rounds each: pairs of them shared a CU while other CUs held one, and the call took
+  // as long as k + 1 full rounds -- profiles/r04_size_sweep.txt.)  Beyond that: chunks of kmax per lane, as many
+  // workgroups as chunks (oversubscribed on purpose, see DcbScratch).
   auto chunks_of = [&](int sets, int kmax, int& grid, DcbScratch& sc) {
-    const size_t resident = (size_t)d.cus * (size_t)sets * BLOCK;
-    size_t per_lane = (n + resident - 1) / resident;
-    if (per_lane > (size_t)kmax) per_lane = (size_t)kmax;
-    if (per_lane < 1) per_lane = 1;
-    if (d.is_tuned(D377_TUNE_CHUNK_PER_LANE) && (long long)kmax >= d.tuned(D377_TUNE_CHUNK_PER_LANE, 1))
-      per_lane = (size_t)d.tuned(D377_TUNE_CHUNK_PER_LANE, 1);             // developer override (sweeps)
-    size_t nchunks = (n + per_lane * BLOCK - 1) / (per_lane * BLOCK);
+    const size_t places = (size_t)d.cus * (size_t)sets;
+    const size_t rounds = (n + BLOCK - 1) / BLOCK;
+    size_t per_lane, extra = 0, nchunks;
+    if (d.is_tuned(D377_TUNE_CHUNK_PER_LANE)) {                             // developer override (sweeps, route tests): uniform chunks
+      per_lane = (size_t)d.tuned(D377_TUNE_CHUNK_PER_LANE, 1);
+      if (per_lane > (size_t)kmax) per_lane = (size_t)kmax;
+      nchunks = (rounds + per_lane - 1) / per_lane;
+    } else if (rounds <= places) {
+      per_lane = 1; nchunks = rounds;
+    } else if (rounds <= places * (size_t)kmax) {
+      per_lane = rounds / places; extra = rounds % places; nchunks = places;
+    } else {
+      per_lane = (size_t)kmax; nchunks = (rounds + per_lane - 1) / per_lane;
+    }
     if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
     grid = (int)nchunks;
-    sc = DcbScratch{d.dcb_scratch, d.slot_pool, d.cus * sets, (int)per_lane, d.dcb_sets * BLOCK};
+    sc = DcbScratch{d.dcb_scratch, d.slot_pool, d.cus * sets, (int)per_lane, d.dcb_sets * BLOCK, (int)extra, d.pool_health};
   };
   chunks_of(WAVES_PER_SIMD, DCB_K, gv, dcb);  // every chunked kernel but the fixed-base one
   GuardScope vb{d.vb_guard, s};            // released (event recorded) when this function returns, if it was acquired
@@ -1124,7 +1148,8 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       // at every batch size
       // (2^20 elements: 7.33e7/s with 8 per lane, 7.44 with 4, 7.59 with 2, 7.54 with 1)
       DcbScratch dv = dcb;
-      if (dv.per_lane > 2) dv.per_lane = 2;
+      dv.extra = 0;                                          // this kernel walks uniform chunks
+      dv.per_lane = n > d.resident_lanes() ? 2 : 1;
       size_t nch = (n + (size_t)dv.per_lane * BLOCK - 1) / ((size_t)dv.per_lane * BLOCK);
       if (nch > (size_t)d.cus * 64) nch = (size_t)d.cus * 64;
       if ((rc = vb.acquire())) return rc;
@@ -1159,7 +1184,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
   }
   HIP_TRY(hipGetLastError());
-  return D377_OK;
+  return vb.finish();
 }
 
 struct OpShape { size_t in0, in1, out0, out1; };   // bytes per element
@@ -1454,14 +1479,16 @@ int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out) {
     }
   }
   // peer access between the context's devices (xGMI): the sharded device-pointer path copies slices directly
+  ctx->peer.assign(ids.size() * ids.size(), 0);
   for (size_t a = 0; a < ids.size(); ++a)
     for (size_t b = 0; b < ids.size(); ++b) {
-      if (ids[a] == ids[b]) continue;
+      if (ids[a] == ids[b]) { ctx->peer[a * ids.size() + b] = 1; continue; }
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, ids[a], ids[b]) == hipSuccess && can) {
         (void)hipSetDevice(ids[a]);
         hipError_t e = hipDeviceEnablePeerAccess(ids[b], 0);
         if (e != hipSuccess) (void)hipGetLastError();      // already enabled is fine; copies fall back to staging otherwise
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ctx->peer[a * ids.size() + b] = 2;
       }
     }
   *out = ctx;
@@ -1526,6 +1553,100 @@ int d377_ctx_get_tuning(d377_ctx* ctx, int key, int64_t* value) {
   *value = ctx->tune.v[key];
   return D377_OK;
 }
+// ---- the lane-set pool's way back (dcb.hpp) ----
+static int read_pool(DeviceState& d, std::vector<int>& pool, uint32_t health[4]) {
+  pool.resize((size_t)d.dcb_sets);
+  HIP_TRY(hipMemcpyAsync(pool.data(), d.slot_pool, pool.size() * sizeof(int), hipMemcpyDeviceToHost, d.copy_stream));
+  HIP_TRY(hipMemcpyAsync(health, d.pool_health, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copy_stream));
+  HIP_TRY(hipStreamSynchronize(d.copy_stream));             // the copy stream is idle between host-path calls (they hold ctx->mu)
+  return D377_OK;
+}
+int d377_ctx_health(d377_ctx* ctx, int dev, int* sets_claimed, uint64_t* waited_long, uint64_t* gave_up) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceState& d = ctx->devs[(size_t)dev];
+  HIP_TRY(hipSetDevice(d.id));
+  std::vector<int> pool;
+  uint32_t h[4];
+  int rc = read_pool(d, pool, h);
+  if (rc) return rc;
+  int c = 0;
+  for (int v : pool) c += v != 0;
+  if (sets_claimed) *sets_claimed = c;
+  if (waited_long) *waited_long = h[1];
+  if (gave_up) *gave_up = h[2];
+  return D377_OK;
+}
+// Is anything this context enqueued (or was handed a stream for) still running on the device?
+static bool device_busy(DeviceState& d) {
+  if (hipStreamQuery(d.stream) == hipErrorNotReady) return true;
+  if (d.vb_guard.used && hipEventQuery(d.vb_guard.ev) == hipErrorNotReady) return true;
+  if (d.msm.guard.used && hipEventQuery(d.msm.guard.ev) == hipErrorNotReady) return true;
+  (void)hipGetLastError();
+  return false;
+}
+static bool wait_idle(DeviceState& d, int ms) {
+  const auto t0 = std::chrono::steady_clock::now();
+  while (device_busy(d)) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(ms)) return false;
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  return true;
+}
+int d377_ctx_reset_scratch(d377_ctx* ctx, int dev, int* sets_released) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceState& d = ctx->devs[(size_t)dev];
+  HIP_TRY(hipSetDevice(d.id));
+  if (sets_released) *sets_released = 0;
+  std::vector<int> before, after;
+  uint32_t h[4];
+  int rc;
+  if ((rc = read_pool(d, before, h))) return rc;
+  // 1. The normal case: whatever is in flight finishes (a chunk is milliseconds of work), and then no workgroup holds
+  //    anything: every claim still in the pool is a leak.
+  const bool idle = wait_idle(d, RESET_WAIT_MS);
+  if ((rc = read_pool(d, after, h))) return rc;
+  // 2. Work that does not finish is waiting for sets that never come back.  A set whose ticket did not change over
+  //    the whole wait has been held by one workgroup for longer than any chunk runs: a leak as well.  Those (and only
+  //    those) are freed, by compare-and-swap against the ticket, on the copy stream beside the waiting kernels.
+  std::vector<int> idx, val;
+  for (size_t i = 0; i < after.size(); ++i)
+    if (after[i] != 0 && (idle || after[i] == before[i])) { idx.push_back((int)i); val.push_back(after[i]); }
+  if (!idx.empty()) {
+    int *d_idx = nullptr, *d_val = nullptr;
+    HIP_TRY(hipMalloc(&d_idx, idx.size() * sizeof(int)));
+    if (hipMalloc(&d_val, val.size() * sizeof(int)) != hipSuccess) { (void)hipFree(d_idx); return fail(D377_ERR_HIP, "%s", "hipMalloc failed"); }
+    hipError_t e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, d.copy_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_val, val.data(), val.size() * sizeof(int), hipMemcpyHostToDevice, d.copy_stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_pool_release, dim3((unsigned)((idx.size() + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.copy_stream, d.slot_pool, d_idx, d_val,
+                         (int)idx.size());
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(d.copy_stream);
+    (void)hipFree(d_idx); (void)hipFree(d_val);
+    if (e != hipSuccess) return fail(D377_ERR_HIP, "reset_scratch: %s", hipGetErrorString(e));
+    if (sets_released) *sets_released = (int)idx.size();
+  }
+  if (!idle && !wait_idle(d, 10 * RESET_WAIT_MS))
+    return fail(D377_ERR_HIP, "%s", "reset_scratch: the device is still busy after the leaked lane sets were freed");
+  return D377_OK;
+}
+int d377_debug_poison_pool(d377_ctx* ctx, int dev, int sets) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceState& d = ctx->devs[(size_t)dev];
+  HIP_TRY(hipSetDevice(d.id));
+  if (sets < 0 || sets > d.dcb_sets) sets = d.dcb_sets;
+  if (!wait_idle(d, RESET_WAIT_MS)) return fail(D377_ERR_ARG, "%s", "poison_pool: the device is busy");
+  std::vector<int> v((size_t)sets, 0x7FFFFFFF);              // a ticket no workgroup will draw for a long time
+  if (sets) HIP_TRY(hipMemcpy(d.slot_pool, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+  return D377_OK;
+}
 int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int* max_blocks_per_cu, int* lds_pad_bytes) {
   if (!ctx || dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "bad context or device index");
   const DeviceState& d = ctx->devs[(size_t)dev];
@@ -1538,6 +1659,10 @@ int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int
   if (max_blocks_per_cu) *max_blocks_per_cu = mb;
   if (lds_pad_bytes) *lds_pad_bytes = pad;
   return D377_OK;
+}
+int d377_ctx_peer_access(const d377_ctx* ctx, int dev_a, int dev_b) {
+  if (!ctx || dev_a < 0 || dev_b < 0 || (size_t)dev_a >= ctx->devs.size() || (size_t)dev_b >= ctx->devs.size()) return -1;
+  return ctx->peer[(size_t)dev_a * ctx->devs.size() + (size_t)dev_b];
 }
 int d377_ctx_device_id(const d377_ctx* ctx, int dev) {
   if (!ctx || dev < 0 || (size_t)dev >= ctx->devs.size()) return -1;

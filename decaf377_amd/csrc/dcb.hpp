@@ -36,18 +36,28 @@ static_assert(DCB_K <= DCB_KMAX && FB_K <= DCB_KMAX, "the scratch layout has DCB
 // streams sharing a CU -- the extra workgroup sleeps and retries until a holder, which never waits on anything,
 // finishes.  Claims are atomic and nothing resets the pool between launches, so kernels from different streams
 // (a replayed hipGraph next to an eager call) can share the areas safely.
+//
+// A claim is the claiming workgroup's ticket (a serial number, never 0), so that the host can tell a set that one
+// workgroup has held for seconds -- leaked by a launch that died -- from sets that change hands (d377_ctx_reset_scratch).
+// A workgroup that finds no free set for DCB_STUCK_TICKS counts itself in health[1] and keeps waiting; after
+// DCB_GIVE_UP_TICKS it counts itself in health[2] and leaves without touching its elements, so that no launch spins
+// forever on a pool whose sets were leaked (d377_ctx_health reports both; outputs of such a launch are unwritten).
 struct DcbScratch {
   uint8_t* rec;        // [DCB_SLOTS][DCB_KMAX][lanes] 32-byte records, lanes = all the lane sets of the device x BLOCK
-  int* pool;           // one flag per lane set, 0 = free (cleared once, at context creation; every workgroup frees what it claimed)
+  int* pool;           // one word per lane set, 0 = free, else the holder's ticket (cleared at context creation; every workgroup frees what it claimed)
   int nslots;          // the sets THIS kernel may claim: the first nslots (its resident workgroups: 2 or 3 per CU)
   int per_lane;        // elements per lane in a chunk, 1 .. the kernel's K: smaller for small batches, so that the grid still fills the chip
   int lanes;           // the layout's lane count: the same for every kernel, so a set is the same memory whoever claims it
+  int extra;           // single-generation launches: the first `extra` workgroups take per_lane + 1 elements per lane (0: every chunk alike)
+  uint32_t* health;    // [0] ticket counter, [1] workgroups that waited DCB_STUCK_TICKS for a set, [2] workgroups that gave up
 };
+constexpr uint64_t DCB_STUCK_TICKS = 25000000ull;        // wall_clock64() ticks (100 MHz): 0.25 s
+constexpr uint64_t DCB_GIVE_UP_TICKS = 1000000000ull;    // 10 s
 struct DcbIO {
   uint8_t* scratch;
   uint8_t* out32;
   size_t nlanes, lane, base;            // lane of the claimed set; the chunk's j-th element of this lane is record base + j * BLOCK
-  int slot, per_lane;
+  int slot, per_lane, extra;
   __device__ __forceinline__ size_t rec(int sl, int j) const { return (size_t)(sl * DCB_KMAX + j) * nlanes + lane; }
   __device__ __forceinline__ void put(int sl, int j, const uint32_t w[8]) { store32(scratch, rec(sl, j), w); }
   __device__ __forceinline__ void get(int sl, int j, uint32_t w[8]) const { load32(scratch, rec(sl, j), w); }
@@ -57,14 +67,25 @@ struct DcbIO {
 };
 constexpr int DCB_SLOTS = 5;
 
+// -> the claimed set, or -1 when the workgroup gave up (every lane of the workgroup gets the same answer)
 __device__ __forceinline__ int dcb_claim(const DcbScratch& sc) {
   __shared__ int s_slot;
   if (threadIdx.x == 0) {
+    const int ticket = (int)(atomicAdd(&sc.health[0], 1u) & 0x7FFFFFFFu) + 1;
     int s = (int)(blockIdx.x % (unsigned)sc.nslots);
     int tries = 0;
-    while (atomicCAS(&sc.pool[s], 0, 1) != 0) {
+    uint64_t t0 = 0;
+    bool counted = false;
+    while (atomicCAS(&sc.pool[s], 0, ticket) != 0) {
       s = s + 1 == sc.nslots ? 0 : s + 1;
-      if (++tries >= sc.nslots) { __builtin_amdgcn_s_sleep(32); tries = 0; }    // a whole lap without a free set: back off
+      if (++tries >= sc.nslots) {                                                // a whole lap without a free set: back off
+        __builtin_amdgcn_s_sleep(32);
+        tries = 0;
+        const uint64_t now = wall_clock64();
+        if (t0 == 0) t0 = now;
+        if (!counted && now - t0 > DCB_STUCK_TICKS) { atomicAdd(&sc.health[1], 1u); counted = true; }
+        if (now - t0 > DCB_GIVE_UP_TICKS) { atomicAdd(&sc.health[2], 1u); s = -1; break; }
+      }
     }
     s_slot = s;
   }
@@ -94,11 +115,25 @@ constexpr int DCB_ASSIST_MIN = 3;
 template <int NINV, bool FINISH, bool SMALL_OK = true, class PT, class P0, class P1>
 __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1) {
   constexpr int NW = NINV > 0 ? NINV : 1;
+  // chunk c covers the elements from BLOCK x (c x per_lane + min(c, extra)): the first `extra` chunks are one round longer
+#ifdef D377_DCB_UNIFORM_AB                                                          // A/B only: round 3's loop (uniform chunks)
   const int per_lane = io.per_lane;
-  const bool assist = NINV > 0 && (!SMALL_OK || per_lane >= DCB_ASSIST_MIN);      // uniform over the launch
+  const bool assist = NINV > 0 && (!SMALL_OK || per_lane >= DCB_ASSIST_MIN);
   const size_t CHUNK = (size_t)per_lane * BLOCK;
   for (size_t chunk = blockIdx.x; chunk * CHUNK < n; chunk += gridDim.x) {
     io.base = chunk * CHUNK + threadIdx.x;
+#else
+  // (a launch with extra != 0 has as many workgroups as chunks: only a workgroup's first chunk can be a long one)
+  const bool longer = blockIdx.x < (unsigned)io.extra;
+  int per_lane = io.per_lane + (longer ? 1 : 0);
+  size_t first = ((size_t)blockIdx.x * (unsigned)io.per_lane + (longer ? blockIdx.x : (unsigned)io.extra)) * BLOCK;
+  // uniform over the launch (the compiler specialises the loop on it): shared inversions as soon as SOME workgroup has
+  // DCB_ASSIST_MIN elements per lane
+  const bool assist = NINV > 0 && (!SMALL_OK || io.per_lane + (io.extra != 0 ? 1 : 0) >= DCB_ASSIST_MIN);
+  for (unsigned chunk = blockIdx.x; first < n;
+       chunk += gridDim.x, per_lane = io.per_lane, first = ((size_t)chunk * (unsigned)io.per_lane + (unsigned)io.extra) * BLOCK) {
+    io.base = first + threadIdx.x;
+#endif
     int cnt = 0;
 #pragma unroll 1
     for (int j = 0; j < per_lane; ++j) {
@@ -125,8 +160,9 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
 }
 #define D377_DCB_BEGIN(out_ptr)                                                                   \
   const int dcb_slot_ = dcb_claim(dcb);                                                           \
+  if (dcb_slot_ < 0) return;                      /* no set for DCB_GIVE_UP_TICKS: counted in health[2] */ \
   DcbIO io{dcb.rec, reinterpret_cast<uint8_t*>(out_ptr), (size_t)dcb.lanes,                      \
-           (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_, dcb.per_lane}
+           (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_, dcb.per_lane, dcb.extra}
 #define D377_DCB_END() dcb_release(dcb, dcb_slot_)
 
 }  // namespace d377

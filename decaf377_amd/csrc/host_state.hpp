@@ -63,6 +63,9 @@ struct GuardScope {
   hipStream_t s;
   bool held = false;
   int acquire() { int rc = g.acquire(s); held = rc == D377_OK; return rc; }
+  // the success path hands over explicitly and reports a failed event record (the next user would not queue behind this
+  // launch); the destructor covers the error paths
+  int finish() { if (!held) return D377_OK; held = false; return g.release(s); }
   ~GuardScope() { if (held) (void)g.release(s); }
 };
 
@@ -105,7 +108,8 @@ struct DeviceState {
   uint32_t* fbase = nullptr;
   uint32_t* vb_scratch = nullptr;
   uint8_t* dcb_scratch = nullptr;        // round records of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish)
-  int* slot_pool = nullptr;              // which of the vb_blocks lane sets of the scratch areas are claimed (d377.hip, DcbScratch)
+  int* slot_pool = nullptr;              // which of the lane sets of the scratch areas are claimed, and by which ticket (dcb.hpp, DcbScratch)
+  uint32_t* pool_health = nullptr;       // ticket counter, workgroups that waited long for a set, workgroups that gave up (dcb.hpp)
   int vb_blocks = 0;
   uint32_t* inv_fail = nullptr;          // device counter of the -DD377_CHECK_INVARIANTS build (always allocated)
   ScratchGuard vb_guard;
@@ -181,4 +185,5 @@ struct d377_ctx {
   std::vector<d377::DeviceState> devs;
   std::mutex mu;
   d377::Tuning tune;
+  std::vector<int> peer;                  // [a][b]: 1 = the same physical device, 2 = peer access a -> b enabled by d377_ctx_create, 0 = none
 };

@@ -994,6 +994,7 @@ int grid_of(const DeviceState& d, size_t n) {
 // `held` releases it on every path out of the caller, error or not.
 struct MsmHeld {
   ScratchGuard& g; hipStream_t s; bool held;
+  int finish() { if (!held) return D377_OK; held = false; return g.release(s); }   // success path: a failed hand-over is an error
   ~MsmHeld() { if (held) (void)g.release(s); }
 };
 int msm_reserve(DeviceState& d, hipStream_t s, size_t bytes, MsmHeld& held) {
@@ -1030,7 +1031,7 @@ int msm_launch_small(DeviceState& d, hipStream_t s, bool encoded, const void* pt
   else hipLaunchKernelGGL(k_msm_small<false>, dim3((unsigned)m), dim3(MS_THREADS), 0, s, T, pts_in, scalars, n, partial, status);
   hipLaunchKernelGGL(k_msm_small_sum, dim3(1), dim3(MSS_THREADS), 0, s, T, partial, (int)m, enc_out, xyzt_out);
   HIP_TRY(hipGetLastError());
-  return D377_OK;
+  return held.finish();
 }
 
 // everything on device pointers, enqueued on `s`
@@ -1128,11 +1129,12 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
         if (per_lane > (size_t)DCB_K) per_lane = DCB_K;
         size_t nchunks = (n + per_lane * BLOCK - 1) / (per_lane * BLOCK);
         if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
-        const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)per_lane, d.dcb_sets * BLOCK};
+        const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)per_lane, d.dcb_sets * BLOCK, 0, d.pool_health};
         GuardScope vb{d.vb_guard, s};                       // the lane-set areas: queue behind their last user
         if ((rc = vb.acquire())) return rc;
         hipLaunchKernelGGL(k_msm_prepare_enc_chunked, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, c, W,
                            pts, dig, status, dcb);
+        if ((rc = vb.finish())) return rc;
       } else {
         hipLaunchKernelGGL(k_msm_prepare_enc, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, c, W, pts,
                            dig, status);
@@ -1194,7 +1196,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   }
   hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, T, cur_in, W, c, enc_out, xyzt_out);
   HIP_TRY(hipGetLastError());
-  return D377_OK;
+  return held.finish();
 }
 
 // one device's share of a host batch: copies in, MSM, partial sum (Element record) and statuses out, synchronised

@@ -100,6 +100,25 @@ class Context:
         _native.check(self._lib.d377_ctx_chunk_residency(self._h, dev, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def peer_access(self, a, b):
+        """d377_ctx_peer_access: 2 = distinct GPUs with peer access enabled, 1 = the same GPU listed twice, 0 = none."""
+        return int(self._lib.d377_ctx_peer_access(self._h, a, b))
+
+    def health(self, dev=0):
+        """(lane sets claimed now, workgroups that waited > 0.25 s for a set, workgroups that gave up): d377_ctx_health."""
+        a, b, c = ctypes.c_int(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _native.check(self._lib.d377_ctx_health(self._h, dev, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    def reset_scratch(self, dev=0):
+        """Frees lane sets leaked by a launch that died (d377_ctx_reset_scratch) -> how many it freed."""
+        a = ctypes.c_int(0)
+        _native.check(self._lib.d377_ctx_reset_scratch(self._h, dev, ctypes.byref(a)))
+        return int(a.value)
+
+    def _debug_poison_pool(self, dev=0, sets=-1):
+        _native.check(self._lib.d377_debug_poison_pool(self._h, dev, sets))
+
     def set_tuning(self, key, value=None):
         """d377_ctx_set_tuning: developer override of one launch rule (TUNE_KEYS); value None restores the built-in rule."""
         _native.check(self._lib.d377_ctx_set_tuning(self._h, TUNE_KEYS[key], -1 if value is None else int(value)))

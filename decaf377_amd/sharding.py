@@ -28,7 +28,8 @@ def _pad_rows(n, world):
 
 def scatter_records(full, n, row_shape, dtype, device, src=0, group=None):
     """Rank `src` holds `full` ([n, *row_shape]); every rank returns its shard_bounds slice.
-    Other ranks pass full=None.  Uses one dist.scatter of equal (padded) chunks."""
+    Other ranks pass full=None.  Uses one dist.scatter of equal chunks: views of `full` when n divides evenly over the
+    ranks (no copy on the root: the collective is all the step pays for), zero-padded copies otherwise."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     rows = _pad_rows(n, world)
@@ -36,12 +37,15 @@ def scatter_records(full, n, row_shape, dtype, device, src=0, group=None):
     chunks = None
     if rank == src:
         assert full is not None and full.shape[0] == n
-        chunks = []
-        for r in range(world):
-            lo, hi = shard_bounds(n, world, r)
-            c = torch.zeros((rows,) + tuple(row_shape), dtype=dtype, device=device)
-            c[: hi - lo] = full[lo:hi]
-            chunks.append(c)
+        if n % world == 0 and full.is_contiguous():
+            chunks = [full[r * rows:(r + 1) * rows] for r in range(world)]
+        else:
+            chunks = []
+            for r in range(world):
+                lo, hi = shard_bounds(n, world, r)
+                c = torch.zeros((rows,) + tuple(row_shape), dtype=dtype, device=device)
+                c[: hi - lo] = full[lo:hi]
+                chunks.append(c)
     dist.scatter(recv, chunks, src=src, group=group)
     lo, hi = shard_bounds(n, world, rank)
     return recv[: hi - lo]
@@ -54,6 +58,15 @@ def gather_records(local, n, dst=0, group=None):
     rows = _pad_rows(n, world)
     lo, hi = shard_bounds(n, world, rank)
     assert local.shape[0] == hi - lo
+    if n % world == 0:
+        # even shards: every rank sends its tensor as it is, and the root receives straight into the slices of the result
+        send = local.contiguous()
+        out = bufs = None
+        if rank == dst:
+            out = torch.empty((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            bufs = [out[r * rows:(r + 1) * rows] for r in range(world)]
+        dist.gather(send, bufs, dst=dst, group=group)
+        return out
     send = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     send[: hi - lo] = local
     bufs = None

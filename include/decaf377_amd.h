@@ -84,6 +84,10 @@ int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out);
 void d377_ctx_destroy(d377_ctx* ctx);
 int d377_ctx_num_devices(const d377_ctx* ctx);
 int d377_ctx_device_id(const d377_ctx* ctx, int dev);
+/* What d377_ctx_create arranged between two devices of the context: 2 = they are distinct GPUs and peer access
+ * dev_a -> dev_b (xGMI) was enabled, 1 = the same physical GPU listed twice, 0 = distinct GPUs without peer access
+ * (d377_batch_sharded_dev then relies on the runtime's staged copies), -1 = bad index. */
+int d377_ctx_peer_access(const d377_ctx* ctx, int dev_a, int dev_b);
 /* The lane-set scratch areas hold `sets_per_cu` sets per compute unit (3: the fixed-base kernel claims among all of
  * them, the other kernels among the first 2 per CU); d377_ctx_create asks the runtime
  * (hipOccupancyMaxActiveBlocksPerMultiprocessor) how many workgroups of each kernel that claims a set can be resident
@@ -91,6 +95,20 @@ int d377_ctx_device_id(const d377_ctx* ctx, int dev);
  * and fails with D377_ERR_INIT if one still exceeds them.  Reports the numbers it settled on: the largest residency over those
  * kernels (<= sets_per_cu) and the largest LDS padding in use (0 when none was needed).  Any pointer may be NULL. */
 int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int* max_blocks_per_cu, int* lds_pad_bytes);
+/* The lane-set pool's health and its way back.  Every workgroup of a chunked kernel claims one lane set of the scratch
+ * areas and frees it when it is done; a launch that dies mid-kernel (a fault in another kernel of the process, a killed
+ * graph) would leave its sets claimed for the life of the context.  Later launches then wait: a workgroup that finds
+ * no free set for 0.25 s is counted in *waited_long and keeps waiting; after 10 s it is counted in *gave_up and leaves
+ * WITHOUT writing its output records (so no launch can spin forever; a nonzero gave_up means outputs are missing).
+ * d377_ctx_health reports the sets claimed right now (0 on an idle device) and both counters since the context was created; it
+ * does not wait for running kernels.  d377_ctx_reset_scratch frees leaked sets: it waits (up to 1.5 s) for the work this
+ * context knows of, and frees every set still claimed then; if work is still running after the wait -- launches
+ * starved by the leak -- it frees exactly the sets whose holder did not change during the wait (no chunk runs that
+ * long) and waits for that work to finish.  *sets_released (may be NULL) = how many it freed; 0 on a healthy context.
+ * d377_debug_poison_pool marks `sets` sets (< 0: all) as claimed by nobody: the test hook for the two calls above. */
+int d377_ctx_health(d377_ctx* ctx, int dev, int* sets_claimed, uint64_t* waited_long, uint64_t* gave_up);
+int d377_ctx_reset_scratch(d377_ctx* ctx, int dev, int* sets_released);
+int d377_debug_poison_pool(d377_ctx* ctx, int dev, int sets);
 /* Debug builds (-DD377_CHECK_INVARIANTS, the counterpart of the reference's debug assertions in
  * Element::new, src/min_curve/element.rs:104-110, and is_on_curve, src/ark_curve/on_curve.rs:14-39): how many
  * group elements failed the curve equation / T Z = X Y / Z != 0 after decompression, the Elligator map or on

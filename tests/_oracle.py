@@ -25,6 +25,29 @@ def build_oracle():
     return LIB
 
 
+NATIVE_LIB = os.path.join(ORACLE_DIR, "libd377_oracle_native.so")
+
+
+def build_native():
+    """The -march=native copy for bench.py's cpu_baseline, built on THIS host.  -> path, or None without a compiler."""
+    import fcntl
+    try:
+        with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return NATIVE_LIB
+    except Exception:
+        return None
+
+
+def prebuild(native=False):
+    """Everything Oracle(...) would have to build, built now: callers that open the GPU later (bench.py) call this first and
+    then construct Oracle(build=False), which only loads what exists and never starts a program."""
+    build_oracle()
+    if native:
+        build_native()
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
@@ -40,21 +63,17 @@ class Oracle:
     OPS = {"roundtrip": 0, "scalar_mul_base": 1, "scalar_mul_var": 2, "encode_to_curve": 3, "sqrt_ratio_zeta": 4,
            "sqrt_ratio_zeta_min_curve": 5}
 
-    def __init__(self, native=False):
+    def __init__(self, native=False, build=True):
         """native=True: a copy built on THIS host with -march=native (bench.py's cpu_baseline on the GPU box);
-        falls back to the portable build when the compiler is not there."""
-        path = build_oracle()
+        falls back to the portable build when the compiler is not there.  build=False: load what prebuild() left, start
+        no program (for processes that have opened the GPU)."""
+        path = build_oracle() if build else LIB
         self.flags = "-O3 -march=x86-64-v3"
         if native:
-            try:
-                import fcntl
-                with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
-                    fcntl.flock(lock, fcntl.LOCK_EX)
-                    subprocess.check_call(["make", "-C", ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                path = os.path.join(ORACLE_DIR, "libd377_oracle_native.so")
+            npath = build_native() if build else (NATIVE_LIB if os.path.exists(NATIVE_LIB) else None)
+            if npath:
+                path = npath
                 self.flags = "-O3 -march=native (built on this host)"
-            except Exception:
-                pass
         self.lib = ctypes.CDLL(path)
         self.lib.d377o_init()
         self.lib.d377o_run_threads.restype = ctypes.c_int

@@ -34,6 +34,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=16)
     ap.add_argument("--devices", type=str, default="")
+    ap.add_argument("--require-distinct", action="store_true",
+                    help="fail unless the context spans >= 2 physical GPUs with peer access enabled between all of them")
     args = ap.parse_args()
     assert torch.cuda.is_available()
     G = torch.cuda.device_count()
@@ -57,6 +59,17 @@ def main():
 
     ctx = d.Context(ids)
     assert ctx.device_ids == ids
+    # what d377_ctx_create arranged between the context's devices (d377_ctx_peer_access): the lines of the library that
+    # only run between DISTINCT devices (hipDeviceEnablePeerAccess, hipMemcpyPeerAsync across ids, cross-device
+    # hipStreamWaitEvent in run_sharded_dev) are covered by this leg iff some pair reports 2
+    pairs = [(a, b, ctx.peer_access(a, b)) for a in range(len(ids)) for b in range(len(ids)) if a != b]
+    n_peer = sum(1 for _, _, v in pairs if v == 2)
+    print("peer access inside the context: %d of %d ordered pairs enabled, %d pairs are one GPU listed twice"
+          % (n_peer, len(pairs), sum(1 for _, _, v in pairs if v == 1)), flush=True)
+    if args.require_distinct:
+        if len(distinct) < 2 or n_peer != len(pairs):
+            print("REQUIRE_DISTINCT_FAILED devices=%s pairs=%s: the distinct-device paths were NOT exercised" % (ids, pairs), flush=True)
+            sys.exit(3)
     single = d.Context([distinct[0]])
     dev0 = torch.device("cuda", distinct[0])
     t0 = lambda x: torch.from_numpy(x).to(dev0)
@@ -133,7 +146,8 @@ def main():
     print("multi-device msm ok", flush=True)
     ctx.close()
     single.close()
-    print("CTX_LEG_OK devices=%s" % ids, flush=True)
+    print("CTX_LEG_OK devices=%s distinct_devices=%d peer_pairs_enabled=%d%s" %
+          (ids, len(distinct), n_peer, "" if n_peer else "  (same-device run: peer copies and cross-device events NOT covered)"), flush=True)
 
 
 if __name__ == "__main__":

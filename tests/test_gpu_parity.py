@@ -467,6 +467,102 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
         assert torch.equal(k2, fb), n
 
 
+def test_ragged_chunks_match_uniform_chunks(ctx, torch_mod, oracle):
+    """Batches of up to DCB_K rounds per resident workgroup run in one generation with the rounds dealt out evenly: the
+    first `rounds % places` workgroups take one round more than the others (d377.hip `chunks_of`, DcbScratch::extra),
+    and a workgroup decides by its own count whether it shares an inversion between its square roots.  Every chunked
+    operation gives the same bytes as with uniform chunks of 1, 2, 3 and 8 elements per lane forced through the tuning
+    call, at sizes that leave 1 .. places - 1 workgroups with the extra round (and a partial last round), and a
+    sample of them is the oracle's."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    places = torch.cuda.get_device_properties(0).multi_processor_count * 2
+    g = torch.Generator(device=dev).manual_seed(515)
+    sizes = [places * 256 + 1, places * 256 + 256 * 97 - 13, 2 * places * 256 + 255, 3 * places * 256 - 256 - 1,
+             (7 * places + 1) * 256 + 5, (3 * places + places // 2) * 256]
+    for n in sizes:
+        r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+        k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+        enc = ctx.encode_to_curve(r0)
+        enc[5::1009, 31] |= 0x80
+        want = {
+            "sqrt": ctx.sqrt_ratio_zeta(r0, k),
+            "encode": (enc,),
+            "hash": (ctx.hash_to_curve(r0, k),),
+            "var": ctx.scalar_mul_var(enc, k),
+            "base": (ctx.scalar_mul_base(k),),
+            "encode_el": (ctx.encode_to_curve_element(r0),),
+        }
+        for per_lane in (1, 2, 3, 8):
+            with ctx.tuning(chunk_per_lane=per_lane):
+                got = {
+                    "sqrt": ctx.sqrt_ratio_zeta(r0, k),
+                    "encode": (ctx.encode_to_curve(r0),),
+                    "hash": (ctx.hash_to_curve(r0, k),),
+                    "var": ctx.scalar_mul_var(enc, k),
+                    "base": (ctx.scalar_mul_base(k),),
+                    "encode_el": (ctx.encode_to_curve_element(r0),),
+                }
+            got["encode"][0][5::1009, 31] |= 0x80
+            for name in want:
+                for a, b in zip(want[name], got[name]):
+                    assert torch.equal(a, b), (name, n, per_lane)
+        idx = np.unique(np.concatenate([np.arange(40), np.arange(n - 300, n), np.arange(17, n, n // 61)]))
+        ti = torch.from_numpy(idx).to(dev)
+        o_root, o_sq = oracle.sqrt_ratio_zeta(r0[ti].cpu().numpy(), k[ti].cpu().numpy())
+        assert (want["sqrt"][0][ti].cpu().numpy() == o_root).all() and (want["sqrt"][1][ti].cpu().numpy() == o_sq).all(), n
+        o_out, o_st = oracle.scalar_mul_var(enc[ti].cpu().numpy(), k[ti].cpu().numpy())
+        assert (want["var"][0][ti].cpu().numpy() == o_out).all() and (want["var"][1][ti].cpu().numpy() == o_st).all(), n
+        assert (want["hash"][0][ti].cpu().numpy() == oracle.hash_to_curve(r0[ti].cpu().numpy(), k[ti].cpu().numpy())).all(), n
+        assert (want["base"][0][ti].cpu().numpy() == oracle.scalar_mul_base(k[ti].cpu().numpy())).all(), n
+
+
+def test_lane_set_pool_health_and_reset(torch_mod, oracle):
+    """The lane-set pool has a way back (dcb.hpp, d377_ctx_health / d377_ctx_reset_scratch).  A context of its own: every
+    set is marked as claimed by nobody (the debug hook: what a launch that died mid-kernel leaves behind), a chunked
+    operation is enqueued and starves -- its workgroups count themselves as having waited long, the health call sees
+    them without waiting for the kernel --, the reset frees exactly the leaked sets while the kernel is still waiting,
+    the kernel then runs to completion with the oracle's bytes, and the pool is empty afterwards."""
+    import time
+    import decaf377_amd as d
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    c = d.Context([0])
+    try:
+        sets_total = c.chunk_residency()[0] * torch.cuda.get_device_properties(0).multi_processor_count
+        assert c.health() == (0, 0, 0) and c.reset_scratch() == 0
+        g = torch.Generator(device=dev).manual_seed(77)
+        n = 70000
+        r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+        want = c.encode_to_curve(r0)
+        torch.cuda.synchronize()
+        c._debug_poison_pool()
+        assert c.health()[0] == sets_total
+        out = torch.zeros_like(want)
+        c.encode_to_curve(r0, outs=[out])                      # enqueued; every workgroup waits for a set
+        t0 = time.time()
+        while c.health()[1] == 0:
+            assert time.time() - t0 < 8.0, "no workgroup reported a long wait"
+            time.sleep(0.05)
+        assert c.health()[2] == 0                             # nobody has given up yet (10 s)
+        freed = c.reset_scratch()                              # waits 1.5 s, sees the same tickets, frees them, waits for the kernel
+        assert freed == sets_total, (freed, sets_total)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        claimed, waited, gave_up = c.health()
+        assert claimed == 0 and waited >= 1 and gave_up == 0
+        idx = np.arange(0, n, n // 50)
+        assert (out[torch.from_numpy(idx).to(dev)].cpu().numpy() == oracle.encode_to_curve(r0[torch.from_numpy(idx).to(dev)].cpu().numpy())).all()
+        # a partial leak: the operation still completes by itself (free sets remain), and the reset then finds the leaked ones
+        c._debug_poison_pool(sets=37)
+        assert torch.equal(c.encode_to_curve(r0), want)
+        torch.cuda.synchronize()
+        assert c.health()[0] == 37 and c.reset_scratch() == 37 and c.health()[0] == 0
+        assert torch.equal(c.scalar_mul_base(r0), c.scalar_mul_base(r0.clone()))
+    finally:
+        c.close()
+
+
 def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
     """Batches that cannot fill the chip with one lane per element (up to 7 or 8 x 16 quads per CU) run one element per QUAD of
     lanes (d377.hip k_scalar_mul_var_small, quad_ops.hpp).  Same bytes as the one-lane-per-element kernel (forced with
@@ -1380,8 +1476,8 @@ def test_bench_self_launches_its_ranks():
     import json
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
-                        "--steps", "2", "--warmup", "1", "--log2n", "16", "--no-cpu-baseline", "--no-extra"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+                        "--steps", "2", "--warmup", "1", "--log2n", "16"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -1389,6 +1485,18 @@ def test_bench_self_launches_its_ranks():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
     assert line["parity_sample_ok"] is True and line["parity_sample_per_rank"] == 256
     assert line["config"]["elements_total"] == 2 << 16 and line["value"] > 0
+    # one invocation carries everything a multi-GPU node can give: the weak headline, BASELINE configs[3] as written
+    # (2^log2n in total, and from rank 0 with the scatter / gather timed), configs[4] at its total size, the CPU leg
+    ex = line["extra"]
+    strong, root, ell = ex["strong_2^16_total"], ex["from_root"], ex["encode_to_curve_2^20_total"]
+    assert strong["elements_total"] == 1 << 16 and strong["elements_per_rank"] == [1 << 15, 1 << 15]
+    assert len(strong["kernel_ms_per_rank"]) == 2 and all(v > 0 for v in strong["kernel_ms_per_rank"]) and strong["value"] > 0
+    assert root["elements_total"] == 1 << 16 and root["collective_ms"] > 0 and root["parity_sample_ok"] and strong["parity_sample_ok"]
+    assert root["ms_per_step"] >= root["collective_ms"] and len(root["kernel_ms_per_rank"]) == 2
+    assert ell["elements_total"] == 1 << 16 and len(ell["kernel_ms_per_rank"]) == 2 and ell["parity_sample_ok"] and ell["value"] > 0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["matches_gpu_output"] is True and cb["value"] > 0 and cb["cores"] >= 1
+    assert line["roofline"]["kernel"] == "k_scalar_mul_var" and "encodes_per_sec" in ex
 
 
 def test_multigpu_selftest_tool():
@@ -1398,6 +1506,19 @@ def test_multigpu_selftest_tool():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multigpu_selftest.py"), "--log2n", "14"], cwd=ROOT,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "MULTIGPU_SELFTEST_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    # the log says what it did not cover, and --require-distinct turns that into a failure: a one-GPU log cannot pass for
+    # coverage of the peer copies / cross-device events of d377_batch_sharded_dev and d377_ctx_create
+    r2 = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+    if int(r2.stdout.strip().splitlines()[-1]) < 2:
+        assert "distinct_device_paths=NOT covered" in r.stdout and "peer_pairs_enabled=0" in r.stdout
+        r3 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multigpu_selftest.py"), "--log2n", "14", "--require-distinct"],
+                            cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r3.returncode == 3 and "MULTIGPU_SELFTEST_OK" not in r3.stdout, r3.stdout[-2000:]
+        r4 = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multigpu_worker.py"), "--log2n", "10", "--devices", "0,0",
+                             "--require-distinct"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r4.returncode == 3 and "REQUIRE_DISTINCT_FAILED" in r4.stdout, r4.stdout[-2000:]
+    else:
+        assert "distinct_device_paths=covered" in r.stdout
 
 
 def test_rccl_sharding_single_rank():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """First contact with a multi-GPU node: every multi-device path of the engine, exit code 0 only if all of it is right.
 
-    python tools/multigpu_selftest.py [--gpus G] [--log2n 16]
+    python tools/multigpu_selftest.py [--gpus G] [--log2n 16] [--require-distinct]
 
 This launcher never touches a GPU itself (a process that has opened the GPU must not start programs on this pool):
 it only starts the legs below as child processes and checks their exit codes.
@@ -76,16 +76,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=0, help="GPUs to use (default: all visible)")
     ap.add_argument("--log2n", type=int, default=16)
+    ap.add_argument("--require-distinct", action="store_true",
+                    help="exit non-zero unless every leg ran on >= 2 physical GPUs (a one-GPU run lists GPU 0 twice and "
+                         "covers slicing, staging and ordering, but no peer copy, no cross-device event, no RCCL transfer)")
     args = ap.parse_args()
     G = args.gpus or gpu_count()
     if G < 1:
         print("multigpu_selftest: no GPU visible")
         return 2
     print("multigpu_selftest: %d GPU(s)" % G, flush=True)
+    if args.require_distinct and G < 2:
+        print("multigpu_selftest: --require-distinct: only %d GPU visible -- the distinct-device paths cannot be covered here" % G)
+        return 3
     devs = ",".join(str(g) for g in range(G)) if G > 1 else "0,0"
 
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multigpu_worker.py"), "--log2n", str(args.log2n), "--devices", devs],
-                       cwd=ROOT, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multigpu_worker.py"), "--log2n", str(args.log2n), "--devices", devs]
+                       + (["--require-distinct"] if args.require_distinct else []), cwd=ROOT, timeout=1500)
     if r.returncode != 0:
         print("multigpu_selftest: leg 1 (one context over %s) FAILED rc=%d" % (devs, r.returncode))
         return 1
@@ -111,7 +117,7 @@ def main():
         print("multigpu_selftest: leg 3 line is wrong: %s" % lines[0])
         return 1
     print("leg 3 ok: %d ranks, %.3g scalar-mults/s, parity ok" % (want, line["value"]), flush=True)
-    print("MULTIGPU_SELFTEST_OK gpus=%d" % G)
+    print("MULTIGPU_SELFTEST_OK gpus=%d distinct_device_paths=%s" % (G, "covered" if G > 1 else "NOT covered (one GPU listed twice)"))
     return 0
 
 
