@@ -1,0 +1,239 @@
+// row_ops.hpp -- Fq arithmetic spread over the lanes of a DPP row (device only), for the chains nothing else runs beside.
+//
+// The tail of every multi-scalar multiplication is ONE dependency chain: ~250 doublings of a single point (msm.hip,
+// k_msm_final), whatever the batch size.  One lane per element (fq29.hpp) makes that chain 196 + 168 instructions per
+// product pair and leaves 63 lanes of the wave idle; four lanes per point (quad_ops.hpp) run the four products of a
+// round side by side, 521 instructions per doubling.  Here a field element lies ACROSS lanes -- limb j in lane j of a
+// 16-lane row -- so that the 100 limb products of one field product are 10 per lane, and the four rows of a wave
+// carry the four products of a round: ~100 instructions per product on the critical path instead of 196.
+//
+// Representation: 10 limbs of 28 bits (lanes 0..9 of the row; lanes 10..15 hold 0), PLAIN residues mod q -- no
+// Montgomery factor: the reduction is a fold of the product's high columns with the precomputed residues
+// FOLD[m] = 2^(28 (10 + m)) mod q, which has no serial digit chain (a Montgomery reduction produces its digits one
+// after the other: nine dependent steps, each a cross-lane broadcast).  Values are lazily reduced:
+//   tight   output of row_mul: limbs 0..8 < 2^28 + 2^12, limb 9 < 2^20 + 2^12     (value < 2^272.01)
+//   lazy    sums and differences of a few tight values: limbs 0..8 < 2^30.25, limb 9 < 2^24
+//   row_mul takes tight or lazy operands (every accumulator stays below 2^64: tools/row_model.py walks the worst case
+//   and runs the same steps on random operands against a * b mod q).
+// Semantics: the reference's Fq product / sum / difference (src/fields/fq/u64/wrapper.rs:99-132) on residues.
+//
+// Why 10 x 28 and not the 9 x 29 of fq29.hpp: 9 x 29 = 261 bits leave 8 bits above q, and the unreduced low half of a
+// product overhangs its top limb by ~35 bits, so every product would need three or four folds to come back under
+// 2^261; 280 bits leave 27: the fold of the high columns, one of the 36-bit overhang and one of the top limb's upper ten
+// bits (2^272 mod q) bring a product back under 2^272, which leaves the lazy sums 4 bits in every limb and 11 in the top one.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "curve.hpp"
+
+namespace d377 {
+namespace row {
+
+#include "row_constants.inc"
+
+constexpr int RL = 10, RW = 28;
+constexpr uint32_t M28 = (1u << RW) - 1u;
+
+// DPP moves inside a 16-lane row.  Lanes that would read outside the row get 0 (bound_ctrl).
+template <int N> __device__ __forceinline__ uint32_t bcast(uint32_t v) {       // every lane <- lane N of its row
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xF, 0xF, true);
+}
+template <int N> __device__ __forceinline__ uint32_t shr(uint32_t v) {         // lane j <- lane j - N (0 for j < N)
+  if (N == 0) return v;
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, true);
+}
+template <int N> __device__ __forceinline__ uint32_t shl(uint32_t v) {         // lane j <- lane j + N (0 beyond the row)
+  if (N == 0) return v;
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xF, 0xF, true);
+}
+
+// per-lane constants, loaded once per kernel
+struct RowK {
+  uint32_t fold[11];     // limb j of FOLD[m]
+  uint32_t f272;         // limb j of 2^272 mod q
+  uint32_t keep2;        // all ones for lanes 0..8, 2^20 - 1 for lane 9, 0 beyond
+  uint32_t keep;         // final carry passes: M28 for lanes 0..8, all ones for lane 9 (the top limb is not split), 0 beyond
+  uint32_t cmask;        // all ones for lanes 0..8 (they hand a carry up), 0 for lane 9 and beyond
+  uint32_t valid;        // all ones for lanes 0..9
+  uint32_t sub_tight, sub_lazy, one, k2d;
+};
+__device__ __forceinline__ RowK row_consts() {
+  const int j = threadIdx.x & 15;
+  RowK K;
+#pragma unroll
+  for (int m = 0; m < 11; ++m) K.fold[m] = ROW_FOLD[j][m];
+  K.f272 = ROW_F272[j];
+  K.keep2 = j < 9 ? 0xFFFFFFFFu : (j == 9 ? 0xFFFFFu : 0u);
+  K.keep = j < 9 ? M28 : (j == 9 ? 0xFFFFFFFFu : 0u);
+  K.cmask = j < 9 ? 0xFFFFFFFFu : 0u;
+  K.valid = j < 10 ? 0xFFFFFFFFu : 0u;
+  K.sub_tight = ROW_SUB_TIGHT[j]; K.sub_lazy = ROW_SUB_LAZY[j]; K.one = ROW_ONE[j]; K.k2d = ROW_2D[j];
+  return K;
+}
+
+// x = lo + 2^28 mid + 2^56 top  ->  lo_j + mid_(j-1) + top_(j-2): limbs < 2^29 + 2^8, the value unchanged
+__device__ __forceinline__ uint32_t split3(uint64_t x) {
+  const uint32_t lo = (uint32_t)x & M28, mid = (uint32_t)(x >> RW) & M28, top = (uint32_t)(x >> (2 * RW));
+  return lo + shr<1>(mid) + shr<2>(top);
+}
+
+// The cross-lane operands of the whole product are fetched first, each into a register of its own, and multiplied
+// afterwards: a DPP move whose destination was written by one of the two instructions before it costs wait states
+// (the destination is also its tied "old" operand), which is what register reuse inside a fetch-multiply-fetch sequence gives.
+template <int I> struct Fetch {
+  static __device__ __forceinline__ void run(uint32_t a, uint32_t b, uint32_t (&ai)[RL], uint32_t (&bl)[RL]) {
+    ai[I] = bcast<I>(a);
+    bl[I] = shr<I>(b);                                   // lane j: b_(j-i), so that a_i b_(j-i) belongs to column j
+    Fetch<I + 1>::run(a, b, ai, bl);
+  }
+};
+template <> struct Fetch<RL> { static __device__ __forceinline__ void run(uint32_t, uint32_t, uint32_t (&)[RL], uint32_t (&)[RL]) {} };
+template <int M> struct FoldFetch {
+  static __device__ __forceinline__ void run(uint32_t h, uint32_t (&hm)[11]) { hm[M] = bcast<M>(h); FoldFetch<M + 1>::run(h, hm); }
+};
+template <> struct FoldFetch<11> { static __device__ __forceinline__ void run(uint32_t, uint32_t (&)[11]) {} };
+
+// a * b mod q (lazily reduced: tight).  a, b: tight or lazy, lanes 10..15 zero.
+__device__ __forceinline__ uint32_t row_mul(uint32_t a, uint32_t b, const RowK& K) {
+  // The 19 columns of the product.  The row has 16 lanes, so lane j of L takes column j for ALL j = 0..15 (b's lanes
+  // 10..15 are zero: shr<i>(b) feeds lanes 10..15 exactly the terms of columns 10..15), and only columns 16, 17, 18 need
+  // a second accumulator: H, lanes 6..8, from the steps i = 7, 8, 9.
+  const int j = threadIdx.x & 15;
+  uint32_t ai[RL], bl[RL];
+  Fetch<0>::run(a, b, ai, bl);
+  const uint32_t bh7 = shl<3>(b), bh8 = shl<2>(b), bh9 = shl<1>(b);    // lane j: b_(j+10-i)
+  uint64_t L = 0;
+#pragma unroll
+  for (int i = 0; i < RL; ++i) L += (uint64_t)ai[i] * bl[i];
+  const uint64_t H = (uint64_t)ai[7] * bh7 + (uint64_t)ai[8] * bh8 + (uint64_t)ai[9] * bh9;   // lanes 6..8 count (lanes 0..5: strays)
+  // the high half, columns 10..18, as lanes 0..8
+  // (the moves stand outside the selects: a DPP move inside a conditional arm runs with the other lanes switched off, and a
+  // switched-off source lane reads as zero)
+  const uint32_t slo = shl<10>((uint32_t)L), shi = shl<10>((uint32_t)(L >> 32));
+  const uint32_t ulo = j < 6 ? slo : (uint32_t)H, uhi = j < 6 ? shi : (uint32_t)(H >> 32);
+  L = j < RL ? L : 0;
+  const uint32_t h = split3(((uint64_t)uhi << 32) | ulo);   // ... as limbs 0..10 of 2^280 x (...)
+  uint32_t hm[11];
+  FoldFetch<0>::run(h, hm);
+#pragma unroll
+  for (int m = 0; m < 11; ++m) L += (uint64_t)hm[m] * K.fold[m];   // L + sum_m h_m FOLD[m]: < 2^64 per lane
+  const uint32_t n = split3(L);                          // limbs 0..11; 10 and 11 overhang the representation
+  uint64_t R = (uint64_t)(n & K.valid);
+  R += (uint64_t)bcast<10>(n) * K.fold[0];
+  R += (uint64_t)bcast<11>(n) * K.fold[1];               // < 2^56: the value is below 2^283 now
+  const uint32_t f = ((uint32_t)R & K.keep) + shr<1>((uint32_t)(R >> RW) & K.cmask);     // < 2^29.5, limb 9 whole
+  const uint32_t t = bcast<9>(f) >> 20;                  // what the top limb holds above 2^272: ten bits
+  const uint64_t R3 = (uint64_t)(f & K.keep2) + (uint64_t)t * K.f272;
+  return ((uint32_t)R3 & K.keep) + shr<1>((uint32_t)(R3 >> RW) & K.cmask);
+}
+__device__ __forceinline__ uint32_t row_add(uint32_t a, uint32_t b) { return a + b; }
+// a - b for a TIGHT b (limbs 0..8 <= 2^28 + 8, limb 9 < 2^31)
+__device__ __forceinline__ uint32_t row_sub(uint32_t a, uint32_t b, const RowK& K) { return a + K.sub_tight - b; }
+// one carry pass: lazy -> tight-ish (limbs 0..8 <= 2^28 + 15), the value unchanged
+__device__ __forceinline__ uint32_t row_carry(uint32_t f, const RowK& K) { return (f & K.keep) + shr<1>((f >> RW) & K.cmask); }
+
+
+// ---- group elements on the four rows of a wave ---------------------------------------------------------------------
+// Row r of the wave holds coordinate r of the point (X, Y, Z, T), limb j in lane j of the row; the four products of a
+// round of the doubling / addition formulas run on the four rows.  Between the rounds the rows trade values with
+// v_permlane16_swap / v_permlane32_swap (gfx950):
+//   swap16(a, b) -> lo = (a0, b0, a2, b2), hi = (a1, b1, a3, b3)      (the rows of each result, from rows of a and b)
+//   swap32(a, b) -> lo = (a0, a1, b0, b1), hi = (a2, a3, b2, b3)
+struct RowPair { uint32_t lo, hi; };
+__device__ __forceinline__ RowPair swap16(uint32_t a, uint32_t b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  return RowPair{r[0], r[1]};
+}
+__device__ __forceinline__ RowPair swap32(uint32_t a, uint32_t b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  return RowPair{r[0], r[1]};
+}
+
+// Which row a lane belongs to, as masks: selections between per-row values are bitfield inserts (one VALU instruction,
+// no condition code, no branch for the compiler to build out of a conditional expression).
+struct RowSel {
+  int r, j;
+  uint32_t m0, m1, m2, m3;     // all ones in row 0 / 1 / 2 / 3
+  __device__ __forceinline__ static uint32_t pick(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+};
+__device__ __forceinline__ RowSel row_sel() {
+  RowSel S;
+  S.r = (threadIdx.x >> 4) & 3; S.j = threadIdx.x & 15;
+  S.m0 = S.r == 0 ? ~0u : 0u; S.m1 = S.r == 1 ? ~0u : 0u; S.m2 = S.r == 2 ? ~0u : 0u; S.m3 = S.r == 3 ? ~0u : 0u;
+  return S;
+}
+
+// -[2]P with the formulas of ge_double_neg / gq_double_neg (curve.hpp, quad_ops.hpp; the reference's doubling,
+// src/min_curve/element.rs:119-136, with E = 2XY taken as 2TZ and F, G, H sign-folded): v tight -> tight.
+__device__ __forceinline__ uint32_t rq_double_neg(uint32_t v, const RowSel& S, const RowK& K) {
+  const RowPair e = swap16(v, v);                                  // (X, X, Z, Z), (Y, Y, T, T)
+  const uint32_t m1 = row_mul(v, RowSel::pick(S.m3, e.lo, v), K);  // A = X^2, B = Y^2, Z^2, T Z
+  const RowPair q = swap16(m1, m1);                                // (A, A, ZZ, ZZ), (B, B, TZ, TZ)
+  const RowPair s = swap32(m1, m1);                                // (A, B, A, B), ...
+  const RowPair t = swap32(q.hi, q.hi);                            // (B, B, B, B), ...
+  const uint32_t pa = RowSel::pick(S.m0, m1, RowSel::pick(S.m1, q.lo, s.lo));   // A in rows 0, 1, 2
+  const uint32_t diff = pa + K.sub_tight - t.lo, sum = pa + t.lo;  // A - B, A + B
+  // G' = A - B, H' = A + B, F' = G' + 2 Z^2, E = 2 T Z
+  const uint32_t w = (RowSel::pick(S.m1, sum, diff) & ~S.m3) + ((m1 + m1) & (S.m2 | S.m3));
+  const RowPair a1 = swap16(w, w);                                 // (G', G', F', F'), (H', H', E, E)
+  const RowPair a2 = swap32(w, w);                                 // (G', H', G', H'), (F', E, F', E)
+  const RowPair a3 = swap32(a1.hi, a1.hi);                         // (H', H', H', H'), (E, E, E, E)
+  const uint32_t opa = RowSel::pick(S.m0, a3.hi, RowSel::pick(S.m1, a1.lo, w));   // E, G', F', E
+  const uint32_t opb = RowSel::pick(S.m0, a2.hi, RowSel::pick(S.m1, w, a2.lo));   // F', H', G', H'
+  return row_mul(opa, opb, K);                                     // E F', G' H', F' G', E H'
+}
+// P + Q or P - Q (neg_q, wave-uniform) with Q cached as four rows of 16 words -- slot 0 Y - X, 1 Y + X, 2 2dT, 3 Z, plain
+// residues with limbs below 2^28 -- as gq_add (src/min_curve/element.rs:291-322): v tight -> tight.
+__device__ __forceinline__ uint32_t rq_add(uint32_t v, const uint32_t* qrec, const RowSel& S, bool neg_q, const RowK& K) {
+  const RowPair e = swap16(v, v);                                  // (X, X, Z, Z), (Y, Y, T, T)
+  // Y - X, Y + X, T, 2Z
+  const uint32_t opa = RowSel::pick(S.m0, e.hi + K.sub_tight - v, RowSel::pick(S.m1, v + e.lo, RowSel::pick(S.m2, e.hi, e.lo + e.lo)));
+  const int slot = (S.r < 2 && neg_q) ? (S.r ^ 1) : S.r;           // -Q: Y - X and Y + X change places
+  const uint32_t m1 = row_mul(opa, qrec[slot * 16 + S.j], K);      // a, b, c, d
+  const RowPair q = swap16(m1, m1);                                // (a, a, c, c), (b, b, d, d)
+  const uint32_t odd = S.m1 | S.m3;
+  const uint32_t u = RowSel::pick(odd, m1, q.hi), w_ = RowSel::pick(odd, q.lo, m1);   // (b, b, d, d), (a, a, c, c)
+  const uint32_t subm = S.m0 | (neg_q ? S.m3 : S.m2);              // E = b - a, H = b + a, F = d -+ c, G = d +- c
+  const uint32_t w = RowSel::pick(subm, u + K.sub_tight - w_, u + w_);
+  const RowPair a1 = swap16(w, w);                                 // (E, E, F, F), (H, H, G, G)
+  const RowPair a2 = swap32(w, w);                                 // (E, H, E, H), (F, G, F, G)
+  const RowPair a3 = swap32(a1.lo, a1.lo);                         // (E, E, E, E), (F, F, F, F)
+  const uint32_t opx = RowSel::pick(S.m1, a2.hi, RowSel::pick(S.m3, a3.lo, w));   // E, G, F, E
+  const uint32_t opy = RowSel::pick(S.m0, a3.hi, RowSel::pick(S.m1, w, RowSel::pick(S.m2, a1.hi, a2.lo)));   // F, H, G, H
+  return row_mul(opx, opy, K);                                     // E F, G H, F G, E H
+}
+
+// ---- between the two forms (whole field elements in a lane, Montgomery 9 x 29 <-> plain 10 x 28 across a row) --------
+// one lane writes an element as a row record: 16 words, canonical value, limbs 10..15 zero
+__device__ __forceinline__ void row_store_from_fe(uint32_t* rec16, const fe& x) {
+  uint32_t w[8];
+  fe_to_words(fe_canon(x), w);
+#pragma unroll
+  for (int k = 0; k < RL; ++k) {
+    const int bit = RW * k, lo = bit >> 5, sh = bit & 31;
+    uint32_t v = w[lo] >> sh;
+    if (sh + RW > 32 && lo + 1 < 8) v |= w[lo + 1] << (32 - sh);
+    rec16[k] = v & M28;
+  }
+#pragma unroll
+  for (int k = RL; k < 16; ++k) rec16[k] = 0;
+}
+// one lane reads a (tight) row record back: Montgomery form, a lazy sum of two products
+__device__ __forceinline__ fe row_load_to_fe(const uint32_t* rec16) {
+  uint32_t w[9];
+  uint64_t acc = 0;                                                // the integer, 32 bits at a time
+  int have = 0, wi = 0;
+#pragma unroll
+  for (int k = 0; k < RL; ++k) {
+    acc += (uint64_t)rec16[k] << have;                             // limbs below 2^29: the carry rides in acc
+    have += RW;
+    if (have >= 32) { w[wi++] = (uint32_t)acc; acc >>= 32; have -= 32; }
+  }
+  w[wi] = (uint32_t)acc;                                           // wi == 8: bits 256 .. (value < 2^273)
+  uint32_t hi[8] = {w[8], 0, 0, 0, 0, 0, 0, 0};
+  return fe_from_wide_words(w, hi);
+}
+
+}  // namespace row
+}  // namespace d377
