@@ -55,9 +55,12 @@ constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a seri
 // issue time); the wide last level is for runs that hold most of the points (many equal scalars).
 // `skip`: a level runs only if some bucket still has more than this many partials; fewer are summed by the lane that
 // finishes the bucket (a level of its own for two or three leftovers -- the tail of the Poisson run lengths -- cost 27-56 us).
-// Segment length x skip threshold swept at 2^20 / 2^22 (16-64 x 4-16): everything within 2 %.
+// Segment length x skip threshold swept at 2^20 / 2^22 (16-64 x 4-16): everything within 2 %; round 4 (tools/msm_tune_sweep.py,
+// skip 4 / 8 / 16): 2^16 553 / 537 / 529 us, 2^18 804 / 799 / 799, 2^20 1786 / 1773 / 1768, 2^22 5840 / 5814 / 5832 -- with random
+// scalars a bucket leaves 4-16 partials at every size, and the lane that finishes the bucket sums those in less time than a
+// level of its own costs: 16.
 struct RedSizes { int g[3]; uint32_t skip; };
-constexpr RedSizes RED_DEFAULT = {{8, 8, 32}, 4};
+constexpr RedSizes RED_DEFAULT = {{8, 8, 32}, 16};
 // Points per lane in k_msm_segments (`seg`, a launch parameter): 8, 16 or 32 by batch size -- pick_seg() below.
 constexpr int MAX_SEG = 128;
 
@@ -171,10 +174,15 @@ k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* sca
 // once otherwise.  (Round 2 made the choice per wave inside the 32-per-lane kernel, which left the common Z = 1 case
 // on a grid sized for sharing inversions it did not need: 0.48 ms per 2^22 points.)
 __global__ void __launch_bounds__(BLOCK, 4)
-k_msm_prepare_affine(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c, int W, uint32_t* pts, int16_t* digits,
+k_msm_prepare_affine(SqrtTables T, const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c, int W, uint32_t* pts, int16_t* digits,
                      uint32_t* flag) {
   const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
+  (void)T;
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+    // The bucket route rebuilds 2dxy from X, Y, Z and never reads T; the small-batch route (k_msm_small) runs on the record's T.
+    // A record with T Z != X Y would sum differently on the two: the check build counts such records (here, before the
+    // early exits: this kernel sees every record of the batch unless a projective one sends it home) and k_msm_small's.
+    D377_INVARIANT(T, load_ge_mont256(xyzt, i), true);
     // Once any wave has met a Z != 1, k_msm_prepare_el redoes the whole batch and nothing written here is used: the wave
     // that meets one raises the flag at once and leaves, and every other wave leaves when it sees the flag (a batch of
     // projective Elements -- sums, products -- spent 0.39 ms per 2^22 points in this kernel for nothing).
@@ -923,6 +931,7 @@ k_msm_small(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n,
   } else {
     g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), e);
     skip |= fe_is_zero(g.z);                                     // a record with z = 0 is no group element
+    D377_INVARIANT(T, g, active && role == 0 && !skip);          // check build: T Z = X Y is what this route relies on
   }
   const fe id = gq_from_ge(ge_identity(), role);
   fe v = gq_scalar_mul_w4(gq_from_ge(g, role), dg, tab + quad * GQ_TAB_ENTRIES * GQ_WORDS, role);
@@ -1176,7 +1185,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
     } else {
       uint32_t* zflag = (uint32_t*)(m + o_flag);
       HIP_TRY(hipMemsetAsync(zflag, 0, sizeof(uint32_t), s));
-      hipLaunchKernelGGL(k_msm_prepare_affine, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, (const uint64_t*)pts_in, scalars, n, c, W, pts,
+      hipLaunchKernelGGL(k_msm_prepare_affine, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint64_t*)pts_in, scalars, n, c, W, pts,
                          dig, zflag);
       // ~32 elements per lane share one inversion, but never fewer lanes than one wave per SIMD (see k_to_affine)
       size_t lanes = (n + 31) / 32;
@@ -1201,7 +1210,11 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   lv.buf[0] = partial;
   for (int l = 1; l < REDUCE_LEVELS; ++l) {
     uint32_t* r = (uint32_t*)(m + o_r[l]);
-    hipLaunchKernelGGL(k_msm_reduce, dim3(grid_of(d, max_g[l])), dim3(BLOCK), 0, s, lv.buf[l - 1], segoff + (size_t)(l - 1) * so_stride,
+    // (levels 3 and 4 only ever run for runs that hold most of the points: a small grid that strides, so that the launch that
+    // finds nothing to do costs a few hundred workgroups, not thousands)
+    int gr = grid_of(d, max_g[l]);
+    if (l >= 2 && gr > d.cus * 4) gr = d.cus * 4;
+    hipLaunchKernelGGL(k_msm_reduce, dim3(gr), dim3(BLOCK), 0, s, lv.buf[l - 1], segoff + (size_t)(l - 1) * so_stride,
                        segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax + (l - 1), red.skip);
     lv.buf[l] = r;
   }

@@ -1399,6 +1399,17 @@ bad = xyzt[:100].copy(); bad[:, 0] ^= np.uint64(2)          # x limb flipped: no
 ctx.compress(bad)
 on, cnt = ctx.invariant_failures()
 assert on and cnt == 100, cnt
+# Element records whose T is not X Y / Z would sum differently on the MSM's two routes (the quads run on the record's T, the
+# buckets rebuild it from X, Y, Z): both routes count them here
+tbad = xyzt[:300].copy(); tbad[7, 12] ^= np.uint64(4); tbad[200, 13] ^= np.uint64(1)
+with ctx.tuning(msm_small_max=0):
+    ctx.msm(tbad, k[:300])
+assert ctx.invariant_failures() == (True, 102)
+with ctx.tuning(msm_small_max=1000000):
+    ctx.msm(tbad, k[:300])
+assert ctx.invariant_failures() == (True, 104)
+ctx.msm(xyzt[:300], k[:300])
+assert ctx.invariant_failures() == (True, 104)
 print("INVARIANTS_OK")
 """
     env = dict(os.environ, D377_LIB=lib)
