@@ -1522,7 +1522,7 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count) {
 static bool tuning_range(int key, long long* lo, long long* hi) {
   const long long big = (long long)1 << 62;
   switch (key) {
-    case D377_TUNE_SMALL_MAX: case D377_TUNE_MSM_SMALL_MAX: case D377_TUNE_DECOMPRESS_CHUNKED_MIN:
+    case D377_TUNE_SMALL_MAX: case D377_TUNE_MSM_SMALL_MAX: case D377_TUNE_DECOMPRESS_CHUNKED_MIN: case D377_TUNE_MSM_TINY_MAX:
     case D377_TUNE_MSM_ENC_CHUNKED_MIN: *lo = 0; *hi = big; return true;
     case D377_TUNE_FB_WIDE: case D377_TUNE_MSM_CHUNKED_SUMS: *lo = 0; *hi = 1; return true;
     case D377_TUNE_FB_K: *lo = 1; *hi = DCB_KMAX; return true;

@@ -58,9 +58,9 @@ constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a seri
 // Segment length x skip threshold swept at 2^20 / 2^22 (16-64 x 4-16): everything within 2 %; round 4 (tools/msm_tune_sweep.py,
 // skip 4 / 8 / 16): 2^16 553 / 537 / 529 us, 2^18 804 / 799 / 799, 2^20 1786 / 1773 / 1768, 2^22 5840 / 5814 / 5832 -- with random
 // scalars a bucket leaves 4-16 partials at every size, and the lane that finishes the bucket sums those in less time than a
-// level of its own costs: 16.
+// level of its own costs: 16 -- and 32 since four lanes share a bucket's partials (k_msm_buckets): up to eight additions per lane.
 struct RedSizes { int g[3]; uint32_t skip; };
-constexpr RedSizes RED_DEFAULT = {{8, 8, 32}, 16};
+constexpr RedSizes RED_DEFAULT = {{8, 8, 32}, 32};
 // Points per lane in k_msm_segments (`seg`, a launch parameter): 8, 16 or 32 by batch size -- pick_seg() below.
 constexpr int MAX_SEG = 128;
 
@@ -303,8 +303,15 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digit
 // and the four totals of the workgroup in tot[w][chunk][]; k_msm_scan2 adds the totals of the chunks before.  (One
 // workgroup per window walking its buckets 1024 at a time took 0.12 ms at every size: 18 workgroups on 256 CUs.)
 constexpr int REDUCE_LEVELS = 4;
-// lvlmax[l] (zeroed by the host before the launch) receives the largest number of level-(l+1) partials any bucket has:
-// a reduction level whose input leaves no bucket with more than `skip` partials returns at once.
+// lvlmax (zeroed by the host before the launch) receives, per reduction level l and WINDOW w, the largest number of
+// level-(l+1) partials any bucket of that window has -- lvlmax[l * LVL_STRIDE + w] -- and per level the largest over all
+// windows, lvlmax[REDUCE_LEVELS * LVL_STRIDE + l].  A level returns at once when no window needs it, and leaves the
+// windows alone whose buckets are down to `skip` partials: the lane that finishes the bucket adds those (k_msm_buckets).
+// The decision is per window because the TOP window is not like the others: k / 2 mod r < 2^250.2 leaves it 10.2 (12-bit
+// windows) or 12.2 (14-bit) unsigned bits, so its points spread over 0.58 of the buckets the sign-folded windows use and
+// its runs are 1.7 times as long -- one window in 18 that used to switch a level on for all of them.
+constexpr int LVL_STRIDE = 64;
+constexpr int LVL_WORDS = REDUCE_LEVELS * LVL_STRIDE + REDUCE_LEVELS;
 __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, uint32_t* tot, int nb,
                                                     int S, int W, int nchunk, int seg, RedSizes red, uint32_t* lvlmax) {
   __shared__ uint32_t part[1 + REDUCE_LEVELS][1024];
@@ -330,7 +337,10 @@ __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_
   for (int l = 1; l <= REDUCE_LEVELS; ++l)
     if (own[l] > 1) atomicMax(&bmax[l - 1], own[l]);
   __syncthreads();
-  if (t < REDUCE_LEVELS && bmax[t] > 1) atomicMax(&lvlmax[t], bmax[t]);
+  if (t < REDUCE_LEVELS && bmax[t] > 1) {
+    atomicMax(&lvlmax[t * LVL_STRIDE + w], bmax[t]);
+    atomicMax(&lvlmax[REDUCE_LEVELS * LVL_STRIDE + t], bmax[t]);
+  }
   for (int off = 1; off < 1024; off <<= 1) {
     uint32_t v[1 + REDUCE_LEVELS];
     for (int l = 0; l <= REDUCE_LEVELS; ++l) v[l] = (t >= off) ? part[l][t - off] : 0u;
@@ -508,8 +518,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place2(const uint32_t* tmp
 
 // Lane gi of a reduction level -> (window, bucket, group within the bucket) by a short search in that level's
 // prefix sums so[w][0..nb] (W <= 63 windows; groups of a window are contiguous).  False beyond the last group.
+// wmax / skip (optional): the per-window maxima of the level's input; a lane of a window that needs no further level gets
+// *w_out = -1 before it has searched anything.
 __device__ __forceinline__ bool msm_locate(size_t gi, const uint32_t* so_all, int W, int nb, int* w_out, int* b_out, uint32_t* k_out,
-                                           size_t* base_out) {
+                                           size_t* base_out, const uint32_t* wmax = nullptr, uint32_t skip = 0) {
   const int len = nb + 1;
   size_t base = 0;
   int w = 0;
@@ -519,6 +531,7 @@ __device__ __forceinline__ bool msm_locate(size_t gi, const uint32_t* so_all, in
     base += tot;
   }
   if (w == W) return false;
+  if (wmax && wmax[w] <= skip) { *w_out = -1; return true; }
   const uint32_t local = (uint32_t)(gi - base);
   const uint32_t* so = so_all + (size_t)w * len;
   int lo_b = 0, hi_b = nb;                             // largest b with so[b] <= local
@@ -583,14 +596,15 @@ k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, c
 // level cuts its partials by `red` instead of leaving them to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, int W, int nb, size_t max_groups, uint32_t* out,
-             int red, const uint32_t* in_max, uint32_t skip) {
-  if (*in_max <= skip) return;                       // every bucket is down to a few partials: k_msm_buckets adds those itself
+             int red, const uint32_t* lvlmax, int level, uint32_t skip) {
+  if (lvlmax[REDUCE_LEVELS * LVL_STRIDE + level] <= skip) return;   // every bucket is down to a few partials: k_msm_buckets adds those itself
   const int len = nb + 1;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_groups; gi += (size_t)gridDim.x * BLOCK) {
     int w, b;
     uint32_t k;
     size_t base;
-    if (!msm_locate(gi, so_out, W, nb, &w, &b, &k, &base)) break;
+    if (!msm_locate(gi, so_out, W, nb, &w, &b, &k, &base, lvlmax + level * LVL_STRIDE, skip)) break;
+    if (w < 0) continue;                              // a window whose buckets need no further level
     const size_t in_base = msm_window_base(so_in, w, nb);
     const uint32_t s0 = so_in[(size_t)w * len + b], s1 = so_in[(size_t)w * len + b + 1];
     uint32_t lo = s0 + k * (uint32_t)red, hi = lo + (uint32_t)red;
@@ -612,35 +626,64 @@ k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, 
 }
 
 // one lane per bucket: sum of what the last level that ran left of it (a few partials at most with random scalars).
-// Level l + 1 ran iff lvlmax[l - 1] > skip; the levels that ran are a prefix.
+// Level l + 1 ran for window w iff lvlmax[(l - 1) * LVL_STRIDE + w] > skip; the levels that ran for a window are a prefix.
 struct MsmLevels {
   const uint32_t* buf[REDUCE_LEVELS];                     // partial sums after level 1 (segments), 2, ...
 };
+// A PAIR of lanes per bucket (BKT_LANES; a quad was measured too).  With random scalars a bucket is left with 4-30 partials (n / 2^(c-1) points in segments of 8-32;
+// the top window's runs are 1.7 times as long), and one lane per bucket walking them was the slowest way to add a million
+// points: 2.25 waves per SIMD of 7-15 dependent additions each, two generations on a kernel that holds two (129 us for
+// 1.03 M additions at 2^20, 2.4 times the time the segment sums take per addition; a reduction level in front of it costs
+// the same additions in the same shape).  Here lane q of the group sums the partials q, q + L, q + 2L, ... of the bucket, the
+// group adds its sums in one (pair) or two (quad) exchange steps (DPP quad_perm moves of the 36 limbs), and lane 0 stores:
+// shorter chains, more waves to fill the SIMDs with.
+template <int P0, int P1, int P2, int P3>
+__device__ __forceinline__ ge ge_quad_perm(const ge& g) {
+  ge r;
+  r.x = fe_quad_perm<P0, P1, P2, P3>(g.x); r.y = fe_quad_perm<P0, P1, P2, P3>(g.y);
+  r.z = fe_quad_perm<P0, P1, P2, P3>(g.z); r.t = fe_quad_perm<P0, P1, P2, P3>(g.t);
+  return r;
+}
+#ifndef D377_MSM_BUCKET_LANES
+#define D377_MSM_BUCKET_LANES 2
+#endif
+constexpr int BKT_LANES = D377_MSM_BUCKET_LANES;             // lanes that share a bucket: 2 (a pair) or 4 (a quad)
+constexpr int BKT_SHIFT = BKT_LANES == 4 ? 2 : 1;
+static_assert(BKT_LANES == 2 || BKT_LANES == 4, "a bucket is shared by a pair or a quad of lanes");
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_buckets(MsmLevels lv, const uint32_t* segoff_all, const uint32_t* lvlmax, uint32_t skip, int W, int nb, uint32_t* buckets) {
   const int len = nb + 1;
-  const size_t total = (size_t)W * nb;
-  int last = 0;
-  while (last + 1 < REDUCE_LEVELS && lvlmax[last] > skip) ++last;
-  const uint32_t* partial = lv.buf[last];
-  const uint32_t* segoff = segoff_all + (size_t)last * W * len;
-  for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < total; gi += (size_t)gridDim.x * BLOCK) {
+  const size_t total = (size_t)W * nb;                      // buckets = groups of BKT_LANES lanes
+  const int q = threadIdx.x & (BKT_LANES - 1);
+  const size_t nquads = ((size_t)gridDim.x * BLOCK) >> BKT_SHIFT;
+  // every quad of a wave takes the same number of trips: the DPP exchanges below need all four lanes of a quad active,
+  // so a quad past the end redoes the last bucket and does not store
+  const size_t trips = (total + nquads - 1) / nquads;
+  size_t gq = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> BKT_SHIFT;
+  for (size_t trip = 0; trip < trips; ++trip, gq += nquads) {
+    const size_t gi = gq < total ? gq : total - 1;
     const int w = (int)(gi / nb), b = (int)(gi % nb);
+    int last = 0;
+    while (last + 1 < REDUCE_LEVELS && lvlmax[last * LVL_STRIDE + w] > skip) ++last;
+    const uint32_t* partial = lv.buf[last];
+    const uint32_t* segoff = segoff_all + (size_t)last * W * len;
     const size_t base = msm_window_base(segoff, w, nb);
-    const uint32_t s0 = segoff[(size_t)w * len + b], s1 = segoff[(size_t)w * len + b + 1];
+    const uint32_t s0 = segoff[(size_t)w * len + b] + (uint32_t)q, s1 = segoff[(size_t)w * len + b + 1];
     ge acc = ge_identity();
     if (s0 < s1) {
       acc = pt_load_ext(partial + (base + s0) * PT_WORDS);
       ge nx = acc;
-      if (s0 + 1 < s1) nx = pt_load_ext(partial + (base + s0 + 1) * PT_WORDS);
+      if (s0 + BKT_LANES < s1) nx = pt_load_ext(partial + (base + s0 + BKT_LANES) * PT_WORDS);
 #pragma unroll 1
-      for (uint32_t j = s0 + 1; j < s1; ++j) {
+      for (uint32_t j = s0 + BKT_LANES; j < s1; j += BKT_LANES) {   // the next partial is in flight while this one is added
         const ge cur = nx;
-        if (j + 1 < s1) nx = pt_load_ext(partial + (base + j + 1) * PT_WORDS);
+        if (j + BKT_LANES < s1) nx = pt_load_ext(partial + (base + j + BKT_LANES) * PT_WORDS);
         acc = ge_add(acc, cur);
       }
     }
-    pt_store_ext(buckets + gi * PT_WORDS, acc);
+    acc = ge_add(acc, ge_quad_perm<1, 0, 3, 2>(acc));        // neighbours: sums 0 + 1 (and 2 + 3)
+    if (BKT_LANES == 4) acc = ge_add(acc, ge_quad_perm<2, 3, 0, 1>(acc));   // every lane: the bucket
+    if (q == 0 && gq < total) pt_store_ext(buckets + gi * PT_WORDS, acc);
   }
 }
 
@@ -948,6 +991,51 @@ k_msm_small(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n,
   if (quad == 0) slot_store(partial + (size_t)blockIdx.x * PT_WORDS + role * SLOT, v);   // X, Y, Z, T: pt_store_ext's layout
 }
 
+// ---- the smallest batches: one WAVE per point ---------------------------------------------------------------------------
+// Up to one point per SIMD (4 x the CUs: 1 024 on an MI355X) even the quads leave most of the chip idle, and the call is one
+// point's chain of 252 doublings.  In the lane-spread form (row_ops.hpp) that chain is half as long: every wave computes
+// [k_i / 2]P_i with the point across its four rows, converts back and writes one partial; k_msm_small_sum adds them up.
+template <bool ENCODED>
+__global__ void __launch_bounds__(64)
+k_msm_tiny(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, uint32_t* partial, uint8_t* status) {
+  __shared__ uint32_t lds_pow_[ENCODED ? POW_TAB * NL * 64 : 1];
+  __shared__ uint32_t tab[row::RQ_TAB_ENTRIES * RQ_WORDS];
+  __shared__ uint32_t xrec[RQ_WORDS];
+  Pow64 pt;
+  pt.col = lds_pow_ + threadIdx.x;
+  const int t = threadIdx.x;
+  const size_t e = blockIdx.x;                                     // grid = n
+  uint32_t k[8], dg[8];
+  load32(scalar32, e, k);
+  fr_reduce_words(k);
+  fr_half_words(k);                                                // the sum is formed with k/2 mod r and doubled at the end
+  fr_recode_signed16(k, dg);
+  ge g;
+  bool skip = false;
+  if (ENCODED) {
+    uint32_t w[8];
+    load32(reinterpret_cast<const uint8_t*>(pts_in), e, w);
+    const uint32_t bad = ge_decompress(T, pt, w, &g);              // every lane: the same chain of squarings
+    if (t == 0) status[e] = (uint8_t)bad;
+    skip = bad != 0;                                               // invalid points contribute nothing
+  } else {
+    g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), e);
+    skip = fe_is_zero(g.z);                                        // a record with z = 0 is no group element
+    D377_INVARIANT(T, g, t == 0 && !skip);
+  }
+  if (skip) g = ge_identity();
+  if (t < 4) row::row_store_from_fe(xrec + 16 * t, fe_pick(t, g.x, g.y, g.z, g.t));   // lanes 0..3: one coordinate each
+  __syncthreads();
+  const row::RowK K = row::row_consts();
+  const row::RowSel S = row::row_sel();
+  const uint32_t v = row::rq_scalar_mul_w4(xrec[t], dg, tab, S, K);
+  __syncthreads();
+  xrec[t] = v;
+  __syncthreads();
+  const ge r = rq_load_point(xrec);
+  if (t == 0) pt_store_ext(partial + (size_t)blockIdx.x * PT_WORDS, r);
+}
+
 // the sum of the m partial results (one quad per MSS_QUADS of them, then a tree over the quads) and its encoding
 __global__ void __launch_bounds__(MSS_THREADS)
 k_msm_small_sum(SqrtTables T, const uint32_t* partial, int m, uint8_t* enc_out, uint64_t* xyzt_out) {
@@ -1062,15 +1150,21 @@ int msm_reserve(DeviceState& d, hipStream_t s, size_t bytes, MsmHeld& held) {
 // Batches up to this many points skip the buckets (k_msm_small).  D377_TUNE_MSM_SMALL_MAX: developer override (0 = never).
 size_t msm_small_max(const DeviceState& d) { return (size_t)d.tuned(D377_TUNE_MSM_SMALL_MAX, (long long)d.cus * 4 * MS_QUADS); }
 
+// Batches up to this many points take one wave per point (k_msm_tiny): one wave per SIMD.  D377_TUNE_MSM_TINY_MAX: developer override.
+size_t msm_tiny_max(const DeviceState& d) { return (size_t)d.tuned(D377_TUNE_MSM_TINY_MAX, (long long)d.cus * 4); }
+
 int msm_launch_small(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,
                      uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
-  const size_t m = (n + MS_QUADS - 1) / MS_QUADS;
+  const bool tiny = n <= msm_tiny_max(d);
+  const size_t m = tiny ? n : (n + MS_QUADS - 1) / MS_QUADS;
   MsmHeld held{d.msm.guard, s, false};
   int rc;
   if ((rc = msm_reserve(d, s, m * PT_WORDS * 4, held))) return rc;
   uint32_t* partial = (uint32_t*)d.msm.mem;
   const SqrtTables T = d.tables();
-  if (encoded) hipLaunchKernelGGL(k_msm_small<true>, dim3((unsigned)m), dim3(MS_THREADS), 0, s, T, pts_in, scalars, n, partial, status);
+  if (tiny && encoded) hipLaunchKernelGGL(k_msm_tiny<true>, dim3((unsigned)n), dim3(64), 0, s, T, pts_in, scalars, n, partial, status);
+  else if (tiny) hipLaunchKernelGGL(k_msm_tiny<false>, dim3((unsigned)n), dim3(64), 0, s, T, pts_in, scalars, n, partial, status);
+  else if (encoded) hipLaunchKernelGGL(k_msm_small<true>, dim3((unsigned)m), dim3(MS_THREADS), 0, s, T, pts_in, scalars, n, partial, status);
   else hipLaunchKernelGGL(k_msm_small<false>, dim3((unsigned)m), dim3(MS_THREADS), 0, s, T, pts_in, scalars, n, partial, status);
   hipLaunchKernelGGL(k_msm_small_sum, dim3(1), dim3(MSS_THREADS), 0, s, T, partial, (int)m, enc_out, xyzt_out);
   HIP_TRY(hipGetLastError());
@@ -1124,7 +1218,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
     max_g[l] = max_g[l - 1] / (size_t)red.g[l - 1] + (size_t)W * nb;
     o_r[l] = carve(max_g[l] * PT_WORDS * 4);
   }
-  const size_t o_lvl = carve(256);
+  const size_t o_lvl = carve(LVL_WORDS * sizeof(uint32_t));
   const size_t o_ch = carve((size_t)W * nchunks * PT_WORDS * 4);
   // ping-pong buffers of the 32-to-1 folds, sized from the fold sequence itself: the first fold writes
   // ceil(nchunks / FOLD) records per window into f0, the second ceil(that / FOLD) into f1, and so on
@@ -1198,7 +1292,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
   uint32_t* tot = (uint32_t*)(m + o_tot);
   uint32_t* lvlmax = (uint32_t*)(m + o_lvl);
-  HIP_TRY(hipMemsetAsync(lvlmax, 0, REDUCE_LEVELS * sizeof(uint32_t), s));
+  HIP_TRY(hipMemsetAsync(lvlmax, 0, LVL_WORDS * sizeof(uint32_t), s));
   hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, segoff, tot, nb, S, W, scan_chunks, seg, red, lvlmax);
   hipLaunchKernelGGL(k_msm_scan2, dim3(W * scan_chunks), dim3(1024), 0, s, offs, segoff, tot, nb, W, scan_chunks);
   hipLaunchKernelGGL(k_msm_place1, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
@@ -1215,10 +1309,10 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
     int gr = grid_of(d, max_g[l]);
     if (l >= 2 && gr > d.cus * 4) gr = d.cus * 4;
     hipLaunchKernelGGL(k_msm_reduce, dim3(gr), dim3(BLOCK), 0, s, lv.buf[l - 1], segoff + (size_t)(l - 1) * so_stride,
-                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax + (l - 1), red.skip);
+                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax, l - 1, red.skip);
     lv.buf[l] = r;
   }
-  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, lv, segoff, lvlmax, red.skip, W, nb, bkt);
+  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb * BKT_LANES)), dim3(BLOCK), 0, s, lv, segoff, lvlmax, red.skip, W, nb, bkt);
   const uint32_t* cur_in;
   if (tree) {
     uint32_t *nodes = (uint32_t*)(m + o_nodes), *sums = (uint32_t*)(m + o_sums);

@@ -204,6 +204,44 @@ __device__ __forceinline__ uint32_t rq_add(uint32_t v, const uint32_t* qrec, con
   return row_mul(opx, opy, K);                                     // E F, G H, F G, E H
 }
 
+// The cached slot a row multiplies by, from a point in row form: row 0 Y - X, 1 Y + X, 2 2dT, 3 Z (what rq_add reads of
+// its other operand).  Lazy limbs (a difference, a sum): multiplicands only.
+__device__ __forceinline__ uint32_t rq_cached_slot(uint32_t v, const RowSel& S, const RowK& K) {
+  const RowPair e = swap16(v, v);                                  // (X, X, Z, Z), (Y, Y, T, T)
+  const uint32_t kt = row_mul(e.hi, K.k2d, K);                     // row 2: 2d T (the other rows' products are not used)
+  return RowSel::pick(S.m0, e.hi + K.sub_tight - v, RowSel::pick(S.m1, v + e.lo, RowSel::pick(S.m2, kt, e.lo)));
+}
+// [k]P for ONE point per wave: signed 4-bit windows (fr_recode_signed16), most significant first -- 63 x (4 sign-folded
+// doublings, 1 addition) over a table of the cached slots of 0 .. 8 times P, 9 x 64 words of LDS that belong to this wave
+// (gq_scalar_mul_w4 of quad_ops.hpp with a wave where that has a quad).  v1: P in row form; every lane of the wave calls this.
+constexpr int RQ_TAB_ENTRIES = 9;
+__device__ __forceinline__ uint32_t rq_scalar_mul_w4(uint32_t v1, const uint32_t dg[8], uint32_t* tab, const RowSel& S, const RowK& K) {
+  const int t = S.r * 16 + S.j;
+  const uint32_t one_or_zero = S.j == 0 ? 1u : 0u;
+  tab[t] = S.r == 2 ? 0u : one_or_zero;                            // the identity's cached slots: 1, 1, 0, 1
+  tab[64 + t] = rq_cached_slot(v1, S, K);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint32_t acc = v1;
+#pragma unroll 1
+  for (int j = 2; j < RQ_TAB_ENTRIES; ++j) {
+    acc = rq_add(acc, tab + 64, S, false, K);                      // [j]P = [j-1]P + P (the unified addition also doubles)
+    tab[j * 64 + t] = rq_cached_slot(acc, S, K);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint32_t id = (S.r == 1 || S.r == 2) ? one_or_zero : 0u;   // the identity: X = 0, Y = 1, Z = 1, T = 0
+  int d = fr_digit(dg, 63);                                        // 0 or 1
+  uint32_t v = d != 0 ? v1 : id;
+#pragma unroll 1
+  for (int i = 62; i >= 0; --i) {
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) v = rq_double_neg(v, S, K);        // four sign-folded doublings keep the sign
+    d = fr_digit(dg, i);
+    const bool neg = d < 0;
+    v = rq_add(v, tab + (neg ? -d : d) * 64, S, neg, K);
+  }
+  return v;
+}
+
 // ---- between the two forms (whole field elements in a lane, Montgomery 9 x 29 <-> plain 10 x 28 across a row) --------
 // one lane writes an element as a row record: 16 words, canonical value, limbs 10..15 zero
 __device__ __forceinline__ void row_store_from_fe(uint32_t* rec16, const fe& x) {

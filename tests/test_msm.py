@@ -49,12 +49,13 @@ def test_four_lane_group_operations_selftest():
 
 
 
-@pytest.fixture(params=["buckets", "quads"])
+@pytest.fixture(params=["buckets", "quads", "waves"])
 def route(request, ctx):
-    """Both routes of the MSM on the same inputs: the bucket method (every size; forced here for the small ones too) and
-    the one-quad-per-point kernel that small batches take by default (forced here for the larger test sizes too, where
-    its grid no longer fits the chip at once and the partial sums take several trips)."""
-    with ctx.tuning(msm_small_max=0 if request.param == "buckets" else 1000000):
+    """The three routes of the MSM on the same inputs: the bucket method (every size; forced here for the small ones too),
+    the one-quad-per-point kernel that batches up to 64 per CU take by default, and the one-wave-per-point kernel
+    (lane-spread arithmetic, row_ops.hpp) of batches up to 4 per CU -- each forced here over all the test sizes, also the
+    ones where its grid no longer fits the chip at once and the partial sums take several trips."""
+    with ctx.tuning(msm_small_max=0 if request.param == "buckets" else 1000000, msm_tiny_max=1000000 if request.param == "waves" else 0):
         yield request.param
 
 @pytest.mark.gpu

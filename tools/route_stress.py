@@ -3,7 +3,7 @@
 is run at random sizes around its thresholds on both routes (d377_ctx_set_tuning forces the other one) and the bytes are
 compared; a sample of each result also goes to the oracle.  Test infrastructure (the oracle is the checker).
   variable base (Encodings / Elements):  one quad of lanes per element  |  one lane per element      small_max
-  MSM (Elements / Encodings):            one quad per point, no buckets |  Pippenger                  msm_small_max
+  MSM (Elements / Encodings):            one wave / one quad per point  |  Pippenger                  msm_tiny_max, msm_small_max
   fixed base:                            2 workgroups per CU, K = 8     |  3 per CU, K = 16           fb_wide / fb_k
 usage: python tools/route_stress.py [rounds=40] [seed=1]   -> summary lines, exit 1 on any mismatch"""
 import os
@@ -66,9 +66,16 @@ def main():
     # MSM, both input forms
     bad0, cnt = bad, 0
     for n in sizes(1, 5 * one_gen, [16, 17, 128 * 16, one_gen]):
-        with ctx.tuning(msm_small_max=10**9):
+        with ctx.tuning(msm_small_max=10**9, msm_tiny_max=0):
             a = bytes(ctx.msm(P_all[:n], k[:n])[0])
             ae = ctx.msm(enc_all[:n], k[:n])
+        if n <= 3000:                                              # one wave per point (lane-spread arithmetic), forced beyond its size
+            with ctx.tuning(msm_small_max=10**9, msm_tiny_max=10**9):
+                aw = bytes(ctx.msm(P_all[:n], k[:n])[0])
+                awe = ctx.msm(enc_all[:n], k[:n])
+            if aw != a or bytes(awe[0]) != bytes(ae[0]) or not torch.equal(torch.as_tensor(awe[2]), torch.as_tensor(ae[2])):
+                bad += 1
+                print("MISMATCH msm (waves) n = %d" % n, flush=True)
         with ctx.tuning(msm_small_max=0):
             b = bytes(ctx.msm(P_all[:n], k[:n])[0])
             be = ctx.msm(enc_all[:n], k[:n])
