@@ -22,6 +22,7 @@
 #include "device_util.hpp"
 #include "dcb.hpp"
 #include "quad_ops.hpp"
+#include "row_ops.hpp"
 #include "host_state.hpp"
 
 using namespace d377;
@@ -466,6 +467,60 @@ k_scalar_mul_var_small(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar
   }
 }
 
+// The smallest batches -- up to one element per SIMD, 4 x the CUs -- give every element a WAVE: the group operations run in
+// the lane-spread form (row_ops.hpp: the point across the four rows, a field product ~100 instructions on the critical path
+// instead of ~200), so the chain of 252 doublings and 63 additions is half as long as on a quad; the square root of the
+// decompression and the inversion of the encoding stay whole-element chains that every lane repeats.
+template <bool ELEMENT>
+__global__ void __launch_bounds__(64)
+k_scalar_mul_var_tiny(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, uint8_t* out32, uint8_t* status) {
+  __shared__ uint32_t lds_pow_[ELEMENT ? 1 : POW_TAB * NL * 64];
+  __shared__ uint32_t tab[row::RQ_TAB_ENTRIES * row::RQ_WORDS];
+  __shared__ uint32_t xrec[row::RQ_WORDS];
+  struct Pow64 {
+    uint32_t* col;
+    __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
+    __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
+  } pt;
+  pt.col = lds_pow_ + threadIdx.x;
+  const int t = threadIdx.x;
+  const size_t e = blockIdx.x;                                   // grid = n
+  uint32_t w[8], k[8], dg[8];
+  load32(scalar32, e, k);
+  ge g;
+  uint32_t bad = 0;
+  fr_reduce_words(k);
+  if (ELEMENT) {
+    g = load_ge_mont256(reinterpret_cast<const uint64_t*>(enc32), e);
+  } else {
+    load32(enc32, e, w);
+    bad = ge_decompress(T, pt, w, &g);                            // every lane: the same chain of squarings
+    fr_half_words(k);                                            // [k]P = [2]([k/2 mod r]P): the encoding of a double needs no square root
+  }
+  fr_recode_signed16(k, dg);
+  if (t < 4) row::row_store_from_fe(xrec + 16 * t, fe_pick(t, g.x, g.y, g.z, g.t));
+  __syncthreads();
+  const row::RowK K = row::row_consts();
+  const row::RowSel S = row::row_sel();
+  const uint32_t v = row::rq_scalar_mul_w4(xrec[t], dg, tab, S, K);
+  __syncthreads();
+  xrec[t] = v;
+  __syncthreads();
+  const ge r = row::rq_load_point(xrec);
+  D377_INVARIANT(T, r, bad == 0 && t == 0);
+  if (ELEMENT) {
+    if (t == 0) store_ge_mont256(reinterpret_cast<uint64_t*>(out32), e, r);
+  } else {
+    OneDcbIO io;
+    dcb_put(io, 0, ge_dcb_from_half(r, bad != 0));               // failed elements: neutral state, all-zero output
+    dcb_finish(pt, io, 1);
+    if (t == 0) {
+      store32(out32, e, io.out);
+      status[e] = (uint8_t)bad;
+    }
+  }
+}
+
 // The reference's own signatures for these operations take and return Elements (`Element * Fr`,
 // src/min_curve/ops.rs:89-95; `Element::encode_to_curve`, `hash_to_curve`, src/min_curve/element.rs:235-244;
 // `vartime_compress_to_field`, :163-181): the same per-lane code as above without the encoding step at either
@@ -834,6 +889,13 @@ size_t small_batch_max(const DeviceState& d, bool element_form) {
   return (size_t)d.tuned(D377_TUNE_SMALL_MAX, (long long)d.cus * SMALL_QUADS * (element_form ? 7 : 8));
 }
 
+// Batches up to this many elements take one WAVE per element (k_scalar_mul_var_tiny): one wave per SIMD.  Capped by
+// small_batch_max, so that switching the small-batch kernels off switches this one off too.  D377_TUNE_TINY_MAX: developer override.
+size_t tiny_batch_max(const DeviceState& d) {
+  const size_t v = (size_t)d.tuned(D377_TUNE_TINY_MAX, (long long)d.cus * 4), cap = small_batch_max(d, true);
+  return v < cap ? v : cap;
+}
+
 int grid_for(const DeviceState& d, size_t n) {
   // >> 256 workgroups when the batch allows it; capped so huge batches grid-stride
   size_t blocks = (n + BLOCK - 1) / BLOCK;
@@ -1068,6 +1130,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     }
     case OP_MUL_VAR:
+      if (n <= tiny_batch_max(d)) {                           // one element per wave, lane-spread arithmetic
+        hipLaunchKernelGGL(k_scalar_mul_var_tiny<false>, dim3((unsigned)n), dim3(64), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                           (uint8_t*)out0, (uint8_t*)out1);
+        break;
+      }
       if (n <= small_batch_max(d, false)) {                   // one element per quad of lanes, table in LDS: no scratch, no hand-over
         hipLaunchKernelGGL(k_scalar_mul_var_small<false>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, T,
                            (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0, (uint8_t*)out1);
@@ -1139,6 +1206,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_neg, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_MUL_VAR_EL: {
+      if (n <= tiny_batch_max(d)) {
+        hipLaunchKernelGGL(k_scalar_mul_var_tiny<true>, dim3((unsigned)n), dim3(64), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                           (uint8_t*)out0, (uint8_t*)nullptr);
+        break;
+      }
       if (n <= small_batch_max(d, true)) {
         hipLaunchKernelGGL(k_scalar_mul_var_small<true>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, T,
                            (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0, (uint8_t*)nullptr);
@@ -1523,6 +1595,7 @@ static bool tuning_range(int key, long long* lo, long long* hi) {
   const long long big = (long long)1 << 62;
   switch (key) {
     case D377_TUNE_SMALL_MAX: case D377_TUNE_MSM_SMALL_MAX: case D377_TUNE_DECOMPRESS_CHUNKED_MIN: case D377_TUNE_MSM_TINY_MAX:
+    case D377_TUNE_TINY_MAX:
     case D377_TUNE_MSM_ENC_CHUNKED_MIN: *lo = 0; *hi = big; return true;
     case D377_TUNE_FB_WIDE: case D377_TUNE_MSM_CHUNKED_SUMS: *lo = 0; *hi = 1; return true;
     case D377_TUNE_FB_K: *lo = 1; *hi = DCB_KMAX; return true;

@@ -78,22 +78,10 @@ __device__ __forceinline__ ge pt_load_ext(const uint32_t* p) {
   return g;
 }
 
-// A point as row records for the lane-spread chains (row_ops.hpp): four rows of 16 words, written by ONE lane.
-constexpr int RQ_WORDS = 64;
-__device__ __forceinline__ void rq_store_point(uint32_t* rec, const ge& p) {            // X, Y, Z, T
-  row::row_store_from_fe(rec, p.x); row::row_store_from_fe(rec + 16, p.y);
-  row::row_store_from_fe(rec + 32, p.z); row::row_store_from_fe(rec + 48, p.t);
-}
-__device__ __forceinline__ void rq_store_cached(uint32_t* rec, const ge& p) {           // Y - X, Y + X, 2dT, Z
-  row::row_store_from_fe(rec, fe_sub(p.y, p.x)); row::row_store_from_fe(rec + 16, fe_add(p.y, p.x));
-  row::row_store_from_fe(rec + 32, fe_mul(fe_const(FE_K), p.t)); row::row_store_from_fe(rec + 48, p.z);
-}
-__device__ __forceinline__ ge rq_load_point(const uint32_t* rec) {                      // every lane: the whole point
-  ge g;
-  g.x = row::row_load_to_fe(rec); g.y = row::row_load_to_fe(rec + 16);
-  g.z = row::row_load_to_fe(rec + 32); g.t = row::row_load_to_fe(rec + 48);
-  return g;
-}
+using row::RQ_WORDS;
+using row::rq_store_point;
+using row::rq_store_cached;
+using row::rq_load_point;
 
 // signed digit w of k (c bits per window, W windows): the top window is not wrapped
 __device__ __forceinline__ int msm_digit(const uint32_t k[8], int w, int c, int W, uint32_t& carry) {

@@ -273,5 +273,24 @@ __device__ __forceinline__ fe row_load_to_fe(const uint32_t* rec16) {
   return fe_from_wide_words(w, hi);
 }
 
+
+// A point as row records: four rows of 16 words (X, Y, Z, T, or the cached form Y - X, Y + X, 2dT, Z), written by ONE lane
+// from whole coordinates; and back, every lane the whole point.
+constexpr int RQ_WORDS = 64;
+__device__ __forceinline__ void rq_store_point(uint32_t* rec, const ge& p) {
+  row_store_from_fe(rec, p.x); row_store_from_fe(rec + 16, p.y);
+  row_store_from_fe(rec + 32, p.z); row_store_from_fe(rec + 48, p.t);
+}
+__device__ __forceinline__ void rq_store_cached(uint32_t* rec, const ge& p) {
+  row_store_from_fe(rec, fe_sub(p.y, p.x)); row_store_from_fe(rec + 16, fe_add(p.y, p.x));
+  row_store_from_fe(rec + 32, fe_mul(fe_const(FE_K), p.t)); row_store_from_fe(rec + 48, p.z);
+}
+__device__ __forceinline__ ge rq_load_point(const uint32_t* rec) {
+  ge g;
+  g.x = row_load_to_fe(rec); g.y = row_load_to_fe(rec + 16);
+  g.z = row_load_to_fe(rec + 32); g.t = row_load_to_fe(rec + 48);
+  return g;
+}
+
 }  // namespace row
 }  // namespace d377

@@ -574,7 +574,7 @@ def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     one_gen, el_max, enc_max = cus * 4 * 16, cus * 7 * 16, cus * 8 * 16       # one wave per SIMD; the two forms' thresholds
     if True:
-        for n in (1, 3, 16, 17, 1000, one_gen - 1, one_gen + 1, el_max, el_max + 1, enc_max, enc_max + 1):
+        for n in (1, 3, 16, 17, 1000, 4 * cus, 4 * cus + 1, one_gen - 1, one_gen + 1, el_max, el_max + 1, enc_max, enc_max + 1):
             enc = oracle.encode_to_curve(rng.integers(0, 256, (min(n, 2048), 32), dtype=np.uint8))
             enc = np.tile(enc, ((n + enc.shape[0] - 1) // enc.shape[0], 1))[:n].copy()
             k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
@@ -582,10 +582,17 @@ def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
             for i, v in enumerate([0, 1, 2, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1][:n]):
                 k[i] = ibytes(v)
             te, tk = torch.from_numpy(enc).to(dev), torch.from_numpy(k).to(dev)
-            out_q, st_q = ctx.scalar_mul_var(te, tk)
+            with ctx.tuning(tiny_max=0):                      # quads
+                out_q, st_q = ctx.scalar_mul_var(te, tk)
             with ctx.tuning(small_max=0):
                 out_l, st_l = ctx.scalar_mul_var(te, tk)
             assert torch.equal(out_q, out_l) and torch.equal(st_q, st_l), n
+            if n <= 4 * cus + 1:                              # one wave per element (lane-spread arithmetic), also one past its size
+                with ctx.tuning(tiny_max=10**6):
+                    out_w, st_w = ctx.scalar_mul_var(te, tk)
+                assert torch.equal(out_w, out_l) and torch.equal(st_w, st_l), n
+            out_d, st_d = ctx.scalar_mul_var(te, tk)          # whatever the size picks
+            assert torch.equal(out_d, out_l) and torch.equal(st_d, st_l), n
             sel = np.unique(np.concatenate([np.arange(min(n, 24)), np.arange(max(0, n - 24), n)]))
             o_out, o_st = oracle.scalar_mul_var(enc[sel], k[sel])
             assert (out_q.cpu().numpy()[sel] == o_out).all() and (st_q.cpu().numpy()[sel] == o_st).all(), n
@@ -593,10 +600,15 @@ def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
             valid = torch.from_numpy(oracle.encode_to_curve(rng.integers(0, 256, (min(n, 512), 32), dtype=np.uint8))).to(dev)
             valid = valid.repeat((n + valid.shape[0] - 1) // valid.shape[0], 1)[:n].contiguous()
             P, _ = ctx.decompress(valid)
-            e_q = ctx.compress(ctx.scalar_mul_var_element(P, tk))
+            with ctx.tuning(tiny_max=0):
+                e_q = ctx.compress(ctx.scalar_mul_var_element(P, tk))
             with ctx.tuning(small_max=0):
                 e_l = ctx.compress(ctx.scalar_mul_var_element(P, tk))
             assert torch.equal(e_q, e_l), n
+            if n <= 4 * cus + 1:
+                with ctx.tuning(tiny_max=10**6):
+                    assert torch.equal(ctx.compress(ctx.scalar_mul_var_element(P, tk)), e_l), n
+            assert torch.equal(ctx.compress(ctx.scalar_mul_var_element(P, tk)), e_l), n
             want, _ = ctx.scalar_mul_var(valid, tk)
             assert torch.equal(e_q, want), n
 

@@ -2,7 +2,7 @@
 """Randomised cross-check of the size-dependent routes: every operation that picks a kernel or a launch shape by batch size
 is run at random sizes around its thresholds on both routes (d377_ctx_set_tuning forces the other one) and the bytes are
 compared; a sample of each result also goes to the oracle.  Test infrastructure (the oracle is the checker).
-  variable base (Encodings / Elements):  one quad of lanes per element  |  one lane per element      small_max
+  variable base (Encodings / Elements):  one wave / one quad per element |  one lane per element      tiny_max, small_max
   MSM (Elements / Encodings):            one wave / one quad per point  |  Pippenger                  msm_tiny_max, msm_small_max
   fixed base:                            2 workgroups per CU, K = 8     |  3 per CU, K = 16           fb_wide / fb_k
 usage: python tools/route_stress.py [rounds=40] [seed=1]   -> summary lines, exit 1 on any mismatch"""
@@ -47,9 +47,16 @@ def main():
     # variable base, both forms
     cnt = 0
     for n in sizes(1, 3 * one_gen, [16, one_gen, 7 * cus * 16, 8 * cus * 16]):
-        with ctx.tuning(small_max=10**9):
+        with ctx.tuning(small_max=10**9, tiny_max=0):
             q = ctx.scalar_mul_var(enc_all[:n], k[:n])
             qe = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
+        if n <= 2500:                                              # one wave per element, forced beyond its size
+            with ctx.tuning(small_max=10**9, tiny_max=10**9):
+                qw = ctx.scalar_mul_var(enc_all[:n], k[:n])
+                qwe = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
+            if not (torch.equal(qw[0], q[0]) and torch.equal(qw[1], q[1]) and torch.equal(qwe, qe)):
+                bad += 1
+                print("MISMATCH variable base (waves) n = %d" % n, flush=True)
         with ctx.tuning(small_max=0):
             l = ctx.scalar_mul_var(enc_all[:n], k[:n])
             le_ = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
