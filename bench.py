@@ -513,6 +513,25 @@ def main():
             ker, _ = time_op(torch, fn, 5, 2)
             small[name] = ker
         extra["small_batch_2^12_ms_per_call"] = small
+        # the smallest batches (up to one element per SIMD: 4 x the CUs) take one WAVE per element / point, lane-spread arithmetic
+        nt = 1 << 8
+        tiny = {}
+        for name, fn in [
+            ("msm", lambda: ctx.msm(pm[:nt], scalars[:nt])),
+            ("msm_encoded", lambda: ctx.msm(enc1[:nt], scalars[:nt])),
+            ("scalar_mul_var", lambda: ctx.scalar_mul_var(enc1[:nt], scalars[:nt], outs=[o1[:nt], s1[:nt]])),
+            ("scalar_mul_var_element", lambda: ctx.scalar_mul_var_element(pm[:nt], scalars[:nt])),
+        ]:
+            ker, _ = time_op(torch, fn, 5, 2)
+            tiny[name] = ker
+        extra["tiny_batch_2^8_ms_per_call"] = tiny
+        # mid-size MSMs (what a batch verifier holds): whole call
+        mid = {}
+        for lg in (16, 18):
+            if ne >= (1 << lg):
+                ker, _ = time_op(torch, lambda: ctx.msm(pm[:1 << lg], scalars[:1 << lg]), 5, 2)
+                mid["2^%d" % lg] = ker
+        extra["msm_mid_ms_per_call"] = mid
         aff = torch.empty((ne, 8), dtype=torch.int64, device=dev)
         ker, _ = time_op(torch, lambda: ctx.to_affine(pm, outs=[aff]), 3, 1)
         extra["to_affine"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}

@@ -1489,6 +1489,9 @@ def test_bench_line_contract():
     assert abs(d_["value"] - (1 << 16) * 2 / (d_["ms_per_step"] * 2e-3)) / d_["value"] < 1e-6
     small = d_["extra"]["small_batch_2^12_ms_per_call"]
     assert set(small) == {"msm", "msm_encoded", "scalar_mul_var", "scalar_mul_var_element", "scalar_mul_base"} and all(0 < v < 5 for v in small.values())
+    tiny = d_["extra"]["tiny_batch_2^8_ms_per_call"]
+    assert set(tiny) == {"msm", "msm_encoded", "scalar_mul_var", "scalar_mul_var_element"} and all(0 < v < 5 for v in tiny.values())
+    assert set(d_["extra"]["msm_mid_ms_per_call"]) == {"2^16"}
 
 
 def test_bench_self_launches_its_ranks():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies what tools/round_artifacts.sh produced (merged back by gpurun) into profiles/ under this round's names.
-# usage: tools/copy_artifacts.sh gpurun_out/r03/final3 r03
+# usage: tools/copy_artifacts.sh gpurun_out/r04/final r04
 F=$1; R=$2
 cp $F/pmc/pmc_traffic.json profiles/pmc_traffic.json
 sed -i "s#\"source\": \"$F/pmc/pmc_summary.csv\"#\"source\": \"profiles/${R}_pmc_summary.csv\"#" profiles/pmc_traffic.json
@@ -17,4 +17,8 @@ grep -v "amdgpu.ids" $F/soak.txt > profiles/${R}_soak.txt
 grep -v "amdgpu.ids" $F/host_path.txt > profiles/${R}_host_path.txt
 grep -v "amdgpu.ids" $F/hbm_priced_ops.txt > profiles/${R}_hbm_priced_ops.txt
 [ -f $F/route_stress.txt ] && grep -v "amdgpu.ids" $F/route_stress.txt > profiles/${R}_route_stress.txt
+for f in size_sweep_quarter size_sweep_msm row_ops; do [ -f $F/$f.txt ] && grep -v "amdgpu.ids\|warning\|hipFree\|\^~\|^ *[0-9]* |" $F/$f.txt > profiles/${R}_$f.txt; done
+[ -f $F/clock_vs_traffic.txt ] && cp $F/clock_vs_traffic.txt profiles/${R}_clock_vs_traffic_rerun.txt
 tools/resource_usage.sh > profiles/${R}_resource_usage.txt 2>/dev/null
+# the release check of the PMC record against the kernel sources in the tree (tests/test_abi.py, skipped in the ordinary suites)
+D377_CHECK_ARTEFACTS=1 python3 -m pytest tests/test_abi.py -q -k pmc_record | tail -1
