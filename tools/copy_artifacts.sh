@@ -6,7 +6,7 @@ cp $F/pmc/pmc_traffic.json profiles/pmc_traffic.json
 sed -i "s#\"source\": \"$F/pmc/pmc_summary.csv\"#\"source\": \"profiles/${R}_pmc_summary.csv\"#" profiles/pmc_traffic.json
 cp $F/pmc/pmc_summary.csv profiles/${R}_pmc_summary.csv
 cp $F/pmc/kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
-tail -1 $F/pmc/bench_under_rocprof.log > profiles/${R}_bench_line_under_rocprof.json
+grep "^{" $F/pmc/bench_under_rocprof.log | tail -1 > profiles/${R}_bench_line_under_rocprof.json
 tail -1 $F/bench_line.json > profiles/${R}_bench_line.json
 grep -v "amdgpu.ids" $F/size_sweep.txt > profiles/${R}_size_sweep.txt
 cp $F/msm_kernel_breakdown.txt profiles/${R}_msm_kernel_breakdown.txt
