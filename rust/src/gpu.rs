@@ -71,6 +71,23 @@ impl GpuContext {
     pub fn num_devices(&self) -> usize {
         unsafe { ffi::d377_ctx_num_devices(self.0) as usize }
     }
+    /// (lane sets claimed now, workgroups that waited > 0.25 s for one, workgroups that gave up after 10 s) of device `dev`:
+    /// (0, 0, 0) on a healthy idle context.  Does not wait for running kernels.
+    pub fn health(&self, dev: i32) -> Result<(i32, u64, u64), GpuError> {
+        let (mut claimed, mut waited, mut gave_up) = (0i32, 0u64, 0u64);
+        check(unsafe { ffi::d377_ctx_health(self.0, dev, &mut claimed, &mut waited, &mut gave_up) })?;
+        Ok((claimed, waited, gave_up))
+    }
+    /// Frees lane sets leaked by a launch that died; returns how many it freed (0 on a healthy context).
+    pub fn reset_scratch(&self, dev: i32) -> Result<i32, GpuError> {
+        let mut freed = 0i32;
+        check(unsafe { ffi::d377_ctx_reset_scratch(self.0, dev, &mut freed) })?;
+        Ok(freed)
+    }
+    /// Developer interface: override one launch rule (`ffi::D377_TUNE_*`); `None` restores the built-in rule.
+    pub fn set_tuning(&self, key: i32, value: Option<i64>) -> Result<(), GpuError> {
+        check(unsafe { ffi::d377_ctx_set_tuning(self.0, key, value.unwrap_or(ffi::D377_TUNE_DEFAULT as i64)) })
+    }
 }
 impl Drop for GpuContext {
     fn drop(&mut self) {
