@@ -162,6 +162,11 @@ D377_HD bool fe_strict_is_zero(const fe& a) {
 // uv = z^((m+1)/2), z = num/den, WITHOUT an inversion -- s = den^(2^47-1), t = s^2 den, w = (num t)^((m-1)/2) s,
 // whose exponent of den is -(m+1)/2 modulo q - 1 -- at the price of the 46 S + 9 M chain for s; with 1/den at hand
 // the same two field values are z^((m-1)/2) and its product with z, and everything after them is unchanged.
+// The table phase and everything after it (invsqrt.rs:97-166), from v = z^((m-1)/2) and uv = z^((m+1)/2): shared by
+// fe_sqrt_ratio_zeta below and by the callers that raise z to those powers elsewhere (the one-wave-per-element kernels:
+// row_ops.hpp runs the 300 products of the power chains in the lane-spread form).
+D377_HD bool fe_sqrt_tail(const SqrtTables& T, const fe& v, const fe& uv, bool den_zero, bool num_zero, fe* res, bool min_curve_root);
+
 template <bool NUM_IS_ONE, class PT>
 D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, const fe& den, fe* res,
                                 bool min_curve_root = false, const fe* inv_den = nullptr, bool use_inv = true) {
@@ -184,6 +189,9 @@ D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, cons
     v = fe_mul(w, den);                               // :93
     uv = NUM_IS_ONE ? w : fe_mul(w, num);             // :94
   }
+  return fe_sqrt_tail(T, v, uv, den_zero, num_zero, res, min_curve_root);
+}
+D377_HD bool fe_sqrt_tail(const SqrtTables& T, const fe& v, const fe& uv, bool den_zero, bool num_zero, fe* res, bool min_curve_root) {
   fe x5 = fe_mul(uv, v);                            // :97
   fe x4 = fe_sqr_n(x5, 8);                          // :101-107
   fe x3 = fe_sqr_n(x4, 8);
@@ -231,7 +239,7 @@ D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, cons
   bool was_square = !nonsq;
   // early-outs of invsqrt.rs:81-86, applied as selects so the wave stays converged
   if (den_zero) { r = fe_zero(); was_square = false; }
-  if (!NUM_IS_ONE && num_zero) { r = fe_zero(); was_square = true; }
+  if (num_zero) { r = fe_zero(); was_square = true; }
   *res = r;
   return was_square;
 }
@@ -249,6 +257,38 @@ D377_HD fe fe_from_words_mod_order_strict(const uint32_t w[8]) {   // value < 2q
 // chunks, value = lo + 2^256 * hi (hi zero-padded).  The result is a lazy sum of two products.
 D377_HD fe fe_from_wide_words(const uint32_t lo[8], const uint32_t hi[8]) {
   return fe_add(fe_mul(fe_from_words(lo), fe_const(FE_R2)), fe_mul(fe_from_words(hi), fe_const(FE_R2_SHIFT256)));
+}
+// A whole element <-> the 10 x 28-bit limbs of the lane-spread form (row_ops.hpp: plain residues, one 16-word record per
+// element, words 10..15 zero).  Out: the canonical value.  In: lazily reduced limbs (each below 2^29, value below 2^273:
+// what row_mul leaves), back as a PRODUCT -- tight limbs, value < 9q, what every consumer of a whole element (doubling,
+// cached forms, the encoder) is specified for.  (The sum of the two wide-reduction products by itself is lazy with a value
+// up to 18q and was handed on like that at first: the doubling of such a point overflowed a column for some inputs.)
+D377_HD void fe_to_limbs28(const fe& x, uint32_t rec16[16]) {
+  uint32_t w[8];
+  fe_to_words(fe_canon(x), w);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const int bit = 28 * k, lo = bit >> 5, sh = bit & 31;
+    uint32_t v = w[lo] >> sh;
+    if (sh + 28 > 32 && lo + 1 < 8) v |= w[lo + 1] << (32 - sh);
+    rec16[k] = v & 0x0FFFFFFFu;
+  }
+#pragma unroll
+  for (int k = 10; k < 16; ++k) rec16[k] = 0;
+}
+D377_HD fe fe_from_limbs28(const uint32_t rec16[16]) {
+  uint32_t w[9];
+  uint64_t acc = 0;                                                // the integer, 32 bits at a time
+  int have = 0, wi = 0;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    acc += (uint64_t)rec16[k] << have;                             // limbs below 2^29: the carry rides in acc
+    have += 28;
+    if (have >= 32) { w[wi++] = (uint32_t)acc; acc >>= 32; have -= 32; }
+  }
+  w[wi] = (uint32_t)acc;                                           // wi == 8: bits 256 .. (value < 2^273)
+  const uint32_t hi[8] = {w[8], 0, 0, 0, 0, 0, 0, 0};
+  return fe_mul(fe_from_wide_words(w, hi), fe_const(FE_ONE));      // (lo R + hi 2^256 R), then times R / R
 }
 // Montgomery-261 -> canonical 32 bytes (Fq::to_bytes_le)
 D377_HD void fe_to_bytes_words(const fe& a, uint32_t w[8]) { fe_to_words(fe_canon(a), w); }
@@ -540,8 +580,9 @@ D377_HD fe ge_decompress_den(const uint32_t w[8]) {
   fe u1sq = fe_sqr_strict(fe_sub(fe_const(FE_ONE), ss));
   return fe_mul_strict(fe_sub(u1sq, fe_mul(fe_const(FE_4D), ss)), u1sq);
 }
-template <class PT>
-D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8], ge* out, const fe* inv_den = nullptr) {
+// SQRT: (den, &v) -> was_square, the square root of 1 / den (encoding.rs:57)
+template <class SQRT>
+D377_HD uint32_t ge_decompress_with(const SqrtTables& T, const uint32_t w[8], ge* out, SQRT sqrt_of) {
   uint32_t bad = (w[7] >> 29) != 0;                       // top three bits, encoding.rs:34
   bad |= (uint32_t)words_geq(w, FQ_MODULUS_W_LIT);        // canonical, :43-44
   bad |= (w[0] & 1u);                                     // s negative, :45
@@ -551,7 +592,7 @@ D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8],
   fe u1sq = fe_sqr_strict(u1);                            // strict: keeps den below 2q for the zero test
   fe u2 = fe_sub(u1sq, fe_mul(fe_const(FE_4D), ss));      // :54
   fe v;
-  const bool was_square = fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), fe_mul_strict(u2, u1sq), &v, false, inv_den);   // :57
+  const bool was_square = sqrt_of(fe_mul_strict(u2, u1sq), &v);                                                     // :57
   bad |= (uint32_t)!was_square;                           // :58-60
   fe two_s_u1 = fe_mul(fe_dbl(s), u1);                    // :63
   if (fe_is_negative(fe_mul(two_s_u1, v))) v = fe_neg(v); // :64-67
@@ -561,6 +602,18 @@ D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8],
   out->t = fe_mul(out->x, out->y);
   D377_INVARIANT(T, *out, bad == 0);                      // encoding.rs:75-78 / element.rs:104-110
   return bad;
+}
+template <class PT>
+D377_HD uint32_t ge_decompress(const SqrtTables& T, PT& pt, const uint32_t w[8], ge* out, const fe* inv_den = nullptr) {
+  return ge_decompress_with(T, w, out, [&](const fe& den, fe* v) {
+    return fe_sqrt_ratio_zeta<true>(T, pt, fe_zero(), den, v, false, inv_den);
+  });
+}
+// the same with v = (1/den)^((m-1)/2), uv = (1/den)^((m+1)/2) raised elsewhere (see fe_sqrt_tail)
+D377_HD uint32_t ge_decompress_from_powers(const SqrtTables& T, const uint32_t w[8], const fe& pv, const fe& puv, ge* out) {
+  return ge_decompress_with(T, w, out, [&](const fe& den, fe* v) {
+    return fe_sqrt_tail(T, pv, puv, fe_strict_is_zero(den), false, v, false);
+  });
 }
 
 // Element::vartime_compress, src/ark_curve/encoding.rs:91-128 -> canonical words of s

@@ -474,16 +474,12 @@ k_scalar_mul_var_small(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar
 template <bool ELEMENT>
 __global__ void __launch_bounds__(64)
 k_scalar_mul_var_tiny(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, uint8_t* out32, uint8_t* status) {
-  __shared__ uint32_t lds_pow_[ELEMENT ? 1 : POW_TAB * NL * 64];
   __shared__ uint32_t tab[row::RQ_TAB_ENTRIES * row::RQ_WORDS];
-  __shared__ uint32_t xrec[row::RQ_WORDS];
-  struct Pow64 {
-    uint32_t* col;
-    __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
-    __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
-  } pt;
-  pt.col = lds_pow_ + threadIdx.x;
+  __shared__ uint32_t xrec[2 * row::RQ_WORDS];
+  struct NoPow { __device__ __forceinline__ void put(int, const fe&) {} __device__ __forceinline__ fe get(int) const { return fe_zero(); } } pt;   // (the encoder takes a table it does not use)
   const int t = threadIdx.x;
+  const row::RowK K = row::row_consts();
+  const row::RowSel S = row::row_sel();
   const size_t e = blockIdx.x;                                   // grid = n
   uint32_t w[8], k[8], dg[8];
   load32(scalar32, e, k);
@@ -494,14 +490,22 @@ k_scalar_mul_var_tiny(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar3
     g = load_ge_mont256(reinterpret_cast<const uint64_t*>(enc32), e);
   } else {
     load32(enc32, e, w);
-    bad = ge_decompress(T, pt, w, &g);                            // every lane: the same chain of squarings
+    // the square root's power chains in the lane-spread form (every row the same element), its table phase and the rest of
+    // the decompression as whole-element code
+    if (t < 4) row::row_store_from_fe(xrec + 16 * t, ge_decompress_den(w));
+    __syncthreads();
+    const row::RowPowers pw = row::row_sqrt_powers(xrec[t], tab, t, K);
+    __syncthreads();
+    xrec[t] = pw.v; xrec[row::RQ_WORDS + t] = pw.uv;
+    __syncthreads();
+    const fe pv = row::row_load_to_fe(xrec), puv = row::row_load_to_fe(xrec + row::RQ_WORDS);
+    __syncthreads();
+    bad = ge_decompress_from_powers(T, w, pv, puv, &g);
     fr_half_words(k);                                            // [k]P = [2]([k/2 mod r]P): the encoding of a double needs no square root
   }
   fr_recode_signed16(k, dg);
   if (t < 4) row::row_store_from_fe(xrec + 16 * t, fe_pick(t, g.x, g.y, g.z, g.t));
   __syncthreads();
-  const row::RowK K = row::row_consts();
-  const row::RowSel S = row::row_sel();
   const uint32_t v = row::rq_scalar_mul_w4(xrec[t], dg, tab, S, K);
   __syncthreads();
   xrec[t] = v;

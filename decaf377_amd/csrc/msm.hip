@@ -986,12 +986,11 @@ k_msm_small(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n,
 template <bool ENCODED>
 __global__ void __launch_bounds__(64)
 k_msm_tiny(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, uint32_t* partial, uint8_t* status) {
-  __shared__ uint32_t lds_pow_[ENCODED ? POW_TAB * NL * 64 : 1];
   __shared__ uint32_t tab[row::RQ_TAB_ENTRIES * RQ_WORDS];
-  __shared__ uint32_t xrec[RQ_WORDS];
-  Pow64 pt;
-  pt.col = lds_pow_ + threadIdx.x;
+  __shared__ uint32_t xrec[2 * RQ_WORDS];
   const int t = threadIdx.x;
+  const row::RowK K = row::row_consts();
+  const row::RowSel S = row::row_sel();
   const size_t e = blockIdx.x;                                     // grid = n
   uint32_t k[8], dg[8];
   load32(scalar32, e, k);
@@ -1003,7 +1002,17 @@ k_msm_tiny(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, 
   if (ENCODED) {
     uint32_t w[8];
     load32(reinterpret_cast<const uint8_t*>(pts_in), e, w);
-    const uint32_t bad = ge_decompress(T, pt, w, &g);              // every lane: the same chain of squarings
+    // the square root's two power chains (~300 products) in the lane-spread form, every row the same element; its table
+    // phase and the rest of the decompression as whole-element code, every lane alike
+    if (t < 4) row::row_store_from_fe(xrec + 16 * t, ge_decompress_den(w));
+    __syncthreads();
+    const row::RowPowers pw = row::row_sqrt_powers(xrec[t], tab, t, K);
+    __syncthreads();
+    xrec[t] = pw.v; xrec[RQ_WORDS + t] = pw.uv;
+    __syncthreads();
+    const fe pv = row::row_load_to_fe(xrec), puv = row::row_load_to_fe(xrec + RQ_WORDS);
+    __syncthreads();
+    const uint32_t bad = ge_decompress_from_powers(T, w, pv, puv, &g);
     if (t == 0) status[e] = (uint8_t)bad;
     skip = bad != 0;                                               // invalid points contribute nothing
   } else {
@@ -1014,8 +1023,6 @@ k_msm_tiny(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, 
   if (skip) g = ge_identity();
   if (t < 4) row::row_store_from_fe(xrec + 16 * t, fe_pick(t, g.x, g.y, g.z, g.t));   // lanes 0..3: one coordinate each
   __syncthreads();
-  const row::RowK K = row::row_consts();
-  const row::RowSel S = row::row_sel();
   const uint32_t v = row::rq_scalar_mul_w4(xrec[t], dg, tab, S, K);
   __syncthreads();
   xrec[t] = v;

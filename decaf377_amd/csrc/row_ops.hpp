@@ -242,37 +242,61 @@ __device__ __forceinline__ uint32_t rq_scalar_mul_w4(uint32_t v1, const uint32_t
   return v;
 }
 
-// ---- between the two forms (whole field elements in a lane, Montgomery 9 x 29 <-> plain 10 x 28 across a row) --------
-// one lane writes an element as a row record: 16 words, canonical value, limbs 10..15 zero
-__device__ __forceinline__ void row_store_from_fe(uint32_t* rec16, const fe& x) {
-  uint32_t w[8];
-  fe_to_words(fe_canon(x), w);
-#pragma unroll
-  for (int k = 0; k < RL; ++k) {
-    const int bit = RW * k, lo = bit >> 5, sh = bit & 31;
-    uint32_t v = w[lo] >> sh;
-    if (sh + RW > 32 && lo + 1 < 8) v |= w[lo + 1] << (32 - sh);
-    rec16[k] = v & M28;
-  }
-#pragma unroll
-  for (int k = RL; k < 16; ++k) rec16[k] = 0;
+// ---- the power chains of the square root (curve.hpp: fe_pow_2_47_m1, fe_pow_m12) in the lane-spread form ---------------
+// A square root is ~300 dependent products before its table phase; with one element per wave (or per row) they run here at
+// ~0.2 us each instead of ~0.33.  The table phase stays whole-element code (fe_sqrt_tail: canonical values, hash keys).
+__device__ __forceinline__ uint32_t row_sqr_n(uint32_t x, int n, const RowK& K) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) x = row_mul(x, x, K);
+  return x;
 }
-// one lane reads a (tight) row record back: Montgomery form, a lazy sum of two products
-__device__ __forceinline__ fe row_load_to_fe(const uint32_t* rec16) {
-  uint32_t w[9];
-  uint64_t acc = 0;                                                // the integer, 32 bits at a time
-  int have = 0, wi = 0;
-#pragma unroll
-  for (int k = 0; k < RL; ++k) {
-    acc += (uint64_t)rec16[k] << have;                             // limbs below 2^29: the carry rides in acc
-    have += RW;
-    if (have >= 32) { w[wi++] = (uint32_t)acc; acc >>= 32; have -= 32; }
+// x^(2^47 - 1): 46 S + 9 M, the chain of fe_pow_2_47_m1
+__device__ __forceinline__ uint32_t row_pow_2_47_m1(uint32_t x, const RowK& K) {
+  const uint32_t e2 = row_mul(row_mul(x, x, K), x, K);
+  const uint32_t e4 = row_mul(row_sqr_n(e2, 2, K), e2, K);
+  const uint32_t e5 = row_mul(row_mul(e4, e4, K), x, K);
+  const uint32_t e10 = row_mul(row_sqr_n(e5, 5, K), e5, K);
+  const uint32_t e11 = row_mul(row_mul(e10, e10, K), x, K);
+  const uint32_t e22 = row_mul(row_sqr_n(e11, 11, K), e11, K);
+  const uint32_t e23 = row_mul(row_mul(e22, e22, K), x, K);
+  const uint32_t e46 = row_mul(row_sqr_n(e23, 23, K), e23, K);
+  return row_mul(row_mul(e46, e46, K), x, K);
+}
+// x^((m-1)/2) by the fixed sliding-window schedule D377_POW_CHAIN; the POW_TAB odd powers in `tab` (POW_TAB x 64 words of
+// LDS that belong to this wave; lane t uses word t of every entry)
+__device__ __forceinline__ uint32_t row_pow_m12(uint32_t x, uint32_t* tab, int t, const RowK& K) {
+  const uint32_t x2 = row_mul(x, x, K);
+  uint32_t cur = x;
+  tab[t] = cur;
+#pragma unroll 1
+  for (int j = 1; j < POW_TAB; ++j) {
+    cur = row_mul(cur, x2, K);
+    tab[j * 64 + t] = cur;
   }
-  w[wi] = (uint32_t)acc;                                           // wi == 8: bits 256 .. (value < 2^273)
-  uint32_t hi[8] = {w[8], 0, 0, 0, 0, 0, 0, 0};
-  return fe_from_wide_words(w, hi);
+  uint32_t acc = tab[((int)(D377_POW_CHAIN[0] & 15u) >> 1) * 64 + t];     // (a lane reads back only words it wrote itself)
+#pragma unroll 1
+  for (int i = 1; i < D377_POW_LEN; ++i) {
+    const uint32_t e = D377_POW_CHAIN[i];
+    acc = row_sqr_n(acc, (int)(e >> 4), K);
+    acc = row_mul(acc, tab[((int)(e & 15u) >> 1) * 64 + t], K);
+  }
+  return row_sqr_n(acc, D377_POW_TRAIL, K);
+}
+// v = (1 / den)^((m-1)/2) and uv = (1 / den)^((m+1)/2) without an inversion, as invsqrt.rs:88-94 builds them for num = 1:
+// s = den^(2^47 - 1), t = s^2 den, w = t^((m-1)/2) s, v = w den, uv = w
+struct RowPowers { uint32_t v, uv; };
+__device__ __forceinline__ RowPowers row_sqrt_powers(uint32_t den, uint32_t* tab, int t, const RowK& K) {
+  const uint32_t s = row_pow_2_47_m1(den, K);
+  const uint32_t t_ = row_mul(row_mul(s, s, K), den, K);
+  const uint32_t w = row_mul(row_pow_m12(t_, tab, t, K), s, K);
+  return RowPowers{row_mul(w, den, K), w};
 }
 
+// ---- between the two forms (whole field elements in a lane, Montgomery 9 x 29 <-> plain 10 x 28 across a row) --------
+// one lane writes an element as a row record (16 words, canonical value, limbs 10..15 zero) / reads a tight record back as
+// a product: curve.hpp fe_to_limbs28 / fe_from_limbs28 (whole-element code, so the host build checks its bounds)
+__device__ __forceinline__ void row_store_from_fe(uint32_t* rec16, const fe& x) { fe_to_limbs28(x, rec16); }
+__device__ __forceinline__ fe row_load_to_fe(const uint32_t* rec16) { return fe_from_limbs28(rec16); }
 
 // A point as row records: four rows of 16 words (X, Y, Z, T, or the cached form Y - X, Y + X, 2dT, Z), written by ONE lane
 // from whole coordinates; and back, every lane the whole point.

@@ -247,6 +247,41 @@ void sim_quad_forms(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* db
     (void)q_add(q_add(s1, rec, true), q_cached(q_to_ge(s1)), false);      // sums of sums (the trees), a sum as the cached operand
   }
 }
+// The lane-spread kernels' way in and out (msm.hip k_msm_final / k_msm_wsum_window / k_msm_tiny, d377.hip
+// k_scalar_mul_var_tiny): a point to four records of 10 x 28-bit limbs and back, and then everything those kernels do with
+// a point that came back -- the doubling of the final result, its negation, the encoder's state, the cached forms for the
+// lane and quad chains, the table phase of a square root whose powers came back the same way.  `slack` is added to every
+// limb of the records first (the rows hand back lazily reduced limbs; 0 <= slack < 2^12), with the value it adds removed
+// from limb 0's neighbour so that the element stays the same: limbs (l0 + s, l1 - ... ) is not expressible in general, so
+// the record is re-split instead: limb k gives up 2^28 to limb k-1 wherever it can.
+void sim_row_records(const uint32_t* p, size_t n, int lazy, uint32_t* back, uint32_t* dbl, uint32_t* enc) {
+  for (size_t i = 0; i < n; ++i) {
+    const ge a = ge_load256(p + 32 * i);
+    uint32_t rec[4][16];
+    fe_to_limbs28(a.x, rec[0]); fe_to_limbs28(a.y, rec[1]); fe_to_limbs28(a.z, rec[2]); fe_to_limbs28(a.t, rec[3]);
+    if (lazy)                                                    // the same integers with limbs above 2^28: borrow downwards
+      for (int r = 0; r < 4; ++r)
+        for (int k = 9; k >= 1; --k)
+          if (rec[r][k] > 0) { rec[r][k] -= 1; rec[r][k - 1] += 1u << 28; }
+    ge g;
+    g.x = fe_from_limbs28(rec[0]); g.y = fe_from_limbs28(rec[1]); g.z = fe_from_limbs28(rec[2]); g.t = fe_from_limbs28(rec[3]);
+    ge_store256(g, back + 32 * i);
+    ge_store256(ge_double(g), dbl + 32 * i);
+    (void)ge_neg(g);
+    const Quad rec4 = q_cached(g);                               // gq_store_cached's record
+    (void)q_add(q_double_neg(Quad{{g.x, g.y, g.z, g.t}}), rec4, true);
+    uint32_t cached[16];                                         // rq_store_cached: lazy sums go through fe_canon
+    fe_to_limbs28(fe_sub(g.y, g.x), cached); fe_to_limbs28(fe_add(g.y, g.x), cached); fe_to_limbs28(fe_mul(fe_const(FE_K), g.t), cached);
+    (void)ge_add(g, ge_double(g));                               // partial results summed by k_msm_small_sum / k_msm_combine
+    HostDcbIO io;                                                // msm_emit_doubled: the encoding of [2]g without a square root
+    io.out = enc; io.base = i;
+    dcb_put(io, 0, ge_dcb_from_half(g, false));
+    RegPowTab pt;
+    dcb_finish(pt, io, 1);
+    fe root;
+    (void)fe_sqrt_tail(g_T, g.x, g.y, false, false, &root, false);   // powers that came back from the rows into the table phase
+  }
+}
 // reference-form addition and negation (the API kernels k_add / k_neg / k_hash_to_curve use them)
 void sim_group_misc(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* sum, uint32_t* neg) {
   for (size_t i = 0; i < n; ++i) {

@@ -489,6 +489,8 @@ L.sim_scalar_mul_base(p(k), n_(n), p(out))
 L.sim_double_variants(p(xyzt), n_(n), p(x2), p(a), p(b))
 L.sim_group_misc(p(xyzt), p(x2), n_(n), p(a), p(b))
 L.sim_quad_forms(p(xyzt), p(x2), n_(n), p(a), p(b), p(np.zeros((n, 16), np.uint64)), p(np.zeros((n, 16), np.uint64)))
+for lazy in (0, 1):
+    L.sim_row_records(p(xyzt), n_(n), lazy, p(a), p(b), p(out)); L.sim_row_records(p(x2), n_(n), lazy, p(a), p(b), p(out))
 L.sim_to_affine_raw(p(xyzt), n_(n), p(np.zeros((n, 8), np.uint64))); L.sim_to_affine_raw(p(np.full((n, 16), 0xFFFFFFFFFFFFFFFF, np.uint64)), n_(n), p(np.zeros((n, 8), np.uint64)))
 L.sim_decompress(p(enc), n_(n), p(x2), p(st)); L.sim_msm_bucket(p(x2), p(np.array([0, 1, 1, 0, 0, 1, 0, 1], np.uint8)), n_(n), p(a)); L.sim_msm_bucket(p(x2), p(np.ones(n, np.uint8)), n_(2), p(a)); L.sim_msm_bucket(p(x2), p(np.zeros(n, np.uint8)), n_(3), p(a))
 f = [np.zeros((n, 4), np.uint64) for _ in range(5)]
@@ -632,6 +634,25 @@ def test_four_lane_forms_agree(sim, oracle):
     for got, w in zip(out, want):
         assert oracle.eq_xyzt(got, w).all() and (oracle.compress(got) == oracle.compress(w)).all()
     assert oracle.is_identity(out[2][2:3]).all()
+
+
+def test_row_records_round_trip(sim, oracle):
+    """Whole elements in and out of the lane-spread form's records (curve.hpp fe_to_limbs28 / fe_from_limbs28: what
+    k_msm_final, k_msm_tiny and k_scalar_mul_var_tiny do at either end of their chains): the point that comes back is the
+    point that went in, also when the record's limbs are lazily reduced (above 2^28, as the rows leave them); its doubling
+    and the square-root-free encoding of that doubling are the oracle's."""
+    rng = np.random.default_rng(41)
+    n = 48
+    P = oracle.double_xyzt(oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
+    P[0] = oracle.identity_xyzt()
+    for lazy in (0, 1):
+        back, dbl = np.zeros((n, 16), np.uint64), np.zeros((n, 16), np.uint64)
+        enc = np.zeros((n, 32), np.uint8)
+        sim.sim_row_records(_p(P), n_(n), lazy, _p(back), _p(dbl), _p(enc))
+        assert (back == P).all()                                  # canonical limbs both ways: the same records
+        want = oracle.double_xyzt(P)
+        assert oracle.eq_xyzt(dbl, want).all()
+        assert (enc == oracle.compress(want)).all()
 
 
 def test_to_affine_on_raw_records(sim, oracle):
