@@ -979,51 +979,82 @@ k_msm_small(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n,
   if (quad == 0) slot_store(partial + (size_t)blockIdx.x * PT_WORDS + role * SLOT, v);   // X, Y, Z, T: pt_store_ext's layout
 }
 
-// ---- the smallest batches: one WAVE per point ---------------------------------------------------------------------------
+// ---- the smallest batches: a WAVE per point, or per few points ------------------------------------------------------------
 // Up to one point per SIMD (4 x the CUs: 1 024 on an MI355X) even the quads leave most of the chip idle, and the call is one
 // point's chain of 252 doublings.  In the lane-spread form (row_ops.hpp) that chain is half as long: every wave computes
 // [k_i / 2]P_i with the point across its four rows, converts back and writes one partial; k_msm_small_sum adds them up.
+// Up to MT_MAX points per SIMD a wave takes `m` points (wave b: points b, b + grid, ...) and shares the doublings between them
+// (Straus): 252 doublings and m x 63 additions -- 0.12 + m x 0.04 ms against 0.35 ms for a quad per point.  The square roots of
+// Encoding inputs run their power chains on the four ROWS of the wave at once, one point per row.
+constexpr int MT_MAX = 4;
 template <bool ENCODED>
 __global__ void __launch_bounds__(64)
-k_msm_tiny(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, uint32_t* partial, uint8_t* status) {
-  __shared__ uint32_t tab[row::RQ_TAB_ENTRIES * RQ_WORDS];
+k_msm_tiny(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, int m, uint32_t* partial, uint8_t* status) {
+  __shared__ uint32_t tab[MT_MAX * row::RQ_TAB_ENTRIES * RQ_WORDS];
   __shared__ uint32_t xrec[2 * RQ_WORDS];
+  __shared__ uint32_t sdg[MT_MAX][8];                                // the points' signed digits (wave-uniform reads in the loop)
   const int t = threadIdx.x;
   const row::RowK K = row::row_consts();
   const row::RowSel S = row::row_sel();
-  const size_t e = blockIdx.x;                                     // grid = n
-  uint32_t k[8], dg[8];
-  load32(scalar32, e, k);
-  fr_reduce_words(k);
-  fr_half_words(k);                                                // the sum is formed with k/2 mod r and doubled at the end
-  fr_recode_signed16(k, dg);
+  // lane t looks after point (t & 3) of the wave's m: e_mine (clamped to a real point; `mine` says whether it is one)
+  const int pj = t & 3;
+  const size_t e_raw = (size_t)blockIdx.x + (size_t)pj * gridDim.x;
+  const bool mine = pj < m && e_raw < n;
+  const size_t e_mine = mine ? e_raw : (size_t)blockIdx.x;
   ge g;
-  bool skip = false;
+  bool skip = !mine;
   if (ENCODED) {
     uint32_t w[8];
-    load32(reinterpret_cast<const uint8_t*>(pts_in), e, w);
-    // the square root's two power chains (~300 products) in the lane-spread form, every row the same element; its table
-    // phase and the rest of the decompression as whole-element code, every lane alike
+    load32(reinterpret_cast<const uint8_t*>(pts_in), e_mine, w);
+    // the square roots' power chains (~300 products each) in the lane-spread form, row r = point r of the wave; their table
+    // phases and the rest of the decompressions as whole-element code, lane t for point t & 3
     if (t < 4) row::row_store_from_fe(xrec + 16 * t, ge_decompress_den(w));
     __syncthreads();
     const row::RowPowers pw = row::row_sqrt_powers(xrec[t], tab, t, K);
     __syncthreads();
     xrec[t] = pw.v; xrec[RQ_WORDS + t] = pw.uv;
     __syncthreads();
-    const fe pv = row::row_load_to_fe(xrec), puv = row::row_load_to_fe(xrec + RQ_WORDS);
+    const fe pv = row::row_load_to_fe(xrec + 16 * pj), puv = row::row_load_to_fe(xrec + RQ_WORDS + 16 * pj);
     __syncthreads();
     const uint32_t bad = ge_decompress_from_powers(T, w, pv, puv, &g);
-    if (t == 0) status[e] = (uint8_t)bad;
-    skip = bad != 0;                                               // invalid points contribute nothing
+    if (t < 4 && mine) status[e_mine] = (uint8_t)bad;
+    skip |= bad != 0;                                              // invalid points contribute nothing
   } else {
-    g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), e);
-    skip = fe_is_zero(g.z);                                        // a record with z = 0 is no group element
-    D377_INVARIANT(T, g, t == 0 && !skip);
+    g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), e_mine);
+    skip |= fe_is_zero(g.z);                                       // a record with z = 0 is no group element
+    D377_INVARIANT(T, g, t < 4 && !skip);
   }
-  if (skip) g = ge_identity();
-  if (t < 4) row::row_store_from_fe(xrec + 16 * t, fe_pick(t, g.x, g.y, g.z, g.t));   // lanes 0..3: one coordinate each
-  __syncthreads();
-  const uint32_t v = row::rq_scalar_mul_w4(xrec[t], dg, tab, S, K);
+  // the points' digits (k / 2 mod r: the sum is doubled at the end) and tables, one point after the other
+#pragma unroll 1
+  for (int j = 0; j < m; ++j) {
+    const size_t e = (size_t)blockIdx.x + (size_t)j * gridDim.x;
+    const bool real = e < n;
+    uint32_t k[8], dg[8];
+    load32(scalar32, real ? e : (size_t)blockIdx.x, k);
+    fr_reduce_words(k);
+    fr_half_words(k);
+    fr_recode_signed16(k, dg);
+    // lanes j, j + 4, j + 8, j + 12 hold point j: each writes one coordinate
+    if (pj == j && t < 16) row::row_store_from_fe(xrec + 16 * (t >> 2), fe_pick(t >> 2, g.x, g.y, g.z, g.t));
+    __syncthreads();
+    const bool dead = __shfl((int)skip, j) != 0 || !real;          // (wave-uniform: lane j's verdict on point j)
+    if (t < 8) sdg[j][t] = dead ? 0x88888888u : dg[t];              // dead: every digit 0 (nibble 8 = value 0), the point contributes nothing
+    row::rq_build_table(dead ? row::rq_identity(S) : xrec[t], tab + j * row::RQ_TAB_ENTRIES * RQ_WORDS, S, K);
+    __syncthreads();
+  }
+  uint32_t v = row::rq_identity(S);
+#pragma unroll 1
+  for (int i = 63; i >= 0; --i) {
+    if (i != 63) {
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) v = row::rq_double_neg(v, S, K); // four sign-folded doublings keep the sign
+    }
+#pragma unroll 1
+    for (int j = 0; j < m; ++j) {
+      const int d = fr_digit(sdg[j], i);
+      if (d != 0) v = row::rq_add(v, tab + (j * row::RQ_TAB_ENTRIES + (d < 0 ? -d : d)) * RQ_WORDS, S, d < 0, K);
+    }
+  }
   __syncthreads();
   xrec[t] = v;
   __syncthreads();
@@ -1145,20 +1176,29 @@ int msm_reserve(DeviceState& d, hipStream_t s, size_t bytes, MsmHeld& held) {
 // Batches up to this many points skip the buckets (k_msm_small).  D377_TUNE_MSM_SMALL_MAX: developer override (0 = never).
 size_t msm_small_max(const DeviceState& d) { return (size_t)d.tuned(D377_TUNE_MSM_SMALL_MAX, (long long)d.cus * 4 * MS_QUADS); }
 
-// Batches up to this many points take one wave per point (k_msm_tiny): one wave per SIMD.  D377_TUNE_MSM_TINY_MAX: developer override.
-size_t msm_tiny_max(const DeviceState& d) { return (size_t)d.tuned(D377_TUNE_MSM_TINY_MAX, (long long)d.cus * 4); }
+// Batches up to this many points take a wave per 1 .. MT_MAX points (k_msm_tiny): one wave per SIMD, up to 4 (Elements) or 2
+// (Encodings: a square root per point) points each -- measured against the quads in profiles/r04_size_sweep_msm.txt.
+// D377_TUNE_MSM_TINY_MAX: developer override.
+size_t msm_tiny_max(const DeviceState& d, bool encoded) {
+  return (size_t)d.tuned(D377_TUNE_MSM_TINY_MAX, (long long)d.cus * 4 * (encoded ? 2 : MT_MAX));
+}
 
 int msm_launch_small(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,
                      uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
-  const bool tiny = n <= msm_tiny_max(d);
-  const size_t m = tiny ? n : (n + MS_QUADS - 1) / MS_QUADS;
+  const bool tiny = n <= msm_tiny_max(d, encoded);
+  // points per wave on the wave route: as few as keep one wave per SIMD (more only when a developer override asks for it)
+  size_t per_wave = (n + (size_t)d.cus * 4 - 1) / ((size_t)d.cus * 4);
+  if (per_wave > MT_MAX) per_wave = MT_MAX;
+  if (per_wave < 1) per_wave = 1;
+  const size_t waves = (n + per_wave - 1) / per_wave;
+  const size_t m = tiny ? waves : (n + MS_QUADS - 1) / MS_QUADS;
   MsmHeld held{d.msm.guard, s, false};
   int rc;
   if ((rc = msm_reserve(d, s, m * PT_WORDS * 4, held))) return rc;
   uint32_t* partial = (uint32_t*)d.msm.mem;
   const SqrtTables T = d.tables();
-  if (tiny && encoded) hipLaunchKernelGGL(k_msm_tiny<true>, dim3((unsigned)n), dim3(64), 0, s, T, pts_in, scalars, n, partial, status);
-  else if (tiny) hipLaunchKernelGGL(k_msm_tiny<false>, dim3((unsigned)n), dim3(64), 0, s, T, pts_in, scalars, n, partial, status);
+  if (tiny && encoded) hipLaunchKernelGGL(k_msm_tiny<true>, dim3((unsigned)waves), dim3(64), 0, s, T, pts_in, scalars, n, (int)per_wave, partial, status);
+  else if (tiny) hipLaunchKernelGGL(k_msm_tiny<false>, dim3((unsigned)waves), dim3(64), 0, s, T, pts_in, scalars, n, (int)per_wave, partial, status);
   else if (encoded) hipLaunchKernelGGL(k_msm_small<true>, dim3((unsigned)m), dim3(MS_THREADS), 0, s, T, pts_in, scalars, n, partial, status);
   else hipLaunchKernelGGL(k_msm_small<false>, dim3((unsigned)m), dim3(MS_THREADS), 0, s, T, pts_in, scalars, n, partial, status);
   hipLaunchKernelGGL(k_msm_small_sum, dim3(1), dim3(MSS_THREADS), 0, s, T, partial, (int)m, enc_out, xyzt_out);

@@ -94,6 +94,16 @@ template <int M> struct FoldFetch {
 };
 template <> struct FoldFetch<11> { static __device__ __forceinline__ void run(uint32_t, uint32_t (&)[11]) {} };
 
+// acc + a * k for a multiplicand k that does not change inside a loop (the fold constants).  Written as the instruction itself:
+// from `acc + (uint64_t)a * k` the compiler hoists the widening of k out of the loop, and when the widened value then
+// reaches the loop through a join of two paths it no longer knows that the upper half is zero and multiplies 64 x 32 bits
+// -- two multiply-adds and two moves where one multiply-add does (seen in k_msm_tiny: 82 instead of 54 per doubling).
+__device__ __forceinline__ uint64_t mad_k(uint32_t a, uint32_t k, uint64_t acc) {
+  uint64_t r, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(k), "v"(acc));
+  return r;
+}
+
 // a * b mod q (lazily reduced: tight).  a, b: tight or lazy, lanes 10..15 zero.
 __device__ __forceinline__ uint32_t row_mul(uint32_t a, uint32_t b, const RowK& K) {
   // The 19 columns of the product.  The row has 16 lanes, so lane j of L takes column j for ALL j = 0..15 (b's lanes
@@ -117,14 +127,14 @@ __device__ __forceinline__ uint32_t row_mul(uint32_t a, uint32_t b, const RowK& 
   uint32_t hm[11];
   FoldFetch<0>::run(h, hm);
 #pragma unroll
-  for (int m = 0; m < 11; ++m) L += (uint64_t)hm[m] * K.fold[m];   // L + sum_m h_m FOLD[m]: < 2^64 per lane
+  for (int m = 0; m < 11; ++m) L = mad_k(hm[m], K.fold[m], L);   // L + sum_m h_m FOLD[m]: < 2^64 per lane
   const uint32_t n = split3(L);                          // limbs 0..11; 10 and 11 overhang the representation
   uint64_t R = (uint64_t)(n & K.valid);
-  R += (uint64_t)bcast<10>(n) * K.fold[0];
-  R += (uint64_t)bcast<11>(n) * K.fold[1];               // < 2^56: the value is below 2^283 now
+  R = mad_k(bcast<10>(n), K.fold[0], R);
+  R = mad_k(bcast<11>(n), K.fold[1], R);               // < 2^56: the value is below 2^283 now
   const uint32_t f = ((uint32_t)R & K.keep) + shr<1>((uint32_t)(R >> RW) & K.cmask);     // < 2^29.5, limb 9 whole
   const uint32_t t = bcast<9>(f) >> 20;                  // what the top limb holds above 2^272: ten bits
-  const uint64_t R3 = (uint64_t)(f & K.keep2) + (uint64_t)t * K.f272;
+  const uint64_t R3 = mad_k(t, K.f272, (uint64_t)(f & K.keep2));
   return ((uint32_t)R3 & K.keep) + shr<1>((uint32_t)(R3 >> RW) & K.cmask);
 }
 __device__ __forceinline__ uint32_t row_add(uint32_t a, uint32_t b) { return a + b; }
@@ -215,7 +225,8 @@ __device__ __forceinline__ uint32_t rq_cached_slot(uint32_t v, const RowSel& S, 
 // doublings, 1 addition) over a table of the cached slots of 0 .. 8 times P, 9 x 64 words of LDS that belong to this wave
 // (gq_scalar_mul_w4 of quad_ops.hpp with a wave where that has a quad).  v1: P in row form; every lane of the wave calls this.
 constexpr int RQ_TAB_ENTRIES = 9;
-__device__ __forceinline__ uint32_t rq_scalar_mul_w4(uint32_t v1, const uint32_t dg[8], uint32_t* tab, const RowSel& S, const RowK& K) {
+// the table of one point: entry j = the cached slots of [j]P, RQ_TAB_ENTRIES x 64 words (lane t: word t of every entry)
+__device__ __forceinline__ void rq_build_table(uint32_t v1, uint32_t* tab, const RowSel& S, const RowK& K) {
   const int t = S.r * 16 + S.j;
   const uint32_t one_or_zero = S.j == 0 ? 1u : 0u;
   tab[t] = S.r == 2 ? 0u : one_or_zero;                            // the identity's cached slots: 1, 1, 0, 1
@@ -228,9 +239,13 @@ __device__ __forceinline__ uint32_t rq_scalar_mul_w4(uint32_t v1, const uint32_t
     tab[j * 64 + t] = rq_cached_slot(acc, S, K);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const uint32_t id = (S.r == 1 || S.r == 2) ? one_or_zero : 0u;   // the identity: X = 0, Y = 1, Z = 1, T = 0
+}
+// the identity in row form: X = 0, Y = 1, Z = 1, T = 0
+__device__ __forceinline__ uint32_t rq_identity(const RowSel& S) { return ((S.r == 1 || S.r == 2) && S.j == 0) ? 1u : 0u; }
+__device__ __forceinline__ uint32_t rq_scalar_mul_w4(uint32_t v1, const uint32_t dg[8], uint32_t* tab, const RowSel& S, const RowK& K) {
+  rq_build_table(v1, tab, S, K);
   int d = fr_digit(dg, 63);                                        // 0 or 1
-  uint32_t v = d != 0 ? v1 : id;
+  uint32_t v = d != 0 ? v1 : rq_identity(S);
 #pragma unroll 1
   for (int i = 62; i >= 0; --i) {
 #pragma unroll 1
