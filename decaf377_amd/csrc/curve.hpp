@@ -1272,9 +1272,10 @@ D377_HD void dcb_invert_slot(IO& io, int slot, int cnt) {
 
 // (Fetching the next element's records ahead of the current one's work, here and in the round driver, was measured
 // and bought nothing: the waits are already covered.)
-template <class PT, class IO>
-D377_HD void dcb_finish(PT& pt, IO& io, int cnt) {
-  (void)pt;
+// `invert`: fe -> fe, the inversion of the one product (fe_invert in a lane; the one-wave kernels pass the whole wave's,
+// row_ops.hpp fe_invert_wave)
+template <class IO, class INV>
+D377_HD void dcb_finish_with(IO& io, int cnt, INV invert) {
   if (cnt <= 0) return;
   uint32_t w[8];
   fe c = fe_const(FE_ONE);
@@ -1285,7 +1286,7 @@ D377_HD void dcb_finish(PT& pt, IO& io, int cnt) {
     io.get(0, j, w);
     c = fe_mul_strict(c, fe_from_words(w));
   }
-  fe inv = fe_invert(c);
+  fe inv = invert(c);
 #pragma unroll 1
   for (int j = cnt - 1; j >= 0; --j) {
     io.parked(j, w);
@@ -1300,6 +1301,11 @@ D377_HD void dcb_finish(PT& pt, IO& io, int cnt) {
     fe_to_words(s, w);
     io.emit(j, w);
   }
+}
+template <class PT, class IO>
+D377_HD void dcb_finish(PT& pt, IO& io, int cnt) {
+  (void)pt;
+  dcb_finish_with(io, cnt, [](const fe& c) { return fe_invert(c); });
 }
 
 }  // namespace d377

@@ -476,7 +476,6 @@ __global__ void __launch_bounds__(64)
 k_scalar_mul_var_tiny(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, uint8_t* out32, uint8_t* status) {
   __shared__ uint32_t tab[row::RQ_TAB_ENTRIES * row::RQ_WORDS];
   __shared__ uint32_t xrec[2 * row::RQ_WORDS];
-  struct NoPow { __device__ __forceinline__ void put(int, const fe&) {} __device__ __forceinline__ fe get(int) const { return fe_zero(); } } pt;   // (the encoder takes a table it does not use)
   const int t = threadIdx.x;
   const row::RowK K = row::row_consts();
   const row::RowSel S = row::row_sel();
@@ -517,7 +516,7 @@ k_scalar_mul_var_tiny(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar3
   } else {
     OneDcbIO io;
     dcb_put(io, 0, ge_dcb_from_half(r, bad != 0));               // failed elements: neutral state, all-zero output
-    dcb_finish(pt, io, 1);
+    dcb_finish_with(io, 1, [](const fe& c) { return row::fe_invert_wave(c); });   // (every lane holds the same element)
     if (t == 0) {
       store32(out32, e, io.out);
       status[e] = (uint8_t)bad;

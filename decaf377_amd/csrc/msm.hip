@@ -873,11 +873,12 @@ struct OneIO {
 // r = sum (k_i / 2) P_i: the result is its double, whose encoding needs no square root (curve.hpp, "compression
 // without a square root") -- one element, so the inversion is not shared, but a divsteps inversion (~26 000
 // instructions) is still well under the ~67 000 of a square root on this one dependent chain.  Every lane of the
-// wave runs it; `first` writes.
-__device__ __forceinline__ void msm_emit_doubled(Pow64& pt, const ge& r, bool first, uint8_t* enc_out, uint64_t* xyzt_out) {
+// wave runs it, and the wave inverts together (row_ops.hpp fe_invert_wave: lane 0's value, 18 us instead of 31); `first`
+// (lane 0) writes.
+__device__ __forceinline__ void msm_emit_doubled(const ge& r, bool first, uint8_t* enc_out, uint64_t* xyzt_out) {
   OneIO io;
   dcb_put(io, 0, ge_dcb_from_half(r, false));
-  dcb_finish(pt, io, 1);
+  dcb_finish_with(io, 1, [](const fe& c) { return row::fe_invert_wave(c); });
   if (first) {
     if (xyzt_out) store_ge_mont256(xyzt_out, 0, ge_double(r));
     store32(enc_out, 0, io.out);
@@ -887,9 +888,6 @@ __device__ __forceinline__ void msm_emit_doubled(Pow64& pt, const ge& r, bool fi
 // Horner over the window sums S_w (lanes 0-3 of one wave), result as Element record and as encoding
 __global__ void __launch_bounds__(64, 1)
 k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, uint64_t* xyzt_out) {
-  __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
-  Pow64 pt;
-  pt.col = lds_pow_ + threadIdx.x;
   if (blockIdx.x != 0) return;
   // cached forms of the window sums as row records, one lane each (W <= 63), then the chain in the lane-spread form
   // (row_ops.hpp): the running sum lies across the four rows of this wave, ~250 doublings at ~0.5 us instead of ~1 us on
@@ -916,7 +914,7 @@ k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, 
   ge r = rq_load_point(crec);
   if (negated) r = ge_neg(r);
   (void)T;
-  msm_emit_doubled(pt, r, threadIdx.x == 0, enc_out, xyzt_out);
+  msm_emit_doubled(r, threadIdx.x == 0, enc_out, xyzt_out);
 }
 
 // ---- small batches: no buckets -------------------------------------------------------------------------------------
@@ -1065,7 +1063,6 @@ k_msm_tiny(SqrtTables T, const void* pts_in, const uint8_t* scalar32, size_t n, 
 // the sum of the m partial results (one quad per MSS_QUADS of them, then a tree over the quads) and its encoding
 __global__ void __launch_bounds__(MSS_THREADS)
 k_msm_small_sum(SqrtTables T, const uint32_t* partial, int m, uint8_t* enc_out, uint64_t* xyzt_out) {
-  __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
   __shared__ uint32_t xrec[MSS_QUADS * GQ_WORDS];
   const int role = threadIdx.x & 3, quad = threadIdx.x >> 2;
   const fe id = gq_from_ge(ge_identity(), role);
@@ -1090,10 +1087,8 @@ k_msm_small_sum(SqrtTables T, const uint32_t* partial, int m, uint8_t* enc_out, 
     __syncthreads();
   }
   if (threadIdx.x >= 64) return;                                 // wave 0 encodes (no barrier from here on)
-  Pow64 pt;
-  pt.col = lds_pow_ + threadIdx.x;
   (void)T;
-  msm_emit_doubled(pt, gq_to_ge(v), threadIdx.x == 0, enc_out, xyzt_out);   // lanes 0-3 hold the total
+  msm_emit_doubled(gq_to_ge(v), threadIdx.x == 0, enc_out, xyzt_out);       // lanes 0-3 hold the total
 }
 
 // sum of m Element records (partial results of several GPUs / ranks), one lane

@@ -307,6 +307,100 @@ __device__ __forceinline__ RowPowers row_sqrt_powers(uint32_t den, uint32_t* tab
   return RowPowers{row_mul(w, den, K), w};
 }
 
+// ---- one inversion by the whole wave ------------------------------------------------------------------------------
+// The encoders at the end of the one-wave chains (k_msm_final, k_msm_small_sum, the one-wave-per-element kernels) invert ONE
+// value while 63 lanes have nothing else to do, and that value is the same in every lane -- so nothing diverges whatever the
+// code branches on.  fe_invert (inv30.hpp) is written for 64 different values per wave: 20 rounds of ~880 instructions, 570 of
+// them the 30 branch-free divsteps on the low words and ~310 the round's 2 x 2 matrix applied to the nine limbs of f, g, d, e.
+// Here
+//   * the four numbers lie across the four rows of the wave (row 0 f, 1 g, 2 d, 3 e; limb j in lane j, lanes 9..15 zero): the
+//     matrix is three multiply-adds per lane and two lazy carry passes by DPP, ~30 instructions.  Limbs stay signed and only
+//     nearly normalised between rounds -- lanes 0..7 in (-4, 2^30 + 5), lane 8 the signed top -- which the next round's
+//     products (|u| + |v| <= 2^30: below 2^61.6) and the low-word extractions (x & (2^30 - 1)) take as they are; the result
+//     is normalised once, by normalize_30;
+//   * the divsteps are the variable-time form (scalar code: the low words are wave-uniform): runs of zero bits of g in one
+//     step, and up to eight bits of g cancelled at a time by the multiple w = -g / f mod 2^k of f that the next k divsteps
+//     would add one by one -- the same sequence of divsteps as the plain delta = 1 iteration (Bernstein-Yang 2019; the batched
+//     form is the one libsecp256k1's modinv32 "var" uses), ~6 trips per 30 divsteps instead of 30.  At most 724 divsteps
+//     bring g to zero for inputs below 2^256: 25 rounds; the rounds after g = 0 pass in ~60 instructions each (f, g, d keep
+//     their values).
+// 31 us -> 11 us on a lone wave (tools/row_invert_test.py).  An inverse is a field value: same result as fe_invert.
+// Every lane of the wave must call this; the value inverted is LANE 0's x, the result comes back in every lane.
+__device__ __forceinline__ int32_t divsteps_30_var(int32_t eta, uint32_t f0, uint32_t g0, trans30* t) {
+  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+  int i = 30;
+  for (;;) {
+    const int zeros = __builtin_ctz(g | (0xFFFFFFFFu << i));       // g even: halve it (at most the i steps that are left)
+    g >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+    if (i == 0) break;
+    if (eta < 0) {                                                   // delta > 0 and g odd: swap
+      eta = -eta;
+      const uint32_t tf = f, tu = u, tv = v;
+      f = g; g = 0u - tf; u = q; q = 0u - tu; v = r; r = 0u - tv;
+    }
+    const int limit = eta + 1 > i ? i : eta + 1;                     // the next `limit` steps do not swap
+    const uint32_t mask = (0xFFFFFFFFu >> (32 - limit)) & 255u;
+    uint32_t fi = f;                                                 // 1 / f mod 2^12 (f odd: f * f = 1 mod 8)
+    fi *= 2u - f * fi;
+    fi *= 2u - f * fi;
+    const uint32_t w = (0u - g * fi) & mask;                         // g + w f = 0 mod 2^limit
+    g += f * w; q += u * w; r += v * w;
+  }
+  t->u = (int32_t)u; t->v = (int32_t)v; t->q = (int32_t)q; t->r = (int32_t)r;
+  return eta;
+}
+__device__ __forceinline__ int32_t pick9(const int32_t (&v)[9], int j) {
+  int32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r = j == k ? v[k] : r;
+  return r;
+}
+__device__ __forceinline__ fe fe_invert_wave(const fe& x_own) {
+  const fe c_own = fe_reduce_once(fe_mul_strict(x_own, fe_const(FE_ONE)));     // the residue x R in [0, q), as fe_invert takes it
+  uint32_t cl[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) cl[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_own.l[i]);
+  const s30 g_in = s30_from_limbs29(cl);
+  const int lane = threadIdx.x & 63, r = lane >> 4, j = lane & 15;
+  const bool odd = (r & 1) != 0, de = r >= 2, top = j == 8;
+  const int32_t qj = pick9(FQ_MODULUS_S30, j);
+  int32_t v = r == 0 ? qj : (r == 1 ? pick9(g_in.v, j) : ((r == 3 && j == 0) ? 1 : 0));
+  int32_t eta = -1;                                                  // -delta
+#pragma unroll 1
+  for (int it = 0; it < 25; ++it) {
+    const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane(v, 0) & (uint32_t)M30, g0 = (uint32_t)__builtin_amdgcn_readlane(v, 16) & (uint32_t)M30;
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane(v, 32), e0 = (uint32_t)__builtin_amdgcn_readlane(v, 48);
+    const int32_t sd = __builtin_amdgcn_readlane(v, 40) >> 31, se = __builtin_amdgcn_readlane(v, 56) >> 31;
+    trans30 m;
+    eta = divsteps_30_var(eta, f0, g0, &m);
+    // the multiples of q that keep d and e in (-2q, q) and make the new low limbs vanish (update_de_30; q^-1 mod 2^30 = 1).
+    // (The sign of a lazily carried number is read off its top limb: wrong only for values in (-2^240, 0), which need no lift.)
+    int32_t md = (m.u & sd) + (m.v & se), me = (m.q & sd) + (m.r & se);
+    md -= (int32_t)(((uint32_t)m.u * d0 + (uint32_t)m.v * e0 + (uint32_t)md) & (uint32_t)M30);
+    me -= (int32_t)(((uint32_t)m.q * d0 + (uint32_t)m.r * e0 + (uint32_t)me) & (uint32_t)M30);
+    const RowPair p = swap16((uint32_t)v, (uint32_t)v);                          // (f, f, d, d), (g, g, e, e)
+    const int32_t a = odd ? m.q : m.u, b = odd ? m.r : m.v, mm = de ? (odd ? me : md) : 0;
+    const int64_t c = mac_i64_i32(a, (int32_t)p.lo, mac_i64_i32(b, (int32_t)p.hi, mac_i64_i32(mm, qj, 0)));
+    // c = lo + 2^30 mid + 2^60 tp; the division by 2^30 moves lo one lane down (lane 0's is zero by construction)
+    const uint32_t lo = (uint32_t)c & (uint32_t)M30;
+    const int64_t h = c >> 30;
+    const uint32_t mid = top ? (uint32_t)h : ((uint32_t)h & (uint32_t)M30);     // the top limb keeps its sign
+    const int32_t tp = top ? 0 : (int32_t)(h >> 30);
+    const uint32_t t1 = shl<1>(lo) + mid;                                       // lanes 0..7: below 2^31
+    const uint32_t keep = top ? t1 : (t1 & (uint32_t)M30);
+    const uint32_t up = top ? 0u : ((t1 >> 30) + (uint32_t)tp);
+    v = (int32_t)(keep + shr<1>(up));
+  }
+  const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane(v, 0);                // f = +-1 (+-q for x = 0, where d = 0): bit 1 tells which
+  s30 d;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) d.v[i] = __builtin_amdgcn_readlane(v, 32 + i);
+  normalize_30(&d, (f0 & 2u) ? -1 : 1);
+  fe y;
+  s30_to_limbs29(d, y.l);
+  return fe_mul(y, fe_const(FE_R3));
+}
+
 // ---- between the two forms (whole field elements in a lane, Montgomery 9 x 29 <-> plain 10 x 28 across a row) --------
 // one lane writes an element as a row record (16 words, canonical value, limbs 10..15 zero) / reads a tight record back as
 // a product: curve.hpp fe_to_limbs28 / fe_from_limbs28 (whole-element code, so the host build checks its bounds)

@@ -37,13 +37,14 @@ def test_row_constants_are_current():
 @pytest.mark.gpu
 def test_row_ops_on_the_gpu():
     """row_mul bit-identical to the model on 4 096 operand pairs (tight, lazy, worst case); rq_double_neg / rq_add against
-    the group formulas on integers for 200 random inputs (and chained doublings); outputs tight, lanes 10..15 zero."""
+    the group formulas on integers for 200 random inputs (and chained doublings); outputs tight, lanes 10..15 zero; the
+    wave's inversion (fe_invert_wave) equal to the lane's on 2 048 random, small and edge values, x * (1/x) = 1, 0 -> 0."""
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
     so = os.path.join(ROOT, "build", "row_proto.so")
     deps = [os.path.join(ROOT, "tools", "row_proto.hip")] + [os.path.join(ROOT, "decaf377_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "decaf377_amd", "csrc"))]
     if not os.path.exists(so) or any(os.path.getmtime(d_) > os.path.getmtime(so) for d_ in deps):
         subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                                deps[0], "-o", so], timeout=900)
-    for tool, ok in (("row_proto.py", "0 differ from the model"), ("row_point_test.py", "ROW_POINT_OK")):
+    for tool, ok in (("row_proto.py", "0 differ from the model"), ("row_point_test.py", "ROW_POINT_OK"), ("row_invert_test.py", "ROW_INVERT_OK")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert r.returncode == 0 and ok in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

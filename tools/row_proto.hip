@@ -153,3 +153,56 @@ extern "C" int row_proto_dbl_chain(int which, int iters, const uint32_t* a, uint
   (void)hipFree(da); (void)hipFree(dout);
   return 0;
 }
+
+// the wave's inversion (fe_invert_wave) beside the lane's (fe_invert): one wave per element, 64 words out per element --
+// canonical limbs of 1/x by the wave, by the lane, of x * (1/x), and of one
+__global__ void __launch_bounds__(64) k_row_invert(const uint32_t* a, uint32_t* out, int n) {
+  const int e = blockIdx.x;
+  if (e >= n) return;
+  fe x;
+  for (int i = 0; i < NL; ++i) x.l[i] = a[e * NL + i] & MASK29;
+  x.l[NL - 1] &= 0xFFFFF;
+  const fe iw = row::fe_invert_wave(x), il = fe_invert(x);
+  const fe cw = fe_canon(iw), cl = fe_canon(il), pr = fe_canon(fe_mul(x, iw)), one = fe_canon(fe_const(FE_ONE));
+  if (threadIdx.x == 0)
+    for (int i = 0; i < NL; ++i) {
+      out[e * 64 + i] = cw.l[i]; out[e * 64 + 9 + i] = cl.l[i]; out[e * 64 + 18 + i] = pr.l[i]; out[e * 64 + 27 + i] = one.l[i];
+    }
+}
+__global__ void __launch_bounds__(64) k_invert_chain(const uint32_t* a, uint32_t* out, int iters, int which) {
+  fe x;
+  for (int i = 0; i < NL; ++i) x.l[i] = a[i] & MASK29;
+  x.l[NL - 1] &= 0xFFFFF;
+#pragma unroll 1
+  for (int i = 0; i < iters; ++i) x = fe_add(which == 0 ? row::fe_invert_wave(x) : fe_invert(x), fe_const(FE_ONE));
+  for (int i = 0; i < NL; ++i) out[threadIdx.x * NL + i] = x.l[i];
+}
+extern "C" int row_proto_invert(const uint32_t* a, uint32_t* out, int n) {
+  uint32_t *da, *dout;
+  CK(hipMalloc(&da, (size_t)n * NL * 4)); CK(hipMalloc(&dout, (size_t)n * 64 * 4));
+  CK(hipMemcpy(da, a, (size_t)n * NL * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(dout, 0, (size_t)n * 64 * 4));
+  hipLaunchKernelGGL(k_row_invert, dim3(n), dim3(64), 0, 0, da, dout, n);
+  CK(hipGetLastError());
+  CK(hipMemcpy(out, dout, (size_t)n * 64 * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(dout);
+  return 0;
+}
+// which: 0 = the wave's inversion, 1 = the lane's; -> ms for `iters` dependent inversions
+extern "C" int row_proto_invert_chain(int which, int iters, const uint32_t* a, uint32_t* out, float* ms) {
+  uint32_t *da, *dout;
+  CK(hipMalloc(&da, 64 * 4)); CK(hipMalloc(&dout, 64 * NL * 4));
+  CK(hipMemcpy(da, a, NL * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_invert_chain, dim3(1), dim3(64), 0, 0, da, dout, iters, which);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+  }
+  CK(hipEventElapsedTime(ms, e0, e1));
+  CK(hipMemcpy(out, dout, 64 * NL * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(dout);
+  return 0;
+}
