@@ -167,6 +167,16 @@ D377_HD bool fe_strict_is_zero(const fe& a) {
 // row_ops.hpp runs the 300 products of the power chains in the lane-spread form).
 D377_HD bool fe_sqrt_tail(const SqrtTables& T, const fe& v, const fe& uv, bool den_zero, bool num_zero, fe* res, bool min_curve_root);
 
+// A "power table" that holds the two powers themselves: the four-elements-per-wave kernels (d377.hip) raise z to them on
+// the rows of the wave and pass the results where the other callers pass the table of the exponentiation.
+struct GivenPowers {
+  fe v, uv;                             // z^((m-1)/2), z^((m+1)/2), z = num / den
+  D377_HD void put(int, const fe&) {}
+  D377_HD fe get(int) const { return fe_zero(); }
+};
+template <class PT> struct pt_has_powers { static constexpr bool value = false; };
+template <> struct pt_has_powers<GivenPowers> { static constexpr bool value = true; };
+
 template <bool NUM_IS_ONE, class PT>
 D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, const fe& den, fe* res,
                                 bool min_curve_root = false, const fe* inv_den = nullptr, bool use_inv = true) {
@@ -177,7 +187,10 @@ D377_HD bool fe_sqrt_ratio_zeta(const SqrtTables& T, PT& pt, const fe& num, cons
   fe v, uv;
   // use_inv: a launch-uniform switch for callers that always hold a (possibly meaningless) inverse: a pointer that is
   // null on one path and the address of a local on the other would force that local into scratch memory
-  if (inv_den != nullptr && use_inv) {
+  if constexpr (pt_has_powers<PT>::value) {
+    v = pt.v;
+    uv = pt.uv;
+  } else if (inv_den != nullptr && use_inv) {
     const fe z = NUM_IS_ONE ? *inv_den : fe_mul(num, *inv_den);
     v = fe_pow_m12(z, pt);
     uv = fe_mul(v, z);
@@ -1306,6 +1319,13 @@ template <class PT, class IO>
 D377_HD void dcb_finish(PT& pt, IO& io, int cnt) {
   (void)pt;
   dcb_finish_with(io, cnt, [](const fe& c) { return fe_invert(c); });
+}
+// one element's encoding from its state and 1 / p (what the loop above does per element, on values instead of records)
+D377_HD void dcb_encode_one(const dcb_state& st, const fe& inv_p, uint32_t w[8]) {
+  const bool neg = fe_is_negative(fe_mul(st.w, inv_p));                   // sign of E / F (encoding.rs:104)
+  fe s = fe_canon(fe_mul(fe_select(neg, st.n1, st.n0), inv_p));
+  s = fe_select((s.l[0] & 1u) != 0, fe_canon_negate(s), s);               // .abs(), encoding.rs:110
+  fe_to_words(s, w);
 }
 
 }  // namespace d377

@@ -524,6 +524,220 @@ k_scalar_mul_var_tiny(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar3
   }
 }
 
+// The fixed-base multiplication of the same regime: FB_WINDOWS mixed additions of comb entries, which every lane of a
+// lane-per-element wave does alone (~2.7 us each, then a 31 us inversion: 91 us per call whatever the batch).  One wave per
+// scalar instead: the comb entries of its digits, fetched and turned into row records by 3 x FB_WINDOWS lanes side by side,
+// then the additions in the lane-spread form (0.55 us each) and the wave's inversion (18 us).
+template <bool ELEMENT>
+__global__ void __launch_bounds__(64)
+k_scalar_mul_base_tiny(const uint32_t* fbase, const uint8_t* scalar32, size_t n, uint8_t* out) {
+  __shared__ uint32_t crec[FB_WINDOWS * row::RQ_WORDS];
+  __shared__ uint32_t xrec[row::RQ_WORDS];
+  __shared__ int sdig[FB_WINDOWS];
+  const int t = threadIdx.x;
+  const row::RowK K = row::row_consts();
+  const row::RowSel S = row::row_sel();
+  const size_t e = blockIdx.x;                                   // grid = n
+  uint32_t k[8];
+  load32(scalar32, e, k);
+  fr_reduce_words(k);
+  if (!ELEMENT) fr_half_words(k);                                // [k]B = [2]([k/2 mod r]B): the encoding of a double needs no square root
+  if (t == 0) {
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int i = 0; i < FB_WINDOWS; ++i) sdig[i] = fb_digit(k, i, carry);
+  }
+  __syncthreads();
+  // lane l: coordinate l % 4 of window l / 4's entry (Y + X, Y - X, 2dXY as stored; the fourth is Z = 1) -> the slot a row
+  // multiplies by (row_ops.hpp rq_add: 0 Y - X, 1 Y + X, 2 2dT, 3 Z)
+#pragma unroll 1
+  for (int l = t; l < 4 * FB_WINDOWS; l += 64) {
+    const int i = l >> 2, c = l & 3, d = sdig[i];
+    uint32_t* rec = crec + i * row::RQ_WORDS + 16 * (c == 0 ? 1 : (c == 1 ? 0 : c));
+    if (c == 3) {
+      for (int j = 0; j < 16; ++j) rec[j] = j == 0 ? 1u : 0u;
+    } else {
+      const uint32_t* src = fbase + ((size_t)i * FB_ENTRIES + (size_t)(d < 0 ? -d : d)) * FBW_ENTRY_WORDS + NL * c;
+      fe x;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) x.l[j] = src[j];
+      row::row_store_from_fe(rec, x);
+    }
+  }
+  __syncthreads();
+  uint32_t v = row::rq_identity(S);
+#pragma unroll 1
+  for (int i = 0; i < FB_WINDOWS; ++i) v = row::rq_add(v, crec + i * row::RQ_WORDS, S, sdig[i] < 0, K);
+  xrec[t] = v;
+  __syncthreads();
+  const ge r = row::rq_load_point(xrec);
+  if (ELEMENT) {
+    if (t == 0) store_ge_mont256(reinterpret_cast<uint64_t*>(out), e, r);
+  } else {
+    OneDcbIO io;
+    dcb_put(io, 0, ge_dcb_from_half(r, false));
+    dcb_finish_with(io, 1, [](const fe& c) { return row::fe_invert_wave(c); });   // (every lane holds the same element)
+    if (t == 0) store32(out, e, io.out);
+  }
+}
+
+// ---- the smallest batches of the square-root family: FOUR elements per wave --------------------------------------------
+// A square root is ~300 dependent products (the two fixed exponentiations) and a table phase; with one element per lane a
+// call of any size up to the chip's lanes takes as long as that one chain, ~135 us.  Up to four elements per SIMD
+// (4 x 4 x the CUs: 4 096 on an MI355X) the power chains run in the lane-spread form instead, one element on each ROW of the
+// wave (row_ops.hpp: ~0.2 us per product instead of ~0.33), and everything else -- the table phase, the curve arithmetic
+// around the root -- stays whole-element code that lane t runs for element t & 3 (curve.hpp: GivenPowers hands the powers to
+// the same functions the other kernels call).  The kernels that end in an encoding invert once per wave, for all four
+// elements (row_ops.hpp fe_invert_wave).
+constexpr int TINY4 = 4;
+struct Tiny4Lds {
+  uint32_t tab[POW_TAB * 64];           // the odd powers of the sliding-window exponentiation, one word per lane and entry
+  uint32_t xrec[2 * row::RQ_WORDS];     // row records in and out
+};
+struct Tiny4Lane {
+  size_t e;                             // the element this lane works for (clamped to the batch)
+  bool own;                             // lanes 0..3 of a wave write, if their element exists
+};
+__device__ __forceinline__ Tiny4Lane tiny4_lane(size_t n) {
+  const size_t e = (size_t)blockIdx.x * TINY4 + (threadIdx.x & 3);
+  return Tiny4Lane{e < n ? e : n - 1, threadIdx.x < TINY4 && e < n};
+}
+// lane t passes the argument(s) of element t & 3's square root (lanes 0..3 are read) and gets that element's powers back
+template <bool WITH_NUM>
+__device__ __forceinline__ GivenPowers tiny4_powers(Tiny4Lds& L, const fe& num, const fe& den, const row::RowK& K) {
+  const int t = threadIdx.x;
+  if (t < TINY4) {
+    row::row_store_from_fe(L.xrec + 16 * t, den);
+    if (WITH_NUM) row::row_store_from_fe(L.xrec + row::RQ_WORDS + 16 * t, num);
+  }
+  __syncthreads();
+  const row::RowPowers pw = WITH_NUM ? row::row_sqrt_powers_num(L.xrec[row::RQ_WORDS + t], L.xrec[t], L.tab, t, K)
+                                     : row::row_sqrt_powers(L.xrec[t], L.tab, t, K);
+  __syncthreads();
+  L.xrec[t] = pw.v; L.xrec[row::RQ_WORDS + t] = pw.uv;
+  __syncthreads();
+  GivenPowers g;
+  g.v = row::row_load_to_fe(L.xrec + 16 * (t & 3));
+  g.uv = row::row_load_to_fe(L.xrec + row::RQ_WORDS + 16 * (t & 3));
+  __syncthreads();
+  return g;
+}
+// The encodings of the wave's four elements from their compressor states (curve.hpp, "compression without a square root"):
+// the product of the four p's by two exchanges inside the quad, one inversion by the wave, each lane's own share back.
+__device__ __forceinline__ void tiny4_encode(const dcb_state& st, uint32_t w[8]) {
+  const fe b = fe_quad_perm<1, 0, 3, 2>(st.p);
+  const fe ab = fe_mul_strict(st.p, b);
+  const fe cd = fe_quad_perm<2, 3, 0, 1>(ab);
+  const fe inv = row::fe_invert_wave(fe_mul_strict(ab, cd));    // every quad holds the same four: lane 0's product is the wave's
+  dcb_encode_one(st, fe_mul(fe_mul(inv, cd), b), w);
+}
+
+__global__ void __launch_bounds__(64)
+k_sqrt_ratio_zeta_tiny(SqrtTables T, const uint8_t* num32, const uint8_t* den32, size_t n, uint8_t* root32, uint8_t* was_square,
+                       int min_curve_root) {
+  __shared__ Tiny4Lds L;
+  const row::RowK K = row::row_consts();
+  const Tiny4Lane me = tiny4_lane(n);
+  uint32_t wn[8], wd[8], wr[8];
+  load32(num32, me.e, wn);
+  load32(den32, me.e, wd);
+  const fe num = fe_from_words_mod_order_strict(wn), den = fe_from_words_mod_order_strict(wd);
+  GivenPowers pt = tiny4_powers<true>(L, num, den, K);
+  fe r;
+  const bool ws = fe_sqrt_ratio_zeta<false>(T, pt, num, den, &r, min_curve_root != 0);
+  fe_to_bytes_words(r, wr);
+  if (me.own) {
+    store32(root32, me.e, wr);
+    was_square[me.e] = ws ? 1 : 0;
+  }
+}
+
+// ROUNDTRIP: decompress -> compress (k_roundtrip), two square roots one after the other
+template <bool ROUNDTRIP>
+__global__ void __launch_bounds__(64)
+k_decompress_tiny(SqrtTables T, const uint8_t* enc32, size_t n, uint8_t* out, uint8_t* status) {
+  __shared__ Tiny4Lds L;
+  const row::RowK K = row::row_consts();
+  const Tiny4Lane me = tiny4_lane(n);
+  uint32_t w[8];
+  load32(enc32, me.e, w);
+  GivenPowers pt = tiny4_powers<false>(L, fe_zero(), ge_decompress_den(w), K);
+  ge g;
+  const uint32_t bad = ge_decompress(T, pt, w, &g);
+  if (ROUNDTRIP) {
+    pt = tiny4_powers<false>(L, fe_zero(), ge_compress_den(g), K);
+    ge_compress(T, pt, g, w, bad == 0 && me.own);           // (the check build counts an element once, not once per lane)
+    if (me.own) {
+      status[me.e] = (uint8_t)bad;
+      if (bad) store32_zero(out, me.e); else store32(out, me.e, w);
+    }
+  } else if (me.own) {
+    status[me.e] = (uint8_t)bad;
+    if (bad) {
+      store32_zero(out, 4 * me.e); store32_zero(out, 4 * me.e + 1); store32_zero(out, 4 * me.e + 2); store32_zero(out, 4 * me.e + 3);
+    } else {
+      store_ge_mont256(reinterpret_cast<uint64_t*>(out), me.e, g);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) k_compress_tiny(SqrtTables T, const uint64_t* xyzt, size_t n, uint8_t* enc32) {
+  __shared__ Tiny4Lds L;
+  const row::RowK K = row::row_consts();
+  const Tiny4Lane me = tiny4_lane(n);
+  const ge p = load_ge_mont256(xyzt, me.e);
+  GivenPowers pt = tiny4_powers<false>(L, fe_zero(), ge_compress_den(p), K);
+  uint32_t w[8];
+  ge_compress(T, pt, p, w, me.own);                           // (the check build counts an element once, not once per lane)
+  if (me.own) store32(enc32, me.e, w);
+}
+
+// r2 null: encode_to_curve; otherwise hash_to_curve (two maps one after the other, the sum on the Jacobi quartic; the
+// exceptional pair goes the reference's way as in k_hash_to_curve, with whole-element square roots)
+__global__ void __launch_bounds__(64) k_map_to_curve_tiny(SqrtTables T, const uint8_t* r1, const uint8_t* r2, size_t n, uint8_t* out32) {
+  __shared__ Tiny4Lds L;
+  const row::RowK K = row::row_consts();
+  const Tiny4Lane me = tiny4_lane(n);
+  uint32_t w[8];
+  load32(r1, me.e, w);
+  fe r0 = fe_from_words_mod_order(w), s1, t1;
+  GivenPowers pt = tiny4_powers<false>(L, fe_zero(), ge_elligator_den(r0), K);
+  ge_elligator_st(T, pt, r0, &s1, &t1);
+  D377_INVARIANT(T, ge_from_jacobi_st(s1, t1), true);
+  dcb_state st;
+  if (r2 == nullptr) {
+    st = ge_dcb_from_jacobi_st(s1, t1);
+  } else {
+    fe s2, t2;
+    load32(r2, me.e, w);
+    r0 = fe_from_words_mod_order(w);
+    pt = tiny4_powers<false>(L, fe_zero(), ge_elligator_den(r0), K);
+    ge_elligator_st(T, pt, r0, &s2, &t2);
+    D377_INVARIANT(T, ge_from_jacobi_st(s2, t2), true);
+    bool exceptional;
+    st = ge_dcb_from_jacobi_sum(s1, t1, s2, t2, &exceptional);
+#if defined(D377_CHECK_INVARIANTS)
+    exceptional |= (me.e & 3) == 3;                 // as in k_hash_to_curve: the debug build exercises the exceptional route
+#endif
+    if (__any(exceptional)) {
+      __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
+      struct Pow64 {
+        uint32_t* col;
+        __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
+        __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
+      } lp;
+      lp.col = lds_pow_ + threadIdx.x;
+      uint32_t we[8];
+      hash_exceptional_pair(T, lp, r1, r2, me.e, we);
+      const dcb_state se = dcb_from_encoding_words(we);
+      st.p = fe_select(exceptional, se.p, st.p); st.w = fe_select(exceptional, se.w, st.w);
+      st.n0 = fe_select(exceptional, se.n0, st.n0); st.n1 = fe_select(exceptional, se.n1, st.n1);
+    }
+  }
+  tiny4_encode(st, w);
+  if (me.own) store32(out32, me.e, w);
+}
+
 // The reference's own signatures for these operations take and return Elements (`Element * Fr`,
 // src/min_curve/ops.rs:89-95; `Element::encode_to_curve`, `hash_to_curve`, src/min_curve/element.rs:235-244;
 // `vartime_compress_to_field`, :163-181): the same per-lane code as above without the encoding step at either
@@ -899,6 +1113,10 @@ size_t tiny_batch_max(const DeviceState& d) {
   return v < cap ? v : cap;
 }
 
+// ... and the square-root family's batches of up to FOUR elements per wave (k_*_tiny above)
+size_t tiny4_batch_max(const DeviceState& d) { return tiny_batch_max(d) * TINY4; }
+unsigned tiny4_grid(size_t n) { return (unsigned)((n + TINY4 - 1) / TINY4); }
+
 int grid_for(const DeviceState& d, size_t n) {
   // >> 256 workgroups when the batch allows it; capped so huge batches grid-stride
   size_t blocks = (n + BLOCK - 1) / BLOCK;
@@ -1089,6 +1307,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     // (round records of the batched inversions, window tables): never more lanes than those areas have (gv), and each
     // launch queues behind the areas' last user.
     case OP_SQRT:
+      if (n <= tiny4_batch_max(d)) {                          // four elements per wave: power chains on the rows, no scratch
+        hipLaunchKernelGGL(k_sqrt_ratio_zeta_tiny, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
+                           (uint8_t*)out0, (uint8_t*)out1, aux);
+        break;
+      }
       if ((rc = vb.acquire())) return rc;
       hipLaunchKernelGGL(k_sqrt_ratio_zeta, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_SQRT], s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
                          (uint8_t*)out0, (uint8_t*)out1, aux, dcb);
@@ -1097,6 +1320,10 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       // several generations of chunks: the batched-inverse form (one box, alternating: 2^20 1.93-1.97 against 1.99 ms,
       // 2^21 3.76-3.90 against 4.14-4.18, 2^22 7.71-7.78 against 8.19, 2^23 15.2-15.6 against 16.5); below, the wide grid
       // (the threshold is DECOMPRESS_CHUNKED_GENERATIONS full chunks per resident lane set: 2^21 elements on 256 CUs)
+      if (n <= tiny4_batch_max(d)) {
+        hipLaunchKernelGGL(k_decompress_tiny<false>, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
+        break;
+      }
       const size_t chunked_min = (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN,
                                                  (long long)(d.resident_lanes() * DCB_K * DECOMPRESS_CHUNKED_GENERATIONS));
       if (n >= chunked_min) {
@@ -1109,9 +1336,17 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     }
     case OP_COMPRESS:
+      if (n <= tiny4_batch_max(d)) {
+        hipLaunchKernelGGL(k_compress_tiny, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint64_t*)in0, n, (uint8_t*)out0);
+        break;
+      }
       hipLaunchKernelGGL(k_compress, dim3(g), dim3(BLOCK), 0, s, T, (const uint64_t*)in0, n, (uint8_t*)out0);
       break;
     case OP_ROUNDTRIP:
+      if (n <= tiny4_batch_max(d)) {
+        hipLaunchKernelGGL(k_decompress_tiny<true>, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
+        break;
+      }
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
       break;
     case OP_MUL_BASE: {
@@ -1121,6 +1356,10 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       // Measured, one box, alternating (profiles/README.md), narrow / wide: 2^20 1.13 / 1.06, 2^21 1.14 / 1.17,
       // 3 x 2^20 1.09-1.13 / 1.17-1.20, 2^22 1.08-1.13 / 1.19, 2^23 1.14 / 1.21 x 10^9 per s.
       // (FB_WIDE_GENERATIONS x DCB_K elements per resident lane: 2^21 on 256 CUs)
+      if (n <= tiny_batch_max(d)) {                           // one scalar per wave, lane-spread arithmetic
+        hipLaunchKernelGGL(k_scalar_mul_base_tiny<false>, dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
+        break;
+      }
       bool wide = n >= d.resident_lanes() * DCB_K * FB_WIDE_GENERATIONS;
       if (d.is_tuned(D377_TUNE_FB_WIDE)) wide = d.tuned(D377_TUNE_FB_WIDE, 0) != 0;               // developer overrides (A/B)
       const int fk = (int)d.tuned(D377_TUNE_FB_K, wide ? FB_K : DCB_K);
@@ -1148,10 +1387,18 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
                          (uint8_t*)out0, (uint8_t*)out1, d.vb_scratch, dcb);
       break;
     case OP_ENCODE:
+      if (n <= tiny4_batch_max(d)) {
+        hipLaunchKernelGGL(k_map_to_curve_tiny, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, (const uint8_t*)nullptr, n, (uint8_t*)out0);
+        break;
+      }
       if ((rc = vb.acquire())) return rc;
       hipLaunchKernelGGL(k_encode_to_curve, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_ENCODE], s, T, (const uint8_t*)in0, n, (uint8_t*)out0, dcb);
       break;
     case OP_HASH:
+      if (n <= tiny4_batch_max(d)) {
+        hipLaunchKernelGGL(k_map_to_curve_tiny, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0);
+        break;
+      }
       if ((rc = vb.acquire())) return rc;
       hipLaunchKernelGGL(k_hash_to_curve, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_HASH], s, T, (const uint8_t*)in0, (const uint8_t*)in1, n,
                          (uint8_t*)out0, dcb);
@@ -1233,6 +1480,10 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     }
     case OP_MUL_BASE_EL:
+      if (n <= tiny_batch_max(d)) {
+        hipLaunchKernelGGL(k_scalar_mul_base_tiny<true>, dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
+        break;
+      }
       hipLaunchKernelGGL(k_scalar_mul_base_el, dim3(g), dim3(BLOCK), 0, s, d.fbase, (const uint8_t*)in0, n, (uint64_t*)out0);
       break;
     case OP_COMPRESS_FIELD:

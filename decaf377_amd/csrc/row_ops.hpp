@@ -306,6 +306,13 @@ __device__ __forceinline__ RowPowers row_sqrt_powers(uint32_t den, uint32_t* tab
   const uint32_t w = row_mul(row_pow_m12(t_, tab, t, K), s, K);
   return RowPowers{row_mul(w, den, K), w};
 }
+// the same for a ratio num / den (invsqrt.rs:91-94): w = (num t)^((m-1)/2) s, v = w den, uv = w num
+__device__ __forceinline__ RowPowers row_sqrt_powers_num(uint32_t num, uint32_t den, uint32_t* tab, int t, const RowK& K) {
+  const uint32_t s = row_pow_2_47_m1(den, K);
+  const uint32_t t_ = row_mul(row_mul(s, s, K), den, K);
+  const uint32_t w = row_mul(row_pow_m12(row_mul(num, t_, K), tab, t, K), s, K);
+  return RowPowers{row_mul(w, den, K), row_mul(w, num, K)};
+}
 
 // ---- one inversion by the whole wave ------------------------------------------------------------------------------
 // The encoders at the end of the one-wave chains (k_msm_final, k_msm_small_sum, the one-wave-per-element kernels) invert ONE

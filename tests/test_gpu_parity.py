@@ -613,6 +613,80 @@ def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
             assert torch.equal(e_q, want), n
 
 
+def test_tiny_batch_fixed_base_wave_kernel(ctx, oracle, torch_mod):
+    """Up to one scalar per SIMD the fixed-base multiplication gives every scalar a wave (d377.hip k_scalar_mul_base_tiny: comb
+    entries as row records, lane-spread additions, the wave's inversion).  Same bytes as the lane-per-element kernel (tiny_max
+    = 0) and as the oracle at sizes around its threshold, zero and extreme scalars included; the Element form likewise (as
+    group elements)."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4402)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for n in (1, 2, 17, 1000, 4 * cus, 4 * cus + 1):
+        k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        for i, v in enumerate([0, 1, 2, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1, (1 << 18) - 1, 1 << 17, (1 << 17) + 1][:n]):
+            k[i] = ibytes(v)
+        tk = torch.from_numpy(k).to(dev)
+        with ctx.tuning(tiny_max=0):
+            out_l = ctx.scalar_mul_base(tk)
+            el_l = ctx.compress(ctx.scalar_mul_base_element(tk))
+        with ctx.tuning(tiny_max=10**6):
+            out_w = ctx.scalar_mul_base(tk)
+            el_w = ctx.compress(ctx.scalar_mul_base_element(tk))
+        out_d = ctx.scalar_mul_base(tk)                       # whatever the size picks
+        assert torch.equal(out_w, out_l) and torch.equal(out_d, out_l) and torch.equal(el_w, el_l) and torch.equal(el_l, out_l), n
+        sel = np.unique(np.concatenate([np.arange(min(n, 24)), np.arange(max(0, n - 24), n)]))
+        assert (out_w.cpu().numpy()[sel] == oracle.scalar_mul_base(k[sel])).all(), n
+
+
+def test_tiny_batch_sqrt_family_four_per_wave(ctx, oracle, torch_mod):
+    """Up to four elements per SIMD the square-root family -- sqrt_ratio_zeta (either root), decompress, compress, the round
+    trip, encode_to_curve, hash_to_curve -- runs four elements per wave: the power chains of the square roots on the rows of
+    the wave, one inversion per wave for the encodings (d377.hip k_*_tiny).  Same bytes as the lane-per-element kernels
+    (tiny_max = 0) at sizes around every edge (ragged last wave, one past the threshold), invalid encodings and zero
+    numerators / denominators included, and as the oracle."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4403)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for n in (1, 2, 3, 4, 5, 7, 17, 1000, 16 * cus - 1, 16 * cus, 16 * cus + 1):
+        r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        r1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        r0[0] = 0                                            # zero numerator / Elligator of 0
+        if n > 2:
+            r1[2] = 0                                        # zero denominator
+        if n > 3:
+            r0[3] = 0; r1[3] = 0
+        enc = oracle.encode_to_curve(rng.integers(0, 256, (min(n, 1024), 32), dtype=np.uint8))
+        enc = np.tile(enc, ((n + enc.shape[0] - 1) // enc.shape[0], 1))[:n].copy()
+        enc[::5] = rng.integers(0, 256, (len(enc[::5]), 32), dtype=np.uint8)      # mostly invalid
+        if n > 1:
+            enc[1] = 0                                       # the identity
+        t0, t1, te = (torch.from_numpy(a).to(dev) for a in (r0, r1, enc))
+        res = {}
+        for mode, kv in (("lane", dict(tiny_max=0)), ("wave", dict(tiny_max=10**6)), ("default", {})):
+            with ctx.tuning(**kv):
+                P, st = ctx.decompress(te)
+                valid = st == 0
+                res[mode] = [ctx.sqrt_ratio_zeta(t0, t1), ctx.sqrt_ratio_zeta(t0, t1, root="min_curve"), (P, st), ctx.roundtrip(te),
+                             ctx.encode_to_curve(t0), ctx.hash_to_curve(t0, t1), ctx.compress(P[valid].contiguous()) if bool(valid.any()) else None]
+        flat = lambda r: [x for item in r if item is not None for x in (item if isinstance(item, (tuple, list)) else (item,))]
+        for mode in ("wave", "default"):
+            assert all(torch.equal(a, b) for a, b in zip(flat(res[mode]), flat(res["lane"]))), (n, mode)
+        sel = np.unique(np.concatenate([np.arange(min(n, 40)), np.arange(max(0, n - 40), n)]))
+        w = res["wave"]
+        o_root, o_sq = oracle.sqrt_ratio_zeta(r0[sel], r1[sel])
+        assert (w[0][0].cpu().numpy()[sel] == o_root).all() and (w[0][1].cpu().numpy()[sel] == o_sq).all(), n
+        o_root, o_sq = oracle.sqrt_ratio_zeta_min_curve(r0[sel], r1[sel])
+        assert (w[1][0].cpu().numpy()[sel] == o_root).all() and (w[1][1].cpu().numpy()[sel] == o_sq).all(), n
+        o_P, o_st = oracle.decompress(enc[sel])
+        assert (w[2][1].cpu().numpy()[sel] == o_st).all() and (w[2][0].cpu().numpy().view(np.uint64)[sel] == o_P).all(), n
+        o_rt, o_rst = oracle.roundtrip(enc[sel])
+        assert (w[3][0].cpu().numpy()[sel] == o_rt).all() and (w[3][1].cpu().numpy()[sel] == o_rst).all(), n
+        assert (w[4].cpu().numpy()[sel] == oracle.encode_to_curve(r0[sel])).all(), n
+        assert (w[5].cpu().numpy()[sel] == oracle.hash_to_curve(r0[sel], r1[sel])).all(), n
+
+
 def test_chunk_residency_is_checked(ctx):
     """The lane-set pool of the scratch areas assumes at most `sets` resident workgroups per CU of every kernel that
     claims a set.  d377_ctx_create verifies that with the occupancy query (and pads the launch's LDS where registers
@@ -1406,6 +1480,13 @@ assert (ctx.scalar_mul_base(k) == orc.scalar_mul_base(k)).all()
 xyzt, st = ctx.decompress(enc)
 assert (ctx.compress(ctx.double(ctx.add(xyzt, xyzt[::-1].copy()))) == orc.compress(orc.double_xyzt(orc.add_xyzt(xyzt, xyzt[::-1].copy())))).all()
 e, _, _ = ctx.msm(enc[:3000], k[:3000]); assert bytes(e) == bytes(orc.msm(xyzt[:3000], k[:3000])[0])
+m = 1000                                                    # the smallest batches' kernels (four elements / one scalar per wave)
+assert (ctx.hash_to_curve(r0[:m], r1[:m]) == orc.hash_to_curve(r0[:m], r1[:m])).all()   # exceptional route included
+assert (ctx.encode_to_curve(r0[:m]) == orc.encode_to_curve(r0[:m])).all()
+rt, st = ctx.roundtrip(raw[:m]); o_rt, o_st = orc.roundtrip(raw[:m])
+assert (rt == o_rt).all() and (st == o_st).all()
+assert (ctx.scalar_mul_base(k[:m]) == orc.scalar_mul_base(k[:m])).all()
+assert (ctx.compress(xyzt[:m]) == enc[:m]).all()
 assert ctx.invariant_failures() == (True, 0)
 bad = xyzt[:100].copy(); bad[:, 0] ^= np.uint64(2)          # x limb flipped: not on the curve any more
 ctx.compress(bad)
