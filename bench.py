@@ -521,6 +521,13 @@ def main():
             ("msm_encoded", lambda: ctx.msm(enc1[:nt], scalars[:nt])),
             ("scalar_mul_var", lambda: ctx.scalar_mul_var(enc1[:nt], scalars[:nt], outs=[o1[:nt], s1[:nt]])),
             ("scalar_mul_var_element", lambda: ctx.scalar_mul_var_element(pm[:nt], scalars[:nt])),
+            # one scalar per wave; the square-root family: four elements per wave (up to 16 x the CUs)
+            ("scalar_mul_base", lambda: ctx.scalar_mul_base(scalars[:nt], outs=[o1[:nt]])),
+            ("sqrt_ratio_zeta", lambda: ctx.sqrt_ratio_zeta(r0[:nt], scalars[:nt], outs=[o1[:nt], s1[:nt]])),
+            ("decompress", lambda: ctx.decompress(enc1[:nt])),
+            ("compress", lambda: ctx.compress(pm[:nt], outs=[o1[:nt]])),
+            ("encode_to_curve", lambda: ctx.encode_to_curve(r0[:nt], outs=[o1[:nt]])),
+            ("hash_to_curve", lambda: ctx.hash_to_curve(r0[:nt], scalars[:nt], outs=[o1[:nt]])),
         ]:
             ker, _ = time_op(torch, fn, 5, 2)
             tiny[name] = ker

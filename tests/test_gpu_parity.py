@@ -1571,7 +1571,8 @@ def test_bench_line_contract():
     small = d_["extra"]["small_batch_2^12_ms_per_call"]
     assert set(small) == {"msm", "msm_encoded", "scalar_mul_var", "scalar_mul_var_element", "scalar_mul_base"} and all(0 < v < 5 for v in small.values())
     tiny = d_["extra"]["tiny_batch_2^8_ms_per_call"]
-    assert set(tiny) == {"msm", "msm_encoded", "scalar_mul_var", "scalar_mul_var_element"} and all(0 < v < 5 for v in tiny.values())
+    assert set(tiny) == {"msm", "msm_encoded", "scalar_mul_var", "scalar_mul_var_element", "scalar_mul_base", "sqrt_ratio_zeta", "decompress",
+                         "compress", "encode_to_curve", "hash_to_curve"} and all(0 < v < 5 for v in tiny.values())
     assert set(d_["extra"]["msm_mid_ms_per_call"]) == {"2^16"}
 
 

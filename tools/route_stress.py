@@ -5,6 +5,9 @@ compared; a sample of each result also goes to the oracle.  Test infrastructure 
   variable base (Encodings / Elements):  one wave / one quad per element |  one lane per element      tiny_max, small_max
   MSM (Elements / Encodings):            one wave / one quad per point  |  Pippenger                  msm_tiny_max, msm_small_max
   fixed base:                            2 workgroups per CU, K = 8     |  3 per CU, K = 16           fb_wide / fb_k
+                                         one wave per scalar            |  one lane per scalar        tiny_max
+  sqrt_ratio_zeta, decompress, compress, round trip, encode_to_curve, hash_to_curve:
+                                         four elements per wave         |  one lane per element       tiny_max
 usage: python tools/route_stress.py [rounds=40] [seed=1]   -> summary lines, exit 1 on any mismatch"""
 import os
 import sys
@@ -113,6 +116,29 @@ def main():
         if not ok:
             print("MISMATCH fixed base n = %d" % n, flush=True)
     print("fixed base: %d sizes (small, and around 2^21), narrow == wide == default == oracle sample: %s" % (cnt, "ok" if bad == bad0 else "FAILED"), flush=True)
+    # the smallest batches: one scalar per wave (fixed base), four elements per wave (the square-root family), forced beyond
+    # their sizes, against the lane-per-element kernels
+    bad0, cnt = bad, 0
+    r1 = rnd(6000)
+    for n in sizes(1, 6000, [4, cus * 4, cus * 16]):
+        if n > 6000:
+            continue
+        res = []
+        for kv in (dict(tiny_max=0), dict(tiny_max=10**9)):
+            with ctx.tuning(**kv):
+                P, st = ctx.decompress(enc_all[:n])
+                res.append([ctx.scalar_mul_base(k[:n]), *ctx.sqrt_ratio_zeta(r0[:n], r1[:n]), *ctx.sqrt_ratio_zeta(r0[:n], r1[:n], root="min_curve"),
+                            P, st, *ctx.roundtrip(enc_all[:n]), ctx.compress(P_all[:n]), ctx.encode_to_curve(r0[:n]), ctx.hash_to_curve(r0[:n], r1[:n])])
+        ok = all(torch.equal(a, b) for a, b in zip(*res))
+        sel = np.unique(rng.integers(0, n, 4))
+        ok = ok and (res[1][-1][sel].cpu().numpy() == orc.hash_to_curve(r0[:n][sel].cpu().numpy(), r1[:n][sel].cpu().numpy())).all()
+        ok = ok and (res[1][0][sel].cpu().numpy() == orc.scalar_mul_base(k[:n][sel].cpu().numpy())).all()
+        bad += 0 if ok else 1
+        cnt += 1
+        if not ok:
+            print("MISMATCH smallest batches n = %d" % n, flush=True)
+    print("smallest batches: %d sizes in [1, 6000], fixed base / sqrt (both roots) / decompress / round trip / compress / encode_to_curve / hash_to_curve, "
+          "waves == lanes == oracle sample: %s" % (cnt, "ok" if bad == bad0 else "FAILED"), flush=True)
     print("ROUTE_STRESS_%s" % ("OK" if bad == 0 else "FAILED"))
     return 1 if bad else 0
 
