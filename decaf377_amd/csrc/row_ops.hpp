@@ -324,7 +324,7 @@ __device__ __forceinline__ RowPowers row_sqrt_powers_num(uint32_t num, uint32_t 
 //     matrix is three multiply-adds per lane and two lazy carry passes by DPP, ~30 instructions.  Limbs stay signed and only
 //     nearly normalised between rounds -- lanes 0..7 in (-4, 2^30 + 5), lane 8 the signed top -- which the next round's
 //     products (|u| + |v| <= 2^30: below 2^61.6) and the low-word extractions (x & (2^30 - 1)) take as they are; the result
-//     is normalised once, by normalize_30;
+//     is carried once, at the end;
 //   * the divsteps are the variable-time form (scalar code: the low words are wave-uniform): runs of zero bits of g in one
 //     step, and up to eight bits of g cancelled at a time by the multiple w = -g / f mod 2^k of f that the next k divsteps
 //     would add one by one -- the same sequence of divsteps as the plain delta = 1 iteration (Bernstein-Yang 2019; the batched
@@ -362,7 +362,8 @@ __device__ __forceinline__ int32_t pick9(const int32_t (&v)[9], int j) {
   for (int k = 0; k < 9; ++k) r = j == k ? v[k] : r;
   return r;
 }
-__device__ __forceinline__ fe fe_invert_wave(const fe& x_own) {
+template <bool DBG>
+__device__ __forceinline__ fe fe_invert_wave_impl(const fe& x_own, uint32_t* dbg) {
   const fe c_own = fe_reduce_once(fe_mul_strict(x_own, fe_const(FE_ONE)));     // the residue x R in [0, q), as fe_invert takes it
   uint32_t cl[NL];
 #pragma unroll
@@ -377,14 +378,15 @@ __device__ __forceinline__ fe fe_invert_wave(const fe& x_own) {
   for (int it = 0; it < 25; ++it) {
     const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane(v, 0) & (uint32_t)M30, g0 = (uint32_t)__builtin_amdgcn_readlane(v, 16) & (uint32_t)M30;
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane(v, 32), e0 = (uint32_t)__builtin_amdgcn_readlane(v, 48);
-    const int32_t sd = __builtin_amdgcn_readlane(v, 40) >> 31, se = __builtin_amdgcn_readlane(v, 56) >> 31;
     trans30 m;
     eta = divsteps_30_var(eta, f0, g0, &m);
-    // the multiples of q that keep d and e in (-2q, q) and make the new low limbs vanish (update_de_30; q^-1 mod 2^30 = 1).
-    // (The sign of a lazily carried number is read off its top limb: wrong only for values in (-2^240, 0), which need no lift.)
-    int32_t md = (m.u & sd) + (m.v & se), me = (m.q & sd) + (m.r & se);
-    md -= (int32_t)(((uint32_t)m.u * d0 + (uint32_t)m.v * e0 + (uint32_t)md) & (uint32_t)M30);
-    me -= (int32_t)(((uint32_t)m.q * d0 + (uint32_t)m.r * e0 + (uint32_t)me) & (uint32_t)M30);
+    // the multiples of q that make the new low limbs of d and e vanish (q^-1 mod 2^30 = 1): md, me in (-2^30, 0].  update_de_30
+    // first lifts a negative d or e by q, which keeps them in (-2q, q); the sign of a lazily carried number cannot be read off
+    // its top limb (top limb -1 over a large limb below is a small POSITIVE number: lifting that one walks d out of range,
+    // which a batch of structured residues found), and it is not needed -- without the lift |d|, |e| grow by at most q per
+    // round, (-(round + 2) q, q], 2^17 in the top limb after 25 rounds; the one reduction at the end allows for it.
+    const int32_t md = -(int32_t)(((uint32_t)m.u * d0 + (uint32_t)m.v * e0) & (uint32_t)M30);
+    const int32_t me = -(int32_t)(((uint32_t)m.q * d0 + (uint32_t)m.r * e0) & (uint32_t)M30);
     const RowPair p = swap16((uint32_t)v, (uint32_t)v);                          // (f, f, d, d), (g, g, e, e)
     const int32_t a = odd ? m.q : m.u, b = odd ? m.r : m.v, mm = de ? (odd ? me : md) : 0;
     const int64_t c = mac_i64_i32(a, (int32_t)p.lo, mac_i64_i32(b, (int32_t)p.hi, mac_i64_i32(mm, qj, 0)));
@@ -397,16 +399,31 @@ __device__ __forceinline__ fe fe_invert_wave(const fe& x_own) {
     const uint32_t keep = top ? t1 : (t1 & (uint32_t)M30);
     const uint32_t up = top ? 0u : ((t1 >> 30) + (uint32_t)tp);
     v = (int32_t)(keep + shr<1>(up));
+    if (DBG) {                                                              // (tools/row_proto.hip: the rounds against the Python model)
+      dbg[it * 80 + lane] = (uint32_t)v;
+      if (lane == 0) {
+        dbg[it * 80 + 64] = (uint32_t)eta; dbg[it * 80 + 65] = (uint32_t)m.u; dbg[it * 80 + 66] = (uint32_t)m.v; dbg[it * 80 + 67] = (uint32_t)m.q;
+        dbg[it * 80 + 68] = (uint32_t)m.r; dbg[it * 80 + 69] = (uint32_t)md; dbg[it * 80 + 70] = (uint32_t)me; dbg[it * 80 + 71] = f0; dbg[it * 80 + 72] = g0;
+      }
+    }
   }
   const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane(v, 0);                // f = +-1 (+-q for x = 0, where d = 0): bit 1 tells which
+  // +-d + 32 q, carried: a non-negative integer below 60 q < 2^259 that is +-d mod q; the product with R^3 / R reduces it
+  const bool negate = (f0 & 2u) != 0;
   s30 d;
+  int64_t carry = 0;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) d.v[i] = __builtin_amdgcn_readlane(v, 32 + i);
-  normalize_30(&d, (f0 & 2u) ? -1 : 1);
+  for (int i = 0; i < 9; ++i) {
+    const int32_t di = __builtin_amdgcn_readlane(v, 32 + i);
+    const int64_t t = (int64_t)(negate ? -di : di) + 32ll * FQ_MODULUS_S30[i] + carry;
+    d.v[i] = i < 8 ? (int32_t)(t & M30) : (int32_t)t;
+    carry = t >> 30;
+  }
   fe y;
   s30_to_limbs29(d, y.l);
   return fe_mul(y, fe_const(FE_R3));
 }
+__device__ __forceinline__ fe fe_invert_wave(const fe& x_own) { return fe_invert_wave_impl<false>(x_own, nullptr); }
 
 // ---- between the two forms (whole field elements in a lane, Montgomery 9 x 29 <-> plain 10 x 28 across a row) --------
 // one lane writes an element as a row record (16 words, canonical value, limbs 10..15 zero) / reads a tight record back as

@@ -14,13 +14,19 @@ def limbs29(x):
 
 def main():
     rng = np.random.default_rng(11)
-    n = 2048
+    n = 3072
     a = rng.integers(0, 1 << 29, (n, 9), dtype=np.uint32)
     # edge values: 0, R (the field's one), small residues, q - 1, q, q + 1 (lazy forms of 0 and 1), all-ones limbs
     edge = [0, R % Q, 1, 2, 3, Q - 1, Q, Q + 1, (1 << 253) - 1, (R * (Q - 1)) % Q]
+    # the integer the divsteps see is the element's residue in the internal form, i.e. the limbs themselves mod q: structured
+    # values (powers of two, q minus them, small odd numbers, (q - 1) / 2), and the same divided by R (random-looking)
+    rinv = pow(R, -1, Q)
+    cs = [1 << k for k in range(1, 252)] + [Q - (1 << k) for k in range(0, 252)] + list(range(3, 64, 2)) + [(Q - 1) // 2, (Q + 1) // 2]
+    edge += [c % Q for c in cs] + [c % Q * rinv % Q for c in cs[::3]] + [pow(c, -1, Q) for c in cs[::2]]     # ... and their inverses
     for k, x in enumerate(edge):
         a[k] = limbs29(x)
     a[len(edge)] = [(1 << 29) - 1] * 8 + [(1 << 20) - 1]
+    assert len(edge) + 1 < n
     out = np.zeros((n, 64), np.uint32)
     assert lib.row_proto_invert(P(a), P(out), n) == 0
     am = a.copy(); am[:, 8] &= 0xFFFFF
@@ -29,6 +35,9 @@ def main():
     prod_ok = (out[:, 18:27] == out[:, 27:36]).all(axis=1)
     bad_prod = int((~prod_ok & ~zero).sum())
     zero_ok = bool((out[zero][:, 0:9] == 0).all())
+    for i in np.nonzero((out[:, 0:9] != out[:, 9:18]).any(axis=1))[0][:60]:
+        c = sum(int(v) << (29 * k) for k, v in enumerate(am[i])) % Q
+        print("  differs: element %d, residue %#x (bit length %d)" % (i, c, c.bit_length()))
     print("wave inversion: %d elements (%d zero): %d differ from the lane's, %d with x * (1/x) != 1, zero -> zero %s"
           % (n, int(zero.sum()), differ, bad_prod, zero_ok))
     ms = ctypes.c_float(0)

@@ -206,3 +206,23 @@ extern "C" int row_proto_invert_chain(int which, int iters, const uint32_t* a, u
   (void)hipFree(da); (void)hipFree(dout);
   return 0;
 }
+
+// the rounds of one wave inversion, for the Python model: 25 x 80 words (the 64 lanes' limbs, then eta, u, v, q, r, md, me, f0, g0)
+__global__ void __launch_bounds__(64) k_row_invert_trace(const uint32_t* a, uint32_t* dbg) {
+  fe x;
+  for (int i = 0; i < NL; ++i) x.l[i] = a[i] & MASK29;
+  x.l[NL - 1] &= 0xFFFFF;
+  const fe iw = row::fe_invert_wave_impl<true>(x, dbg);
+  if (threadIdx.x == 0) { const fe c = fe_canon(iw); for (int i = 0; i < NL; ++i) dbg[25 * 80 + i] = c.l[i]; }
+}
+extern "C" int row_proto_invert_trace(const uint32_t* a, uint32_t* out) {
+  uint32_t *da, *dout;
+  CK(hipMalloc(&da, NL * 4)); CK(hipMalloc(&dout, (25 * 80 + 16) * 4));
+  CK(hipMemcpy(da, a, NL * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(dout, 0, (25 * 80 + 16) * 4));
+  hipLaunchKernelGGL(k_row_invert_trace, dim3(1), dim3(64), 0, 0, da, dout);
+  CK(hipGetLastError());
+  CK(hipMemcpy(out, dout, (25 * 80 + 16) * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(dout);
+  return 0;
+}
