@@ -282,6 +282,52 @@ void sim_row_records(const uint32_t* p, size_t n, int lazy, uint32_t* back, uint
     (void)fe_sqrt_tail(g_T, g.x, g.y, false, false, &root, false);   // powers that came back from the rows into the table phase
   }
 }
+// The whole-element steps of the four-elements-per-wave kernels (d377.hip k_*_tiny): the square root's powers arrive as VALUES
+// (GivenPowers: raised on the rows of the wave, back through a 28-bit-limb record) instead of being raised here, and the
+// encodings of four elements share one inversion (tiny4_encode: the product of the four p's by exchanges inside the quad).
+// enc_a: encode_to_curve with the powers handed over, each element finished by itself (dcb_finish); enc_b: the same
+// states through the four-way product and dcb_encode_one; xyzt: decompress(enc_a) and status, powers handed over again.
+void sim_tiny4(const uint32_t* r0, size_t n, uint32_t* enc_a, uint32_t* enc_b, uint32_t* xyzt, uint8_t* status) {
+  auto powers_of = [](const fe& den) {                              // invsqrt.rs:88-94 for num = 1, as row_sqrt_powers computes them
+    RegPowTab pt;
+    const fe s = fe_pow_2_47_m1(den), t_ = fe_mul(fe_sqr(s), den), w = fe_mul(fe_pow_m12(t_, pt), s);
+    uint32_t rec[16];
+    GivenPowers g;
+    fe_to_limbs28(fe_mul(w, den), rec); g.v = fe_from_limbs28(rec);
+    fe_to_limbs28(w, rec); g.uv = fe_from_limbs28(rec);
+    return g;
+  };
+  for (size_t i = 0; i + 4 <= n; i += 4) {
+    dcb_state st[4];
+    for (int j = 0; j < 4; ++j) {
+      const fe r = fe_from_words_mod_order(r0 + 8 * (i + j));
+      GivenPowers gp = powers_of(ge_elligator_den(r));
+      fe s, t;
+      ge_elligator_st(g_T, gp, r, &s, &t);
+      st[j] = ge_dcb_from_jacobi_st(s, t);
+      HostDcbIO io; io.out = enc_a; io.base = i + j;
+      dcb_put(io, 0, st[j]);
+      RegPowTab pt;
+      dcb_finish(pt, io, 1);
+    }
+    fe ab[4];
+    for (int j = 0; j < 4; ++j) ab[j] = fe_mul_strict(st[j].p, st[j ^ 1].p);
+    const fe inv = fe_invert(fe_mul_strict(ab[0], ab[2]));
+    for (int j = 0; j < 4; ++j) dcb_encode_one(st[j], fe_mul(fe_mul(inv, ab[j ^ 2]), st[j ^ 1].p), enc_b + 8 * (i + j));
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t* w = enc_a + 8 * (i + j);
+      GivenPowers gp = powers_of(ge_decompress_den(w));
+      ge g;
+      const uint32_t bad = ge_decompress(g_T, gp, w, &g);
+      status[i + j] = (uint8_t)bad;
+      ge_store256(g, xyzt + 32 * (i + j));
+      gp = powers_of(ge_compress_den(g));                          // ... and the generic compressor on the same terms
+      uint32_t back[8];
+      ge_compress(g_T, gp, g, back, bad == 0);
+      if (memcmp(back, w, 32) != 0) status[i + j] |= 2;
+    }
+  }
+}
 // reference-form addition and negation (the API kernels k_add / k_neg / k_hash_to_curve use them)
 void sim_group_misc(const uint32_t* p, const uint32_t* q, size_t n, uint32_t* sum, uint32_t* neg) {
   for (size_t i = 0; i < n; ++i) {

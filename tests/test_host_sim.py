@@ -491,6 +491,7 @@ L.sim_group_misc(p(xyzt), p(x2), n_(n), p(a), p(b))
 L.sim_quad_forms(p(xyzt), p(x2), n_(n), p(a), p(b), p(np.zeros((n, 16), np.uint64)), p(np.zeros((n, 16), np.uint64)))
 for lazy in (0, 1):
     L.sim_row_records(p(xyzt), n_(n), lazy, p(a), p(b), p(out)); L.sim_row_records(p(x2), n_(n), lazy, p(a), p(b), p(out))
+L.sim_tiny4(p(r0), n_(n), p(np.zeros((n, 32), np.uint8)), p(out), p(a), p(st)); L.sim_tiny4(p(np.zeros((n, 32), np.uint8)), n_(4), p(np.zeros((n, 32), np.uint8)), p(out), p(a), p(st))
 L.sim_to_affine_raw(p(xyzt), n_(n), p(np.zeros((n, 8), np.uint64))); L.sim_to_affine_raw(p(np.full((n, 16), 0xFFFFFFFFFFFFFFFF, np.uint64)), n_(n), p(np.zeros((n, 8), np.uint64)))
 L.sim_decompress(p(enc), n_(n), p(x2), p(st)); L.sim_msm_bucket(p(x2), p(np.array([0, 1, 1, 0, 0, 1, 0, 1], np.uint8)), n_(n), p(a)); L.sim_msm_bucket(p(x2), p(np.ones(n, np.uint8)), n_(2), p(a)); L.sim_msm_bucket(p(x2), p(np.zeros(n, np.uint8)), n_(3), p(a))
 f = [np.zeros((n, 4), np.uint64) for _ in range(5)]
@@ -653,6 +654,24 @@ def test_row_records_round_trip(sim, oracle):
         want = oracle.double_xyzt(P)
         assert oracle.eq_xyzt(dbl, want).all()
         assert (enc == oracle.compress(want)).all()
+
+
+def test_four_per_wave_whole_element_steps(sim, oracle):
+    """What the four-elements-per-wave kernels (d377.hip k_*_tiny) do in whole-element code: the square root's powers handed
+    over as values (curve.hpp GivenPowers) to the Elligator map, the decompression and the generic compressor, and the
+    encodings of four elements from one shared inversion (tiny4_encode / dcb_encode_one) -- all equal to the oracle's."""
+    rng = np.random.default_rng(43)
+    n = 64
+    r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    r0[0] = 0
+    r0[5] = r0[4]                                            # equal elements inside a quad
+    enc_a, enc_b = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
+    xyzt, st = np.zeros((n, 16), np.uint64), np.zeros(n, np.uint8)
+    sim.sim_tiny4(_p(r0), n_(n), _p(enc_a), _p(enc_b), _p(xyzt), _p(st))
+    want = oracle.encode_to_curve(r0)
+    assert (enc_a == want).all() and (enc_b == want).all()
+    o_xyzt, o_st = oracle.decompress(want)
+    assert (st == 0).all() and (o_st == 0).all() and (xyzt == o_xyzt).all()
 
 
 def test_to_affine_on_raw_records(sim, oracle):

@@ -18,6 +18,14 @@ def test_row_model_exact_and_bounded():
     assert r.returncode == 0 and "ROW_MODEL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_wave_inversion_model_exact_and_bounded():
+    """tools/inv_wave_model.py: the wave's inversion (row_ops.hpp fe_invert_wave) step for step on integers -- ~7 900 structured
+    and random residues give pow(c, -1, q), with every product sum inside int64, every limb inside the range the next round
+    assumes, d and e inside (-(round + 2) q, q] and g = 0 after 25 rounds."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "inv_wave_model.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "INV_WAVE_MODEL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_row_constants_are_current():
     """decaf377_amd/csrc/row_constants.inc is what tools/gen_row_constants.py generates (fold residues, subtraction biases)."""
     path = os.path.join(ROOT, "decaf377_amd", "csrc", "row_constants.inc")
