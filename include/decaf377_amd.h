@@ -134,8 +134,10 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
  *   MSM_RED / MSM_SKIP     msm: group size of the second reduction level (2..64) / leftovers a bucket lane sums itself (1..64)
  *   MSM_CHUNKED_SUMS       msm: 1 = weighted bucket sums by chunked running sums instead of the tree of bit-sums
  *   MSM_ENC_CHUNKED_MIN    msm_encoded: batches from this many points decode with shared inversions
- *   TINY_MAX               scalar_mul_var[_element]: batches up to this many elements take one wave per element (0 = never)
- *   MSM_TINY_MAX           msm: batches up to this many points take one wave per point (0 = never; at most MSM_SMALL_MAX applies)
+ *   TINY_MAX               scalar_mul_var[_element], scalar_mul_base[_element]: batches up to this many elements take one wave per
+ *                          element (0 = never); sqrt_ratio_zeta, decompress, compress, roundtrip, encode_to_curve, hash_to_curve:
+ *                          batches up to FOUR times this many take four elements per wave
+ *   MSM_TINY_MAX           msm: batches up to this many points take a wave per one to four points (0 = never; at most MSM_SMALL_MAX applies)
  *   CHUNK_PER_LANE         chunked kernels (sqrt_ratio_zeta, encode_to_curve[_wide], hash_to_curve, scalar_mul_var): elements per lane per chunk, 1..8
  * Returns D377_ERR_ARG for an unknown key or a value outside its range. */
 #define D377_TUNE_SMALL_MAX 0
