@@ -418,6 +418,25 @@ struct OneDcbIO {                                              // the square-roo
   __device__ __forceinline__ void parked(int, uint32_t* w) const { for (int k = 0; k < 8; ++k) w[k] = parked_[k]; }
   __device__ __forceinline__ void emit(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) out[k] = w[k]; }
 };
+// One inversion for the sixteen quads of a wave: each quad holds one value p (its four lanes alike, never zero); every lane
+// gets 1 / p of its own quad.  The product of the sixteen by an exchange tree over the quads (the partner's partial product at
+// every level is what the way back multiplies by), the wave's inversion of the total (row_ops.hpp): 8 products, 36 shuffles
+// and 17 us, against 31 us for sixteen inversions side by side on lanes.
+__device__ __forceinline__ fe fe_shfl_xor(const fe& a, int mask) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)__shfl_xor((int)a.l[i], mask);
+  return r;
+}
+__device__ __forceinline__ fe quads16_invert(const fe& p) {
+  const fe q0 = fe_shfl_xor(p, 4), p1 = fe_mul_strict(p, q0);
+  const fe q1 = fe_shfl_xor(p1, 8), p2 = fe_mul_strict(p1, q1);
+  const fe q2 = fe_shfl_xor(p2, 16), p3 = fe_mul_strict(p2, q2);
+  const fe q3 = fe_shfl_xor(p3, 32);
+  const fe inv = row::fe_invert_wave(fe_mul_strict(p3, q3));      // the same total in every lane
+  return fe_mul(fe_mul(fe_mul(fe_mul(inv, q3), q2), q1), q0);
+}
+
 // ELEMENT: the reference's own signature (Element * Fr -> Element, src/min_curve/ops.rs:89-95): records in and out, no
 // square root at either end, so the whole chain splits four ways (0.88 -> ~0.36 ms per call).
 template <bool ELEMENT>
@@ -455,15 +474,68 @@ k_scalar_mul_var_small(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar
     if (ELEMENT) {
       if (active && role == 0) store_ge_mont256(reinterpret_cast<uint64_t*>(out32), e, r);
     } else {
-      OneDcbIO io;
-      dcb_put(io, 0, ge_dcb_from_half(r, bad != 0));           // failed elements: neutral state, all-zero output
-      dcb_finish(pt, io, 1);
+      const dcb_state st = ge_dcb_from_half(r, bad != 0);     // failed elements: neutral state, all-zero output
+      uint32_t wo[8];
+      dcb_encode_one(st, quads16_invert(st.p), wo);             // one inversion for the sixteen elements of the wave
       if (active && role == 0) {
-        store32(out32, e, io.out);
+        store32(out32, e, wo);
         status[e] = (uint8_t)bad;
       }
     }
     __syncthreads();                                           // the table is rewritten by the next element
+  }
+}
+
+// The fixed-base multiplication on quads, for the same batch sizes: FB_WINDOWS mixed additions of comb entries are 2.7 us each
+// on a lane and 1.1 us on a quad (the lane takes its slot of the entry straight from the table: the comb's records are
+// cached affine points in the internal form already), and the sixteen encodings of a wave share one inversion: 0.098 ->
+// ~0.06 ms per call.
+// lane `role`'s slot of window i's comb entry for the digit d (the records hold Y + X, Y - X, 2dXY; Z = 1).
+// (A free function, not a lambda inside the kernel: with the lambda hipcc compiled EVERY kernel of this file differently --
+// k_scalar_mul_var 249 VGPRs and 84 SGPR spills instead of 256 and 47 -- which tools/resource_usage.sh is there to catch.)
+__device__ __forceinline__ fe fb_fetch_slot(const uint32_t* fbase, int role, int i, int d) {
+  const int slot = gq_add_slot(role, d < 0);
+  const uint32_t* src = fbase + ((size_t)i * FB_ENTRIES + (size_t)(d < 0 ? -d : d)) * FBW_ENTRY_WORDS + NL * (slot == 0 ? 1 : (slot == 1 ? 0 : 2));
+  fe x = fe_const(FE_ONE);
+  if (slot < 3) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) x.l[j] = src[j];
+  }
+  return x;
+}
+template <bool ELEMENT>
+__global__ void __launch_bounds__(SMALL_THREADS)
+k_scalar_mul_base_small(const uint32_t* fbase, const uint8_t* scalar32, size_t n, uint8_t* out) {
+  const int role = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  const size_t e_raw = (size_t)blockIdx.x * SMALL_QUADS + quad;   // grid = ceil(n / 16)
+  const bool active = e_raw < n;
+  const size_t e = active ? e_raw : n - 1;                       // idle quads redo the last element and store nothing
+  uint32_t k[8];
+  load32(scalar32, e, k);
+  fr_reduce_words(k);
+  if (!ELEMENT) fr_half_words(k);                                // [k]B = [2]([k/2 mod r]B): the encoding of a double needs no square root
+  uint32_t carry = 0;
+  int d = fb_digit(k, 0, carry);
+  fe nxt = fb_fetch_slot(fbase, role, 0, d);
+  fe v = gq_from_ge(ge_identity(), role);
+#pragma unroll 1
+  for (int i = 0; i < FB_WINDOWS; ++i) {
+    const fe cur = nxt;
+    const bool neg = d < 0;
+    if (i + 1 < FB_WINDOWS) {                                    // the next entry is in flight during this addition
+      d = fb_digit(k, i + 1, carry);
+      nxt = fb_fetch_slot(fbase, role, i + 1, d);
+    }
+    v = gq_add_with(v, cur, role, neg);
+  }
+  const ge r = gq_to_ge(v);
+  if (ELEMENT) {
+    if (active && role == 0) store_ge_mont256(reinterpret_cast<uint64_t*>(out), e, r);
+  } else {
+    const dcb_state st = ge_dcb_from_half(r, false);
+    uint32_t w[8];
+    dcb_encode_one(st, quads16_invert(st.p), w);
+    if (active && role == 0) store32(out, e, w);
   }
 }
 
@@ -1360,6 +1432,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
         hipLaunchKernelGGL(k_scalar_mul_base_tiny<false>, dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
         break;
       }
+      if (n <= small_batch_max(d, false)) {                   // one scalar per quad of lanes
+        hipLaunchKernelGGL(k_scalar_mul_base_small<false>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, d.fbase,
+                           (const uint8_t*)in0, n, (uint8_t*)out0);
+        break;
+      }
       bool wide = n >= d.resident_lanes() * DCB_K * FB_WIDE_GENERATIONS;
       if (d.is_tuned(D377_TUNE_FB_WIDE)) wide = d.tuned(D377_TUNE_FB_WIDE, 0) != 0;               // developer overrides (A/B)
       const int fk = (int)d.tuned(D377_TUNE_FB_K, wide ? FB_K : DCB_K);
@@ -1482,6 +1559,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     case OP_MUL_BASE_EL:
       if (n <= tiny_batch_max(d)) {
         hipLaunchKernelGGL(k_scalar_mul_base_tiny<true>, dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
+        break;
+      }
+      if (n <= small_batch_max(d, true)) {
+        hipLaunchKernelGGL(k_scalar_mul_base_small<true>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, d.fbase,
+                           (const uint8_t*)in0, n, (uint8_t*)out0);
         break;
       }
       hipLaunchKernelGGL(k_scalar_mul_base_el, dim3(g), dim3(BLOCK), 0, s, d.fbase, (const uint8_t*)in0, n, (uint64_t*)out0);

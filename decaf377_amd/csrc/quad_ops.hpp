@@ -58,18 +58,24 @@ __device__ __forceinline__ void gq_store_cached(uint32_t* rec, const ge& p) {
   for (int i = 0; i < NL; ++i) { rec[i] = ymx.l[i]; rec[NL + i] = ypx.l[i]; rec[2 * NL + i] = kt.l[i]; rec[3 * NL + i] = p.z.l[i]; }
 }
 // P + Q, or P - Q with neg_q (wave-uniform): src/min_curve/element.rs:291-322 with Q cached, as ge_add_cached
-__device__ __forceinline__ fe gq_add(const fe& v, const uint32_t* qrec, int role, bool neg_q) {
+// the slot of Q's cached form lane `role` multiplies by: -Q has Y-X and Y+X change places
+__device__ __forceinline__ int gq_add_slot(int role, bool neg_q) { return (role < 2 && neg_q) ? (role ^ 1) : role; }
+// ... with the lane's slot of Q already in hand (opb), wherever it came from
+__device__ __forceinline__ fe gq_add_with(const fe& v, const fe& opb, int role, bool neg_q) {
   // lane 0: (Yp - Xp)(Yq - Xq), lane 1: (Yp + Xp)(Yq + Xq), lane 2: Tp * 2dTq, lane 3: 2Zp * Zq
   const fe opa = gq_add_in_own(role, fe_quad_perm<1, 1, 3, 2>(v), fe_quad_perm<0, 0, 3, 2>(v));
-  const int slot = (role < 2 && neg_q) ? (role ^ 1) : role;     // -Q: Y-X and Y+X change places
-  fe opb;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) opb.l[i] = qrec[slot * NL + i];
   const fe m1 = fe_mul(opa, opb);                               // a, b, c, d
   // E = b - a, H = b + a, F = d - c, G = d + c; the sign of 2dT (-Q) makes F and G change places
   const bool sub = (role == 0) | ((role >= 2) & ((role == 2) != neg_q));   // (bitwise: no branches on a lane's role)
   const fe w = gq_add_own(sub, fe_quad_perm<1, 1, 3, 3>(m1), fe_quad_perm<0, 0, 2, 2>(m1));   // E, H, F, G
   return fe_mul(fe_quad_perm<0, 3, 2, 0>(w), fe_quad_perm<2, 1, 3, 1>(w));   // E F, G H, F G, E H
+}
+__device__ __forceinline__ fe gq_add(const fe& v, const uint32_t* qrec, int role, bool neg_q) {
+  const int slot = gq_add_slot(role, neg_q);
+  fe opb;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) opb.l[i] = qrec[slot * NL + i];
+  return gq_add_with(v, opb, role, neg_q);
 }
 // a whole point (every lane the same copy) -> its distributed form, and back
 __device__ __forceinline__ fe gq_from_ge(const ge& p, int role) { return fe_pick(role, p.x, p.y, p.z, p.t); }

@@ -1,0 +1,32 @@
+"""The compiler's resource table of the kernels whose code must not move by accident.  hipcc's code generation for one
+kernel of a translation unit can depend on what ELSE the unit contains (a lambda added to an unrelated kernel recompiled
+every kernel of d377.hip: k_scalar_mul_var went from 256 VGPRs / 47 SGPR spills to 249 / 84), and the headline kernels are
+measured, tuned artefacts: a change of their registers or spills has to be a decision, made with a same-box A/B, not a side
+effect.  After such a decision: tools/resource_usage.sh > profiles/rNN_resource_usage.txt (local, no GPU) and point
+COMMITTED below at it."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMITTED = os.path.join(ROOT, "profiles", "r04_resource_usage.txt")
+GUARDED = ("k_scalar_mul_var", "k_scalar_mul_base", "k_sqrt_ratio_zeta", "k_encode_to_curve", "k_hash_to_curve", "k_decompress", "k_compress",
+           "k_roundtrip", "k_scalar_mul_var_el", "k_to_affine", "k_msm_segments", "k_msm_prepare_affine")
+
+
+def rows(text):
+    out = {}
+    for line in text.splitlines():
+        m = re.match(r"(k_\w+)\s+(.*)", line)
+        if m and m.group(1) in GUARDED:
+            out.setdefault(m.group(1), []).append(re.sub(r"\s+", " ", m.group(2)).strip())
+    return out
+
+
+def test_hot_kernels_compile_to_the_committed_resource_table():
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "resource_usage.sh")], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "k_scalar_mul_var" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+    now, want = rows(r.stdout), rows(open(COMMITTED).read())
+    assert set(GUARDED) <= set(want), sorted(set(GUARDED) - set(want))
+    moved = {k: (want[k], now.get(k)) for k in GUARDED if now.get(k) != want[k]}
+    assert not moved, "registers / spills / LDS of guarded kernels differ from %s: %s" % (os.path.relpath(COMMITTED, ROOT), moved)

@@ -615,24 +615,32 @@ def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
 
 def test_tiny_batch_fixed_base_wave_kernel(ctx, oracle, torch_mod):
     """Up to one scalar per SIMD the fixed-base multiplication gives every scalar a wave (d377.hip k_scalar_mul_base_tiny: comb
-    entries as row records, lane-spread additions, the wave's inversion).  Same bytes as the lane-per-element kernel (tiny_max
-    = 0) and as the oracle at sizes around its threshold, zero and extreme scalars included; the Element form likewise (as
-    group elements)."""
+    entries as row records, lane-spread additions, the wave's inversion), up to 64 per CU a quad of lanes
+    (k_scalar_mul_base_small: sixteen encodings per inversion).  Same bytes as the lane-per-element kernel (small_max = 0) and
+    as the oracle at sizes around every threshold, zero and extreme scalars included; the Element form likewise (as group
+    elements)."""
     torch = torch_mod
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(4402)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    for n in (1, 2, 17, 1000, 4 * cus, 4 * cus + 1):
+    for n in (1, 2, 15, 16, 17, 1000, 4 * cus, 4 * cus + 1, 64 * cus - 1, 64 * cus + 1, 112 * cus + 1, 128 * cus + 1):
         k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
         for i, v in enumerate([0, 1, 2, R_ORDER - 1, R_ORDER, R_ORDER + 1, (1 << 256) - 1, (1 << 18) - 1, 1 << 17, (1 << 17) + 1][:n]):
             k[i] = ibytes(v)
         tk = torch.from_numpy(k).to(dev)
-        with ctx.tuning(tiny_max=0):
+        with ctx.tuning(small_max=0):                         # one lane per scalar
             out_l = ctx.scalar_mul_base(tk)
             el_l = ctx.compress(ctx.scalar_mul_base_element(tk))
-        with ctx.tuning(tiny_max=10**6):
-            out_w = ctx.scalar_mul_base(tk)
-            el_w = ctx.compress(ctx.scalar_mul_base_element(tk))
+        with ctx.tuning(tiny_max=0, small_max=10**6):         # one quad of lanes per scalar (k_scalar_mul_base_small)
+            out_q = ctx.scalar_mul_base(tk)
+            el_q = ctx.compress(ctx.scalar_mul_base_element(tk))
+        assert torch.equal(out_q, out_l) and torch.equal(el_q, el_l), n
+        if n <= 4 * cus + 1:
+            with ctx.tuning(tiny_max=10**6):                  # one wave per scalar
+                out_w = ctx.scalar_mul_base(tk)
+                el_w = ctx.compress(ctx.scalar_mul_base_element(tk))
+        else:
+            out_w, el_w = out_q, el_q
         out_d = ctx.scalar_mul_base(tk)                       # whatever the size picks
         assert torch.equal(out_w, out_l) and torch.equal(out_d, out_l) and torch.equal(el_w, el_l) and torch.equal(el_l, out_l), n
         sel = np.unique(np.concatenate([np.arange(min(n, 24)), np.arange(max(0, n - 24), n)]))

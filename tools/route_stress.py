@@ -124,15 +124,15 @@ def main():
         if n > 6000:
             continue
         res = []
-        for kv in (dict(tiny_max=0), dict(tiny_max=10**9)):
+        for kv in (dict(small_max=0), dict(tiny_max=0, small_max=10**9), dict(tiny_max=10**9)):   # lanes, quads (fixed base), waves
             with ctx.tuning(**kv):
                 P, st = ctx.decompress(enc_all[:n])
                 res.append([ctx.scalar_mul_base(k[:n]), *ctx.sqrt_ratio_zeta(r0[:n], r1[:n]), *ctx.sqrt_ratio_zeta(r0[:n], r1[:n], root="min_curve"),
                             P, st, *ctx.roundtrip(enc_all[:n]), ctx.compress(P_all[:n]), ctx.encode_to_curve(r0[:n]), ctx.hash_to_curve(r0[:n], r1[:n])])
-        ok = all(torch.equal(a, b) for a, b in zip(*res))
+        ok = all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(*res))
         sel = np.unique(rng.integers(0, n, 4))
-        ok = ok and (res[1][-1][sel].cpu().numpy() == orc.hash_to_curve(r0[:n][sel].cpu().numpy(), r1[:n][sel].cpu().numpy())).all()
-        ok = ok and (res[1][0][sel].cpu().numpy() == orc.scalar_mul_base(k[:n][sel].cpu().numpy())).all()
+        ok = ok and (res[2][-1][sel].cpu().numpy() == orc.hash_to_curve(r0[:n][sel].cpu().numpy(), r1[:n][sel].cpu().numpy())).all()
+        ok = ok and (res[1][0][sel].cpu().numpy() == res[2][0][sel].cpu().numpy()).all() and (res[2][0][sel].cpu().numpy() == orc.scalar_mul_base(k[:n][sel].cpu().numpy())).all()
         bad += 0 if ok else 1
         cnt += 1
         if not ok:
