@@ -810,6 +810,48 @@ __global__ void __launch_bounds__(64) k_map_to_curve_tiny(SqrtTables T, const ui
   if (me.own) store32(out32, me.e, w);
 }
 
+// hash_to_curve with TWO pairs per wave (batches up to half the size): the four square roots of the wave are the two maps of
+// two pairs, so one pass over the rows serves both maps of a pair (0.235 -> ~0.18 ms per call).  Lane t works for map t & 1
+// of pair (t >> 1) & 1; the two lanes of a pair exchange their (s, t) and both form the sum.
+__global__ void __launch_bounds__(64) k_hash_to_curve_tiny2(SqrtTables T, const uint8_t* r1, const uint8_t* r2, size_t n, uint8_t* out32) {
+  __shared__ Tiny4Lds L;
+  const row::RowK K = row::row_consts();
+  const int t = threadIdx.x, which = t & 1;
+  const size_t e_raw = (size_t)blockIdx.x * 2 + ((t >> 1) & 1);
+  const size_t e = e_raw < n ? e_raw : n - 1;
+  uint32_t w[8];
+  load32(which ? r2 : r1, e, w);
+  const fe r0 = fe_from_words_mod_order(w);
+  fe s_own, t_own;
+  GivenPowers pt = tiny4_powers<false>(L, fe_zero(), ge_elligator_den(r0), K);
+  ge_elligator_st(T, pt, r0, &s_own, &t_own);
+  D377_INVARIANT(T, ge_from_jacobi_st(s_own, t_own), t < 4);
+  const fe s_oth = fe_quad_perm<1, 0, 3, 2>(s_own), t_oth = fe_quad_perm<1, 0, 3, 2>(t_own);
+  const bool second = which != 0;                              // both lanes of a pair: (map of r1) + (map of r2), in that order
+  bool exceptional;
+  dcb_state st = ge_dcb_from_jacobi_sum(fe_select(second, s_oth, s_own), fe_select(second, t_oth, t_own),
+                                        fe_select(second, s_own, s_oth), fe_select(second, t_own, t_oth), &exceptional);
+#if defined(D377_CHECK_INVARIANTS)
+  exceptional |= (e & 3) == 3;                                  // as in k_hash_to_curve: the debug build exercises the exceptional route
+#endif
+  if (__any(exceptional)) {
+    __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
+    struct Pow64 {
+      uint32_t* col;
+      __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
+      __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
+    } lp;
+    lp.col = lds_pow_ + threadIdx.x;
+    uint32_t we[8];
+    hash_exceptional_pair(T, lp, r1, r2, e, we);
+    const dcb_state se = dcb_from_encoding_words(we);
+    st.p = fe_select(exceptional, se.p, st.p); st.w = fe_select(exceptional, se.w, st.w);
+    st.n0 = fe_select(exceptional, se.n0, st.n0); st.n1 = fe_select(exceptional, se.n1, st.n1);
+  }
+  tiny4_encode(st, w);                                          // (the quad's four values are p_A, p_A, p_B, p_B: any four non-zero values do)
+  if (t < 4 && which == 0 && e_raw < n) store32(out32, e, w);
+}
+
 // The reference's own signatures for these operations take and return Elements (`Element * Fr`,
 // src/min_curve/ops.rs:89-95; `Element::encode_to_curve`, `hash_to_curve`, src/min_curve/element.rs:235-244;
 // `vartime_compress_to_field`, :163-181): the same per-lane code as above without the encoding step at either
@@ -1472,6 +1514,10 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_encode_to_curve, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_ENCODE], s, T, (const uint8_t*)in0, n, (uint8_t*)out0, dcb);
       break;
     case OP_HASH:
+      if (n <= tiny4_batch_max(d) / 2) {                      // two pairs per wave: one pass over the rows for both maps
+        hipLaunchKernelGGL(k_hash_to_curve_tiny2, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0);
+        break;
+      }
       if (n <= tiny4_batch_max(d)) {
         hipLaunchKernelGGL(k_map_to_curve_tiny, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, (const uint8_t*)in1, n, (uint8_t*)out0);
         break;

@@ -1171,11 +1171,12 @@ int msm_reserve(DeviceState& d, hipStream_t s, size_t bytes, MsmHeld& held) {
 // Batches up to this many points skip the buckets (k_msm_small).  D377_TUNE_MSM_SMALL_MAX: developer override (0 = never).
 size_t msm_small_max(const DeviceState& d) { return (size_t)d.tuned(D377_TUNE_MSM_SMALL_MAX, (long long)d.cus * 4 * MS_QUADS); }
 
-// Batches up to this many points take a wave per 1 .. MT_MAX points (k_msm_tiny): one wave per SIMD, up to 4 (Elements) or 2
-// (Encodings: a square root per point) points each -- measured against the quads in profiles/r04_size_sweep_msm.txt.
+// Batches up to this many points take a wave per 1 .. MT_MAX points (k_msm_tiny): one wave per SIMD, up to 4 points each --
+// measured against the quads (profiles/r04_size_sweep_msm.txt; Encodings at 3 072 / 4 096 points: 454 / 489 us against 534 / 537).
 // D377_TUNE_MSM_TINY_MAX: developer override.
 size_t msm_tiny_max(const DeviceState& d, bool encoded) {
-  return (size_t)d.tuned(D377_TUNE_MSM_TINY_MAX, (long long)d.cus * 4 * (encoded ? 2 : MT_MAX));
+  (void)encoded;
+  return (size_t)d.tuned(D377_TUNE_MSM_TINY_MAX, (long long)d.cus * 4 * MT_MAX);
 }
 
 int msm_launch_small(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,

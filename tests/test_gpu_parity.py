@@ -650,14 +650,15 @@ def test_tiny_batch_fixed_base_wave_kernel(ctx, oracle, torch_mod):
 def test_tiny_batch_sqrt_family_four_per_wave(ctx, oracle, torch_mod):
     """Up to four elements per SIMD the square-root family -- sqrt_ratio_zeta (either root), decompress, compress, the round
     trip, encode_to_curve, hash_to_curve -- runs four elements per wave: the power chains of the square roots on the rows of
-    the wave, one inversion per wave for the encodings (d377.hip k_*_tiny).  Same bytes as the lane-per-element kernels
+    the wave, one inversion per wave for the encodings (d377.hip k_*_tiny; hash_to_curve up to half the size: two pairs per wave,
+    both maps of a pair in one pass over the rows).  Same bytes as the lane-per-element kernels
     (tiny_max = 0) at sizes around every edge (ragged last wave, one past the threshold), invalid encodings and zero
     numerators / denominators included, and as the oracle."""
     torch = torch_mod
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(4403)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    for n in (1, 2, 3, 4, 5, 7, 17, 1000, 16 * cus - 1, 16 * cus, 16 * cus + 1):
+    for n in (1, 2, 3, 4, 5, 7, 17, 1000, 8 * cus - 1, 8 * cus, 8 * cus + 1, 16 * cus - 1, 16 * cus, 16 * cus + 1):
         r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
         r1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
         r0[0] = 0                                            # zero numerator / Elligator of 0
@@ -1489,7 +1490,8 @@ xyzt, st = ctx.decompress(enc)
 assert (ctx.compress(ctx.double(ctx.add(xyzt, xyzt[::-1].copy()))) == orc.compress(orc.double_xyzt(orc.add_xyzt(xyzt, xyzt[::-1].copy())))).all()
 e, _, _ = ctx.msm(enc[:3000], k[:3000]); assert bytes(e) == bytes(orc.msm(xyzt[:3000], k[:3000])[0])
 m = 1000                                                    # the smallest batches' kernels (four elements / one scalar per wave)
-assert (ctx.hash_to_curve(r0[:m], r1[:m]) == orc.hash_to_curve(r0[:m], r1[:m])).all()   # exceptional route included
+assert (ctx.hash_to_curve(r0[:m], r1[:m]) == orc.hash_to_curve(r0[:m], r1[:m])).all()   # exceptional route included (two pairs per wave)
+assert (ctx.hash_to_curve(r0[:3 * m], r1[:3 * m]) == orc.hash_to_curve(r0[:3 * m], r1[:3 * m])).all()   # ... and four per wave
 assert (ctx.encode_to_curve(r0[:m]) == orc.encode_to_curve(r0[:m])).all()
 rt, st = ctx.roundtrip(raw[:m]); o_rt, o_st = orc.roundtrip(raw[:m])
 assert (rt == o_rt).all() and (st == o_st).all()
