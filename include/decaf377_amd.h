@@ -122,9 +122,10 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
  * context, and read under its mutex by every later call on it (calls already enqueued keep what they were launched
  * with); D377_TUNE_DEFAULT restores the built-in rule.  Nothing in the library reads the process environment on a call
  * path (D377_DEBUG_* diagnostics at context creation and in the multi-device test hook aside).
- *   SMALL_MAX              scalar_mul_var[_element]: batches up to this many elements take the quad-per-element kernel (0 = never)
+ *   SMALL_MAX              scalar_mul_var[_element], scalar_mul_base[_element]: batches up to this many elements take the quad-per-element
+ *                          kernel (0 = never; it also caps TINY_MAX)
  *   DECOMPRESS_CHUNKED_MIN decompress: batches from this many elements decode with shared inversions
- *   FB_WIDE                scalar_mul_base: 0 = narrow launch (2 workgroups per CU), 1 = wide (3 per CU) at every size
+ *   FB_WIDE                scalar_mul_base: 0 = narrow launch (2 workgroups per CU), 1 = wide (3 per CU) at every size the lane kernel takes
  *   FB_K                   scalar_mul_base: elements per lane per shared inversion, 1..16
  *   AFFINE_BLOCKS_PER_CU   to_affine: workgroups per CU that share the batch, >= 1
  *   MSM_WINDOW             msm: window width in bits, 4..16
@@ -136,7 +137,7 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
  *   MSM_ENC_CHUNKED_MIN    msm_encoded: batches from this many points decode with shared inversions
  *   TINY_MAX               scalar_mul_var[_element], scalar_mul_base[_element]: batches up to this many elements take one wave per
  *                          element (0 = never); sqrt_ratio_zeta, decompress, compress, roundtrip, encode_to_curve, hash_to_curve:
- *                          batches up to FOUR times this many take four elements per wave
+ *                          batches up to FOUR times this many take four elements per wave (hash_to_curve up to twice: two pairs)
  *   MSM_TINY_MAX           msm: batches up to this many points take a wave per one to four points (0 = never; at most MSM_SMALL_MAX applies)
  *   CHUNK_PER_LANE         chunked kernels (sqrt_ratio_zeta, encode_to_curve[_wide], hash_to_curve, scalar_mul_var): elements per lane per chunk, 1..8
  * Returns D377_ERR_ARG for an unknown key or a value outside its range. */
