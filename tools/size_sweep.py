@@ -17,15 +17,21 @@ import decaf377_amd as d
 
 
 def timed(fn, reps):
+    # the better of two batches: a host-side stall inside a batch of 100-us calls (seen: +40 us per call on the first small
+    # size after a 2^22 batch, while the graph replay of the same call showed the kernel's time) is not the operation's time
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3          # us
+    best = None
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        best = us if best is None or us < best else best
+    return best
 
 
 def main():
