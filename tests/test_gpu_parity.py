@@ -696,6 +696,40 @@ def test_tiny_batch_sqrt_family_four_per_wave(ctx, oracle, torch_mod):
         assert (w[5].cpu().numpy()[sel] == oracle.hash_to_curve(r0[sel], r1[sel])).all(), n
 
 
+def test_hash_to_curve_exceptional_pairs_in_the_product_build(ctx, oracle, torch_mod):
+    """The exceptional case of the Jacobi quartic's addition law (s1 s2 = +-1), on real inputs in the PRODUCT binary:
+    tests/golden/hash_exceptional_pairs.json holds constructed pairs (r1, r2) that hit it.  Every route of hash_to_curve --
+    two pairs per wave, four per wave, one lane per pair in chunks (a wave takes the fallback branch when one of its lanes
+    needs it) -- and the Element form give the oracle's bytes, for the pairs alone, swapped, and scattered through batches of
+    ordinary pairs."""
+    import json
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    pairs = json.load(open(os.path.join(ROOT, "tests", "golden", "hash_exceptional_pairs.json")))["pairs"]
+    e1 = np.array([list(bytes.fromhex(p["r1"])) for p in pairs], np.uint8)
+    e2 = np.array([list(bytes.fromhex(p["r2"])) for p in pairs], np.uint8)
+    want_e = np.array([list(bytes.fromhex(p["encoding"])) for p in pairs], np.uint8)
+    rng = np.random.default_rng(4404)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for n in (len(pairs), 8 * cus - 3, 16 * cus - 3, 70001):
+        r1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        r2 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        pos = np.arange(len(pairs)) if n == len(pairs) else rng.choice(n, len(pairs), replace=False)
+        r1[pos], r2[pos] = e1, e2
+        half = pos[: len(pos) // 2]
+        r1[half], r2[half] = e2[: len(half)], e1[: len(half)]          # swapped
+        t1, t2 = torch.from_numpy(r1).to(dev), torch.from_numpy(r2).to(dev)
+        outs = []
+        for kv in (dict(tiny_max=0), dict(tiny_max=10**6), {}):
+            with ctx.tuning(**kv):
+                outs.append(ctx.hash_to_curve(t1, t2).cpu().numpy())
+                outs.append(ctx.compress(ctx.hash_to_curve_element(t1, t2)).cpu().numpy())
+        assert all((o == outs[0]).all() for o in outs), n
+        assert (outs[0][pos] == want_e).all(), n
+        sel = np.unique(np.concatenate([pos, rng.integers(0, n, 40)]))
+        assert (outs[0][sel] == oracle.hash_to_curve(r1[sel], r2[sel])).all(), n
+
+
 def test_chunk_residency_is_checked(ctx):
     """The lane-set pool of the scratch areas assumes at most `sets` resident workgroups per CU of every kernel that
     claims a set.  d377_ctx_create verifies that with the occupancy query (and pads the launch's LDS where registers

@@ -407,3 +407,25 @@ def test_element_form_oracle_entry_points(oracle):
     assert (oracle.fq_to_bytes(oracle.compress_to_field(P)) == oracle.compress(P)).all()
     assert (oracle.compress(oracle.hash_to_curve_xyzt(r0, r1)) == oracle.hash_to_curve(r0, r1)).all()
     assert (oracle.hash_to_curve_xyzt(r0, r1) == oracle.add_xyzt(P, oracle.elligator_map_xyzt(r1))).all()
+
+
+def test_hash_to_curve_exceptional_pairs(oracle):
+    """tests/golden/hash_exceptional_pairs.json: constructed inputs (r1, r2) whose Elligator images satisfy s1 s2 = +-1 on the
+    Jacobi quartic (the case the GPU kernels hand to the reference's own route).  The fixture is what its script generates,
+    and the C oracle -- which always adds on the Edwards curve, as the reference does -- gives the model's encodings."""
+    import json, subprocess, sys
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hash_exceptional_pairs.json")
+    before = open(path).read()
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(path), "make_exceptional_pairs.py")], capture_output=True, text=True, timeout=300)
+    after = open(path).read()
+    if after != before:
+        open(path, "w").write(before)
+    assert r.returncode == 0 and after == before, r.stdout + r.stderr
+    pairs = json.loads(before)["pairs"]
+    assert len(pairs) >= 8 and {p["s1_s2"] for p in pairs} == {"+1", "-1"}
+    r1 = np.array([list(bytes.fromhex(p["r1"])) for p in pairs], np.uint8)
+    r2 = np.array([list(bytes.fromhex(p["r2"])) for p in pairs], np.uint8)
+    want = np.array([list(bytes.fromhex(p["encoding"])) for p in pairs], np.uint8)
+    assert (oracle.hash_to_curve(r1, r2) == want).all() and (oracle.hash_to_curve(r2, r1) == want).all()
+    assert (oracle.compress(oracle.hash_to_curve_xyzt(r1, r2)) == want).all()
+    assert any(w.any() for w in want) and any(not w.any() for w in want)          # sums in and outside the identity's class
