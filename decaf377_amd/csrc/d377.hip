@@ -764,6 +764,24 @@ __global__ void __launch_bounds__(64) k_compress_tiny(SqrtTables T, const uint64
   if (me.own) store32(enc32, me.e, w);
 }
 
+// A pair that hits the exceptional case of the quartic's addition law goes the reference's way (as in k_hash_to_curve: whole-
+// element square roots, their power table one LDS column per lane of the wave) and enters the encoder as a finished encoding.
+// Called by the whole wave when any of its lanes needs it.
+__device__ __forceinline__ void tiny_hash_exceptional(SqrtTables T, const uint8_t* r1, const uint8_t* r2, size_t e, bool exceptional, dcb_state& st) {
+  __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
+  struct Pow64 {
+    uint32_t* col;
+    __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
+    __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
+  } lp;
+  lp.col = lds_pow_ + threadIdx.x;
+  uint32_t we[8];
+  hash_exceptional_pair(T, lp, r1, r2, e, we);
+  const dcb_state se = dcb_from_encoding_words(we);
+  st.p = fe_select(exceptional, se.p, st.p); st.w = fe_select(exceptional, se.w, st.w);
+  st.n0 = fe_select(exceptional, se.n0, st.n0); st.n1 = fe_select(exceptional, se.n1, st.n1);
+}
+
 // r2 null: encode_to_curve; otherwise hash_to_curve (two maps one after the other, the sum on the Jacobi quartic; the
 // exceptional pair goes the reference's way as in k_hash_to_curve, with whole-element square roots)
 __global__ void __launch_bounds__(64) k_map_to_curve_tiny(SqrtTables T, const uint8_t* r1, const uint8_t* r2, size_t n, uint8_t* out32) {
@@ -791,20 +809,7 @@ __global__ void __launch_bounds__(64) k_map_to_curve_tiny(SqrtTables T, const ui
 #if defined(D377_CHECK_INVARIANTS)
     exceptional |= (me.e & 3) == 3;                 // as in k_hash_to_curve: the debug build exercises the exceptional route
 #endif
-    if (__any(exceptional)) {
-      __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
-      struct Pow64 {
-        uint32_t* col;
-        __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
-        __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
-      } lp;
-      lp.col = lds_pow_ + threadIdx.x;
-      uint32_t we[8];
-      hash_exceptional_pair(T, lp, r1, r2, me.e, we);
-      const dcb_state se = dcb_from_encoding_words(we);
-      st.p = fe_select(exceptional, se.p, st.p); st.w = fe_select(exceptional, se.w, st.w);
-      st.n0 = fe_select(exceptional, se.n0, st.n0); st.n1 = fe_select(exceptional, se.n1, st.n1);
-    }
+    if (__any(exceptional)) tiny_hash_exceptional(T, r1, r2, me.e, exceptional, st);
   }
   tiny4_encode(st, w);
   if (me.own) store32(out32, me.e, w);
@@ -834,20 +839,7 @@ __global__ void __launch_bounds__(64) k_hash_to_curve_tiny2(SqrtTables T, const 
 #if defined(D377_CHECK_INVARIANTS)
   exceptional |= (e & 3) == 3;                                  // as in k_hash_to_curve: the debug build exercises the exceptional route
 #endif
-  if (__any(exceptional)) {
-    __shared__ uint32_t lds_pow_[POW_TAB * NL * 64];
-    struct Pow64 {
-      uint32_t* col;
-      __device__ __forceinline__ void put(int j, const fe& v) { for (int k = 0; k < NL; ++k) col[(j * NL + k) * 64] = v.l[k]; }
-      __device__ __forceinline__ fe get(int j) const { fe r; for (int k = 0; k < NL; ++k) r.l[k] = col[(j * NL + k) * 64]; return r; }
-    } lp;
-    lp.col = lds_pow_ + threadIdx.x;
-    uint32_t we[8];
-    hash_exceptional_pair(T, lp, r1, r2, e, we);
-    const dcb_state se = dcb_from_encoding_words(we);
-    st.p = fe_select(exceptional, se.p, st.p); st.w = fe_select(exceptional, se.w, st.w);
-    st.n0 = fe_select(exceptional, se.n0, st.n0); st.n1 = fe_select(exceptional, se.n1, st.n1);
-  }
+  if (__any(exceptional)) tiny_hash_exceptional(T, r1, r2, e, exceptional, st);
   tiny4_encode(st, w);                                          // (the quad's four values are p_A, p_A, p_B, p_B: any four non-zero values do)
   if (t < 4 && which == 0 && e_raw < n) store32(out32, e, w);
 }
