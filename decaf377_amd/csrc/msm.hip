@@ -61,7 +61,7 @@ constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a seri
 // level of its own costs: 16 -- and 32 since four lanes share a bucket's partials (k_msm_buckets): up to eight additions per lane.
 struct RedSizes { int g[3]; uint32_t skip; };
 constexpr RedSizes RED_DEFAULT = {{8, 8, 32}, 32};
-// Points per lane in k_msm_segments (`seg`, a launch parameter): 8, 16 or 32 by batch size -- pick_seg() below.
+// Points per lane in k_msm_segments (`seg`, a launch parameter): 8 .. 64 by batch size and window width -- pick_seg() below.
 constexpr int MAX_SEG = 128;
 
 // Every input point is normalised to affine form once (Z = 1 already after decompression; one batched inversion
@@ -1124,14 +1124,30 @@ int pick_window(const DeviceState& d, size_t n) {
   return (int)d.tuned(D377_TUNE_MSM_WINDOW, c);              // developer override: 4 .. 16 (>= 4: at most 63 windows, k_msm_final's table of cached sums)
 }
 
-// Points per segment lane.  Measured on one MI355X (D377_TUNE_MSM_SEG sweep, whole MSM, Elements): 2^20 points 2.12 / 2.15 /
-// 2.26 / 2.64 ms and 2^22 points 6.70 / 6.62 / 6.71 / 6.97 ms with 16 / 32 / 64 / 128 -- once a group of one partial is
-// copied instead of added to the identity, more and shorter segments cost little afterwards and balance the last
-// generation of lanes better.  Small batches take 8: the longest serial chain is what such a call waits for.
-int pick_seg(const DeviceState& d, size_t n, int W) {
-  const size_t adds = n * (size_t)W;
-  const int seg = adds >= ((size_t)1 << 26) ? 32 : adds >= ((size_t)1 << 22) ? 16 : 8;
-  return (int)d.tuned(D377_TUNE_MSM_SEG, seg);               // developer override (sweeps): 1 .. MAX_SEG
+// Points per segment lane.  The segment sums run in GENERATIONS of lanes -- k_msm_segments holds 4 waves per SIMD (128 VGPRs:
+// tests/test_codegen.py), 1 024 lanes per CU -- and a call waits for whole generations: at 2^18 points 16-point segments
+// are 366 000 lanes, two generations of 16 additions, and 32-point segments 194 000 lanes, one generation of 32 -- the
+// same additions, one generation's start-up and drain less (761 -> 741 us).  So: of the candidate lengths the one with the
+// least  generations x (length + ~2 additions of overhead per generation),  with  lanes = buckets x (run length / length +
+// 1/2)  (the last segment of a run is half full on average) against 0.8 of the resident lanes (the run lengths scatter).
+// Measured against fixed lengths, three runs each within 1 % (tools/msm_tune_sweep.py), best fixed length / this rule's:
+// 2^16 8 / 8, 2^17 16 / 16 (582 against 602 us with 8), 2^18 32 / 32, 2^19 48-64 / 64 (1126-1141 against 1188 with 16),
+// 2^20 16 or 48 / 16, 2^21 16 / 32 (1 % apart), 2^22 32-48 / 64 (flat).  The window width decides the buckets, hence `c`.
+constexpr int SEG_BLOCKS_PER_CU = 4;
+int pick_seg(const DeviceState& d, size_t n, int W, int c) {
+  const double buckets = (double)W * (double)((size_t)1 << (c - 1)), run = (double)n * (double)W / buckets;
+  const double cap = 0.8 * (double)d.cus * SEG_BLOCKS_PER_CU * BLOCK;
+  static const int cand[] = {8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+  int best = 8;
+  double best_cost = 0.0;
+  for (int s : cand) {
+    const double lanes = buckets * (run / s + 0.5);
+    double gens = lanes / cap;
+    gens = gens <= 1.0 ? 1.0 : (double)(size_t)(gens + 0.999999);
+    const double cost = gens * (s + 2.0);
+    if (best_cost == 0.0 || cost < best_cost) { best = s; best_cost = cost; }
+  }
+  return (int)d.tuned(D377_TUNE_MSM_SEG, best);              // developer override (sweeps): 1 .. MAX_SEG
 }
 
 int grid_of(const DeviceState& d, size_t n) {
@@ -1229,7 +1245,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_seg = carve((size_t)REDUCE_LEVELS * W * (nb + 1) * 4);
   const int scan_chunks = (nb + 1 + 1023) / 1024;
   const size_t o_tot = carve((size_t)W * scan_chunks * (1 + REDUCE_LEVELS) * 4);
-  const int seg = pick_seg(d, n, W);
+  const int seg = pick_seg(d, n, W, c);
   const size_t max_segs = ((size_t)n * W) / (size_t)seg + (size_t)W * nb;      // sum of ceil(run / seg) never exceeds this
   // the level-1 index array of the sort (W * n words) borrows the segment partials' area, which is free until k_msm_segments
   const size_t par_bytes = max_segs * PT_WORDS * 4, tmp_bytes = (size_t)W * n * 4;
