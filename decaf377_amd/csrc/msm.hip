@@ -1128,11 +1128,12 @@ int pick_window(const DeviceState& d, size_t n) {
 // tests/test_codegen.py), 1 024 lanes per CU -- and a call waits for whole generations: at 2^18 points 16-point segments
 // are 366 000 lanes, two generations of 16 additions, and 32-point segments 194 000 lanes, one generation of 32 -- the
 // same additions, one generation's start-up and drain less (761 -> 741 us).  So: of the candidate lengths the one with the
-// least  generations x (length + ~2 additions of overhead per generation),  with  lanes = buckets x (run length / length +
-// 1/2)  (the last segment of a run is half full on average) against 0.8 of the resident lanes (the run lengths scatter).
-// Measured against fixed lengths, three runs each within 1 % (tools/msm_tune_sweep.py), best fixed length / this rule's:
-// 2^16 8 / 8, 2^17 16 / 16 (582 against 602 us with 8), 2^18 32 / 32, 2^19 48-64 / 64 (1126-1141 against 1188 with 16),
-// 2^20 16 or 48 / 16, 2^21 16 / 32 (1 % apart), 2^22 32-48 / 64 (flat).  The window width decides the buckets, hence `c`.
+// least  generations x (length + ~2 additions of overhead per generation) [+ length / 2 when there are several],  with
+// lanes = buckets x (run length / length + 1/2)  (the last segment of a run is half full on average) against 0.8 of the
+// resident lanes (the run lengths scatter).  A fit to measurements, not a derivation: against fixed lengths, runs within 1 %
+// of each other (tools/msm_tune_sweep.py), best fixed length / this rule's: 2^16 8 / 8, 2^17 16 / 16 (582 against 602 us
+// with 8), 2^18 32 / 32 (741 against 758 with 16), 2^19 32-64 depending on the box / 64, 2^20 16 or 48 / 16, 2^21 16-32 / 24,
+// 2^22 32 / 32.  The window width decides the buckets, hence `c`.
 constexpr int SEG_BLOCKS_PER_CU = 4;
 int pick_seg(const DeviceState& d, size_t n, int W, int c) {
   const double buckets = (double)W * (double)((size_t)1 << (c - 1)), run = (double)n * (double)W / buckets;
@@ -1144,7 +1145,7 @@ int pick_seg(const DeviceState& d, size_t n, int W, int c) {
     const double lanes = buckets * (run / s + 0.5);
     double gens = lanes / cap;
     gens = gens <= 1.0 ? 1.0 : (double)(size_t)(gens + 0.999999);
-    const double cost = gens * (s + 2.0);
+    const double cost = gens * (s + 2.0) + (gens > 1.0 ? 0.5 * s : 0.0);   // (with generations behind it, a long last segment holds its wave's slot)
     if (best_cost == 0.0 || cost < best_cost) { best = s; best_cost = cost; }
   }
   return (int)d.tuned(D377_TUNE_MSM_SEG, best);              // developer override (sweeps): 1 .. MAX_SEG
