@@ -730,7 +730,10 @@ k_msm_fold(const uint32_t* in, int W, int m, int mout, uint32_t* out) {
 // replaces (8 buckets per lane, then a 16-bit double-and-add for the chunk's offset, then five 4-to-1 folds) were ~55
 // dependent group operations, 245 us at every batch size.  k_msm_wsum_block takes 2^m buckets per workgroup through m
 // levels in LDS (points as structure-of-arrays, 36 words each); k_msm_wsum_window merges the block nodes of a window
-// (first level straight from global memory) and finishes with Horner over the c bit-sums, four lanes per point.
+// (first level straight from global memory) and finishes with Horner over the bit-sums, in the lane-spread form.
+// The tree's LEAVES are the buckets 1 .. 2^(c-1), numbered from 0 (bucket 0 is always empty: digit 0 places nothing), so
+// the tree is c - 1 levels deep, a whole number of blocks, and S_w = sum_i (i + 1) L_i = sum_j 2^j V_j + T.  (Numbered
+// by bucket index it was 2^(c-1) + 1 leaves: a level, a Horner step and a block per window for the one top bucket.)
 constexpr int WS_M = 8;                          // at most 2^WS_M buckets per block workgroup
 constexpr int WS_THREADS = 1 << (WS_M - 2);      // one wave: a lane takes FOUR buckets through levels 0 and 1 in registers
 constexpr int LP_WORDS = 4 * NL;
@@ -753,6 +756,17 @@ struct LdsPts {
       base[(2 * NL + i) * cap + p] = g.z.l[i]; base[(3 * NL + i) * cap + p] = g.t.l[i];
     }
   }
+  // one coordinate (0 X, 1 Y, 2 Z, 3 T) of a point: what a lane of a quad holds (quad_ops.hpp)
+  __device__ __forceinline__ fe load_coord(int p, int r) const {
+    fe f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) f.l[i] = base[(r * NL + i) * cap + p];
+    return f;
+  }
+  __device__ __forceinline__ void store_coord(int p, int r, const fe& f) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) base[(r * NL + i) * cap + p] = f.l[i];
+  }
 };
 // one level of merges inside LDS: `cur` holds 2 * merges nodes of (j + 1) points, `nxt` receives merges nodes of (j + 2)
 __device__ __forceinline__ void wsum_level(const LdsPts& cur, LdsPts& nxt, int j, int merges, int t, int nthreads) {
@@ -764,6 +778,30 @@ __device__ __forceinline__ void wsum_level(const LdsPts& cur, LdsPts& nxt, int j
     if (tt == 0) nxt.store(mu * (per + 1) + per, b);          // V_j of the merged node = the right node's total
   }
 }
+// The same level with a QUAD of lanes per addition (quad_ops.hpp: lane r holds coordinate r; ~800 instructions per addition
+// instead of ~1 900 on one lane) for the upper levels, which have fewer additions than the workgroup has quads to spare: a level
+// of up to nthreads / 2 additions takes one or two rounds of quads, 1.5-3.0 us, instead of one round of lanes, 3.7 us.
+// Every lane runs every trip (the DPP exchanges need whole quads); only the stores are predicated.
+__device__ __forceinline__ void wsum_level_quads(const LdsPts& cur, LdsPts& nxt, int j, int merges, int t, int nthreads) {
+  const int per = j + 1, role = t & 3, nq = nthreads >> 2, total = merges * per;
+  for (int l0 = 0; l0 < total; l0 += nq) {
+    const int l = l0 + (t >> 2);
+    const bool live = l < total;
+    const int ll = live ? l : 0;
+    const int mu = ll / per, tt = ll - mu * per;
+    const int pa = (2 * mu) * per + tt, pb = (2 * mu + 1) * per + tt;
+    const fe a = cur.load_coord(pa, role), b = cur.load_coord(pb, role);
+    const fe r = gq_add_with(a, gq_cached_slot(b, role), role, false);
+    if (live) {
+      nxt.store_coord(mu * (per + 1) + tt, role, r);
+      if (tt == 0) nxt.store_coord(mu * (per + 1) + per, role, b);   // V_j of the merged node = the right node's total
+    }
+  }
+}
+__device__ __forceinline__ void wsum_level_any(const LdsPts& cur, LdsPts& nxt, int j, int merges, int t, int nthreads) {
+  if (2 * merges * (j + 1) <= nthreads) wsum_level_quads(cur, nxt, j, merges, t, nthreads);
+  else wsum_level(cur, nxt, j, merges, t, nthreads);
+}
 // One wave per workgroup and four buckets per lane: 18 windows x 33 blocks = 594 waves at c = 14, fewer than the chip has
 // SIMDs, so every wave runs alone on its SIMD (with two buckets per lane there were 1170 waves on 1024 SIMDs and the
 // kernel took as long as the SIMDs that got two: 100-130 us against 47 us for the same depth at c = 7).
@@ -774,8 +812,8 @@ k_msm_wsum_block(const uint32_t* buckets, int nb, int m, int nblk, uint32_t* nod
   const int w = blockIdx.x / nblk, blk = blockIdx.x % nblk, t = threadIdx.x;
   LdsPts A{lds, WSA_CAP0}, B{lds + WSA_CAP0 * LP_WORDS, WSA_CAP1};
   const int M1 = 1 << (m - 2);                                 // nodes after level 1 (m >= 2)
-  if (t < M1) {                                                // buckets 4t .. 4t + 3: T = B0 + B1 + B2 + B3, V_0 = B1 + B3, V_1 = B2 + B3
-    const int b0 = (blk << m) + 4 * t;
+  if (t < M1) {                                                // leaves 4t .. 4t + 3: T = B0 + B1 + B2 + B3, V_0 = B1 + B3, V_1 = B2 + B3
+    const int b0 = (blk << m) + 4 * t + 1;                     // leaf i is bucket i + 1 (bucket 0 holds nothing: digit 0 is skipped)
     const uint32_t* src = buckets + ((size_t)w * nb + b0) * PT_WORDS;
     const ge p0 = b0 < nb ? pt_load_ext(src) : ge_identity();
     const ge p1 = b0 + 1 < nb ? pt_load_ext(src + PT_WORDS) : ge_identity();
@@ -790,7 +828,38 @@ k_msm_wsum_block(const uint32_t* buckets, int nb, int m, int nblk, uint32_t* nod
   LdsPts cur = A, nxt = B;
 #pragma unroll 1
   for (int j = 2; j < m; ++j) {
-    wsum_level(cur, nxt, j, M1 >> (j - 1), t, WS_THREADS);
+    wsum_level_any(cur, nxt, j, M1 >> (j - 1), t, WS_THREADS);
+    __syncthreads();
+    const LdsPts tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (t <= m) pt_store_ext(nodes + (((size_t)w * nblk + blk) * (WS_M + 1) + t) * PT_WORDS, cur.load(t));
+}
+
+// The same with TWO waves per workgroup and two buckets per lane, for launches that leave every wave a SIMD of its own even so
+// (2 x windows x blocks <= the chip's SIMDs: the 12-bit windows of batches below 2^20 points): levels 0 .. 2, which have
+// 96-128 additions each, take one round of the lanes instead of two -- 8 dependent additions per lane instead of 11.
+constexpr int WS2_THREADS = 1 << (WS_M - 1);
+constexpr int WS2_CAP0 = 1 << WS_M, WS2_CAP1 = 3 << (WS_M - 2);            // points after level 0 (256) and level 1 (192)
+static_assert((WS2_CAP0 + WS2_CAP1) * LP_WORDS * 4 <= 65536, "k_msm_wsum_block2's two point buffers fill the static LDS");
+__global__ void __launch_bounds__(WS2_THREADS)
+k_msm_wsum_block2(const uint32_t* buckets, int nb, int m, int nblk, uint32_t* nodes) {
+  __shared__ uint32_t lds[(WS2_CAP0 + WS2_CAP1) * LP_WORDS];
+  const int w = blockIdx.x / nblk, blk = blockIdx.x % nblk, t = threadIdx.x;
+  LdsPts A{lds, WS2_CAP0}, B{lds + WS2_CAP0 * LP_WORDS, WS2_CAP1};
+  const int M0 = 1 << (m - 1);                                 // nodes after level 0 (m >= 2)
+  if (t < M0) {                                                // leaves 2t, 2t + 1: T = B0 + B1, V_0 = B1
+    const int b0 = (blk << m) + 2 * t + 1;                     // leaf i is bucket i + 1
+    const uint32_t* src = buckets + ((size_t)w * nb + b0) * PT_WORDS;
+    const ge p0 = b0 < nb ? pt_load_ext(src) : ge_identity();
+    const ge p1 = b0 + 1 < nb ? pt_load_ext(src + PT_WORDS) : ge_identity();
+    A.store(2 * t, ge_add(p0, p1));
+    A.store(2 * t + 1, p1);
+  }
+  __syncthreads();
+  LdsPts cur = A, nxt = B;
+#pragma unroll 1
+  for (int j = 1; j < m; ++j) {
+    wsum_level_any(cur, nxt, j, M0 >> j, t, WS2_THREADS);
     __syncthreads();
     const LdsPts tmp = cur; cur = nxt; nxt = tmp;
   }
@@ -803,6 +872,7 @@ constexpr int WSB_THREADS = 512;
 constexpr int WSB_CAP0 = 32 * (WS_M + 2), WSB_CAP1 = 16 * (WS_M + 3);   // points after the first / second level at c = 14 (320, 176)
 __global__ void __launch_bounds__(WSB_THREADS)
 k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, uint32_t* sums) {
+  // c here: the DEPTH of the window's tree, log2 of its leaves (the window width less one: see the leaves' numbering above)
   __shared__ uint32_t lds[(WSB_CAP0 + WSB_CAP1) * LP_WORDS];
   const int w = blockIdx.x, t = threadIdx.x;
   LdsPts X{lds, WSB_CAP0}, Y{lds + WSB_CAP0 * LP_WORDS, WSB_CAP1};
@@ -811,7 +881,7 @@ k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, uint32_t* sums)
   if (c == m) {                                                // the block node is the window's node
     if (t <= m) X.store(t, pt_load_ext(wn + (size_t)t * PT_WORDS));
   } else {
-    const int per = m + 1, merges = 1 << (c - m - 1);         // level m, operands in global memory; nodes beyond nblk are empty
+    const int per = m + 1, merges = 1 << (c - m - 1);         // level m, operands in global memory
     for (int l = t; l < merges * per; l += WSB_THREADS) {
       const int mu = l / per, tt = l - mu * per;
       const ge a = 2 * mu < nblk ? pt_load_ext(wn + ((size_t)(2 * mu) * (WS_M + 1) + tt) * PT_WORDS) : ge_identity();
@@ -823,16 +893,17 @@ k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, uint32_t* sums)
   __syncthreads();
 #pragma unroll 1
   for (int j = m + 1; j < c; ++j) {
-    wsum_level(cur, nxt, j, 1 << (c - j - 1), t, WSB_THREADS);
+    wsum_level_any(cur, nxt, j, 1 << (c - j - 1), t, WSB_THREADS);
     __syncthreads();
     const LdsPts tmp = cur; cur = nxt; nxt = tmp;
   }
-  // Horner over the bit-sums: S = V_(c-1); S = 2 S + V_j -- one dependency chain per window, so it runs in the
-  // lane-spread form (row_ops.hpp: the point across the four rows of ONE wave).  The cached forms of the bit-sums
-  // first, one lane each, as row records in the buffer that is free now; then wave 0 runs the chain.
+  // sum_i (i + 1) L_i = sum_j 2^j V_j + T.  Horner over the bit-sums: S = V_(c-1); S = 2 S + V_j; then + T -- one dependency
+  // chain per window, so it runs in the lane-spread form (row_ops.hpp: the point across the four rows of ONE wave).  The
+  // cached forms of the addends first, one lane each, as row records in the buffer that is free now; then wave 0 runs the chain.
   uint32_t* crec = nxt.base;                                   // c + 1 records of RQ_WORDS words (<= the smaller buffer)
   if (t < c - 1) rq_store_cached(crec + t * RQ_WORDS, cur.load(1 + t));   // point 1 + j of the node is V_j
   if (t == c - 1) rq_store_point(crec + (c - 1) * RQ_WORDS, cur.load(c)); // the top bit-sum: where the chain starts
+  if (t == c) rq_store_cached(crec + c * RQ_WORDS, cur.load(0));          // point 0 is the total T
   __syncthreads();
   if (t >= 64) return;
   const row::RowK K = row::row_consts();
@@ -845,6 +916,7 @@ k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, uint32_t* sums)
     negated = !negated;
     v = row::rq_add(v, crec + j * RQ_WORDS, S, negated, K);   // -2S - V_j, or 2S + V_j
   }
+  v = row::rq_add(v, crec + c * RQ_WORDS, S, negated, K);     // -S - T, or S + T
   __shared__ uint32_t xrec[RQ_WORDS];
   xrec[t] = v;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // wave 0 alone is left (the others have returned): its own
@@ -1276,8 +1348,10 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   // weighted bucket sums by the pairwise tree (c <= 14: every width pick_window chooses); wider windows -- developer
   // override only -- keep the chunked running sums
   const bool tree = c <= 14 && d.tuned(D377_TUNE_MSM_CHUNKED_SUMS, 0) == 0;
-  const int ws_m = c < WS_M ? c : WS_M;                      // >= 2: window widths start at 2
-  const int ws_nblk = (nb + (1 << ws_m) - 1) >> ws_m;
+  // the tree's leaves are buckets 1 .. 2^(c-1) (bucket 0 is empty): depth c - 1, a whole number of blocks
+  const int ws_depth = c - 1;
+  const int ws_m = ws_depth < WS_M ? ws_depth : WS_M;        // >= 2: window widths start at 4 here
+  const int ws_nblk = 1 << (ws_depth - ws_m);
   const size_t o_nodes = carve(tree ? (size_t)W * ws_nblk * (WS_M + 1) * PT_WORDS * 4 : 0);
   const size_t o_sums = carve((size_t)W * PT_WORDS * 4);
   int rc;
@@ -1364,8 +1438,11 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const uint32_t* cur_in;
   if (tree) {
     uint32_t *nodes = (uint32_t*)(m + o_nodes), *sums = (uint32_t*)(m + o_sums);
-    hipLaunchKernelGGL(k_msm_wsum_block, dim3(W * ws_nblk), dim3(WS_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
-    hipLaunchKernelGGL(k_msm_wsum_window, dim3(W), dim3(WSB_THREADS), 0, s, nodes, c, ws_m, ws_nblk, sums);
+    if ((size_t)2 * W * ws_nblk <= (size_t)d.cus * 4)          // two waves per block still leave every wave its own SIMD
+      hipLaunchKernelGGL(k_msm_wsum_block2, dim3(W * ws_nblk), dim3(WS2_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
+    else
+      hipLaunchKernelGGL(k_msm_wsum_block, dim3(W * ws_nblk), dim3(WS_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
+    hipLaunchKernelGGL(k_msm_wsum_window, dim3(W), dim3(WSB_THREADS), 0, s, nodes, ws_depth, ws_m, ws_nblk, sums);
     cur_in = sums;
   } else {
     hipLaunchKernelGGL(k_msm_chunks, dim3(grid_of(d, (size_t)W * nchunks)), dim3(BLOCK), 0, s, bkt, W, nb, nchunks, ch);
