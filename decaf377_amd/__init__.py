@@ -4,7 +4,7 @@ Host-side mirror of the reference crate's public hot-path API (penumbra-zone/dec
 `Encoding`, `Element`, `Fq`, `Fr`, `EncodingError`) as batch operations over packed
 32-byte records, backed by hand-written gfx950 kernels behind a C ABI
 (include/decaf377_amd.h).  See DESIGN.md."""
-from ._native import LIB_PATH, NativeError, load  # noqa: F401
+from ._native import LIB_PATH, NativeError, StarvedError, load  # noqa: F401
 from .engine import (  # noqa: F401
     Context,
     Element,
@@ -16,4 +16,4 @@ from .engine import (  # noqa: F401
 )
 
 __all__ = ["Context", "Element", "Encoding", "EncodingError", "Fq", "Fr", "default_context",
-           "NativeError", "load", "LIB_PATH"]
+           "NativeError", "StarvedError", "load", "LIB_PATH"]

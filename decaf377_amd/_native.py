@@ -37,7 +37,7 @@ EXPORTS = [
     "d377_batch_encode_to_curve_element_dev", "d377_batch_hash_to_curve_element_dev",
     "d377_batch_fr_op", "d377_batch_fr_op_dev", "d377_batch_fr_from_wide_bytes", "d377_batch_fr_from_wide_bytes_dev",
     "d377_batch_fq_from_bytes_checked_dev", "d377_batch_fq_to_bytes_dev", "d377_batch_fr_from_le_bytes_mod_order_dev",
-    "d377_batch_fr_from_bytes_checked_dev",
+    "d377_batch_fr_from_bytes_checked_dev", "d377_ctx_starved_counter_dev",
 ]
 
 _lib = None
@@ -45,6 +45,14 @@ _lib = None
 
 class NativeError(RuntimeError):
     pass
+
+
+class StarvedError(NativeError):
+    """D377_ERR_STARVED: workgroups of the call found no free lane set for 10 s and wrote no output (the call's
+    outputs are invalid; Context.health / Context.reset_scratch)."""
+
+
+ERR_STARVED = -5
 
 
 def load():
@@ -86,6 +94,8 @@ def load():
     lib.d377_ctx_reset_scratch.restype = i32
     lib.d377_debug_poison_pool.argtypes = [vp, i32, i32]
     lib.d377_debug_poison_pool.restype = i32
+    lib.d377_ctx_starved_counter_dev.argtypes = [vp, i32, ctypes.POINTER(vp)]
+    lib.d377_ctx_starved_counter_dev.restype = i32
     lib.d377_ctx_set_tuning.argtypes = [vp, i32, ctypes.c_int64]
     lib.d377_ctx_set_tuning.restype = i32
     lib.d377_ctx_get_tuning.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int64)]
@@ -168,4 +178,4 @@ def load():
 
 def check(rc):
     if rc != 0:
-        raise NativeError("decaf377_amd native call failed (%d): %s" % (rc, load().d377_last_error().decode()))
+        raise (StarvedError if rc == ERR_STARVED else NativeError)("decaf377_amd native call failed (%d): %s" % (rc, load().d377_last_error().decode()))

@@ -1048,19 +1048,24 @@ D377_HD void fr_recode_signed256(const uint32_t k[8], int digits[32]) {
 }
 
 // [k]B from the shared table FB[i][j] = affine cached j * 2^(FB_BITS i) * B (i < FB_WINDOWS, j <= 2^(FB_BITS-1)):
-// FB_WINDOWS mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.  FB_BITS must divide the 252
-// significant scalar bits evenly so that the top digit needs no carry-out: 18 (14 windows x 131073 entries, 264 MB in
-// HBM), 14 (18 x 8193, 21 MB, resident in the Infinity Cache), 12 (21 x 2049, 6.2 MB) or, as at first, 8 with
-// FB_WINDOWS = 32 (594 KB).  With the square root gone the additions are the element, so the width pays: measured at
+// FB_WINDOWS mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.  FB_BITS: 18 (14 windows x 131073 entries, 235 MB in
+// HBM), 16 (16 x 32769, 67 MB: inside the Infinity Cache), 14 (18 x 8193, 19 MB), 12 (21 x 2049, 5.5 MB) or, as at
+// first, 8 with FB_WINDOWS = 32 (528 KB); the static_asserts below say what a width has to satisfy.  With the square root gone the additions are the element, so the width pays: measured at
 // 2^20 scalars, 7.8e8/s with 12 bits, 8.6e8/s with 14 (same build), and 9.7e8 -> 11.2e8/s from 14 to 18 (the gathers of
 // 144-byte entries from HBM hide behind the previous addition).  The host simulation builds its tables with 12 or 8.
 #ifndef D377_FB_BITS
 #define D377_FB_BITS 18
 #endif
 constexpr int FB_BITS = D377_FB_BITS;
-constexpr int FB_WINDOWS = (FB_BITS == 8) ? 32 : 252 / FB_BITS;
+constexpr int FB_WINDOWS = (252 + FB_BITS - 1) / FB_BITS;
 constexpr int FB_ENTRIES = (1 << (FB_BITS - 1)) + 1;
-static_assert(FB_BITS == 8 || 252 % FB_BITS == 0, "window width must tile the 252 scalar bits");
+// The top digit must take the recoding's carry without one of its own.  Scalars are < r and r >> 228 = 0x4aad95, so the
+// top window's value is at most R_TOP >> (its first bit - 228); that + 1 has to stay below 2^(FB_BITS - 1).  True for
+// the widths that tile the 252 bits (18, 14, 12) and for ragged tops (8: 32 windows; 16: 16 windows, 11 bits in the last).
+constexpr unsigned long long FB_R_TOP = 0x4aad95ull;                        // r >> 228
+constexpr int FB_TOP_BIT = FB_BITS * (FB_WINDOWS - 1);
+static_assert(FB_BITS >= 4 && FB_BITS <= 21 && FB_TOP_BIT >= 228 && FB_BITS * FB_WINDOWS >= 252, "comb width");
+static_assert((FB_R_TOP >> (FB_TOP_BIT - 228)) + 1 < (1ull << (FB_BITS - 1)), "the top digit of a scalar below r must not carry out");
 // signed digit i of k (FB_BITS wide), with the running carry of the recoding
 D377_HD int fb_digit(const uint32_t k[8], int i, uint32_t& carry) {
   const int bit = FB_BITS * i, wi = bit >> 5, sh = bit & 31;

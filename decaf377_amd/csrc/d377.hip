@@ -1191,6 +1191,7 @@ __global__ void k_pool_release(int* pool, const int* idx, const int* ticket, int
   if (i < m) atomicCAS(&pool[idx[i]], ticket[i], 0);
 }
 constexpr int RESET_WAIT_MS = 1500;
+constexpr int RESET_MIN_MS = 250;        // between the two reads of the pool: many chunks of any kernel (the longest, 8 variable-base elements per lane, is ~15 ms)
 
 // ------------------------------------------------------------------------------ host side ---
 }  // namespace
@@ -1333,6 +1334,8 @@ int init_device(DeviceState& d) {
   HIP_TRY(hipMemsetAsync(d.slot_pool, 0, (size_t)d.dcb_sets * sizeof(int), d.stream));      // every set free; workgroups free what they claim
   HIP_TRY(hipMalloc(&d.pool_health, 4 * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(d.pool_health, 0, 4 * sizeof(uint32_t), d.stream));
+  HIP_TRY(hipHostMalloc(&d.starve_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
+  d.starve_host[0] = d.starve_host[1] = 0;
   if ((rc = check_residency(d))) return rc;
   uint32_t* keys = nullptr;
   int* coll = nullptr;
@@ -1352,6 +1355,8 @@ void free_device(DeviceState& d) {
   (void)d.vb_guard.drain();
   (void)d.msm.guard.drain();
   (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.pool_health); (void)hipFree(d.inv_fail);
+  if (d.starve_host) (void)hipHostFree(d.starve_host);
+  d.starve_host = nullptr;
   for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); (void)hipFree(d.shard[i]); }
   for (int i = 0; i < 2; ++i) {
     if (d.ev_in[i]) (void)hipEventDestroy(d.ev_in[i]);
@@ -1693,6 +1698,8 @@ int run_one_pipelined(DeviceState& d, Op op, int aux, const OpShape& sh, const v
     if ((r = ensure2(d, 2, PIPE_CHUNK * sh.out0))) return r;
     if (sh.out1 && (r = ensure2(d, 3, PIPE_CHUNK * sh.out1))) return r;
     const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+    StarveCheck starve{d, d.stream};
+    if ((r = starve.before())) return r;
     auto bufs = [&](size_t k) -> uint8_t** { return (k & 1) ? d.buf2 : d.buf; };
     auto drain = [&](size_t k) -> int {          // outputs of chunk k -> host (waits for its kernel)
       const size_t lo = k * PIPE_CHUNK, cnt = (lo + PIPE_CHUNK <= n) ? PIPE_CHUNK : n - lo;
@@ -1717,9 +1724,10 @@ int run_one_pipelined(DeviceState& d, Op op, int aux, const OpShape& sh, const v
       HIP_TRY(hipEventRecord(d.ev_done[k & 1], d.stream));
       if (k >= 1 && (r = drain(k - 1))) return r;
     }
+    if ((r = starve.after())) return r;
     if ((r = drain(nchunks - 1))) return r;
     HIP_TRY(hipStreamSynchronize(d.stream));
-    return D377_OK;
+    return starve.verdict();
   };
   rc = body();
   return rc;
@@ -1739,13 +1747,16 @@ int run_one(DeviceState& d, Op op, int aux, const OpShape& sh, const void* in0, 
     if (sh.in1 && (r = ensure(d, 1, n * sh.in1))) return r;
     if ((r = ensure(d, 2, n * sh.out0))) return r;
     if (sh.out1 && (r = ensure(d, 3, n * sh.out1))) return r;
+    StarveCheck starve{d, d.stream};
+    if ((r = starve.before())) return r;
     HIP_TRY(hipMemcpyAsync(d.buf[0], in0, n * sh.in0, hipMemcpyHostToDevice, d.stream));
     if (sh.in1) HIP_TRY(hipMemcpyAsync(d.buf[1], in1, n * sh.in1, hipMemcpyHostToDevice, d.stream));
     if ((r = launch(d, d.stream, op, aux, d.buf[0], d.buf[1], n, d.buf[2], d.buf[3]))) return r;
     HIP_TRY(hipMemcpyAsync(out0, d.buf[2], n * sh.out0, hipMemcpyDeviceToHost, d.stream));
     if (sh.out1) HIP_TRY(hipMemcpyAsync(out1, d.buf[3], n * sh.out1, hipMemcpyDeviceToHost, d.stream));
+    if ((r = starve.after())) return r;
     HIP_TRY(hipStreamSynchronize(d.stream));
-    return D377_OK;
+    return starve.verdict();
   };
   rc = body();
   return rc;
@@ -1968,8 +1979,12 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count) {
 static bool tuning_range(int key, long long* lo, long long* hi) {
   const long long big = (long long)1 << 62;
   switch (key) {
-    case D377_TUNE_SMALL_MAX: case D377_TUNE_MSM_SMALL_MAX: case D377_TUNE_DECOMPRESS_CHUNKED_MIN: case D377_TUNE_MSM_TINY_MAX:
-    case D377_TUNE_TINY_MAX:
+    // routes with a wave or a quad of lanes per element: their grids are n or n / 16 workgroups, and 4 x TINY_MAX is
+    // computed in 64 bits -- 2^24 elements keeps both far inside a grid dimension (and is 2^10 times where they stop paying)
+    case D377_TUNE_SMALL_MAX: case D377_TUNE_MSM_SMALL_MAX: case D377_TUNE_MSM_TINY_MAX:
+    case D377_TUNE_TINY_MAX: *lo = 0; *hi = (long long)1 << 24; return true;
+    // thresholds FROM which a route is taken: a huge value means never
+    case D377_TUNE_DECOMPRESS_CHUNKED_MIN:
     case D377_TUNE_MSM_ENC_CHUNKED_MIN: *lo = 0; *hi = big; return true;
     case D377_TUNE_FB_WIDE: case D377_TUNE_MSM_CHUNKED_SUMS: *lo = 0; *hi = 1; return true;
     case D377_TUNE_FB_K: *lo = 1; *hi = DCB_KMAX; return true;
@@ -2025,6 +2040,12 @@ int d377_ctx_health(d377_ctx* ctx, int dev, int* sets_claimed, uint64_t* waited_
   if (gave_up) *gave_up = h[2];
   return D377_OK;
 }
+int d377_ctx_starved_counter_dev(d377_ctx* ctx, int dev, const uint32_t** counter_dev) {
+  if (!ctx || !counter_dev) return fail(D377_ERR_ARG, "%s", "null argument");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  *counter_dev = ctx->devs[(size_t)dev].pool_health + 2;
+  return D377_OK;
+}
 // Is anything this context enqueued (or was handed a stream for) still running on the device?
 static bool device_busy(DeviceState& d) {
   if (hipStreamQuery(d.stream) == hipErrorNotReady) return true;
@@ -2052,16 +2073,19 @@ int d377_ctx_reset_scratch(d377_ctx* ctx, int dev, int* sets_released) {
   uint32_t h[4];
   int rc;
   if ((rc = read_pool(d, before, h))) return rc;
-  // 1. The normal case: whatever is in flight finishes (a chunk is milliseconds of work), and then no workgroup holds
-  //    anything: every claim still in the pool is a leak.
+  // Whatever is in flight gets time to finish or to move on: a workgroup draws a new ticket for every chunk it starts
+  // (dcb.hpp: dcb_rounds), so over RESET_MIN_MS -- many chunks -- the word of every set that is in use changes, whether
+  // its launch is one this context can see or a replayed hipGraph, and however long the launch is.  A ticket that
+  // stood still between the two reads belongs to no running workgroup: a leak.  Those (and only those) are freed, by
+  // compare-and-swap against the ticket, on the copy stream beside whatever waits for them.
+  const auto t0 = std::chrono::steady_clock::now();
   const bool idle = wait_idle(d, RESET_WAIT_MS);
+  const auto waited = std::chrono::steady_clock::now() - t0;
+  if (waited < std::chrono::milliseconds(RESET_MIN_MS)) std::this_thread::sleep_for(std::chrono::milliseconds(RESET_MIN_MS) - waited);
   if ((rc = read_pool(d, after, h))) return rc;
-  // 2. Work that does not finish is waiting for sets that never come back.  A set whose ticket did not change over
-  //    the whole wait has been held by one workgroup for longer than any chunk runs: a leak as well.  Those (and only
-  //    those) are freed, by compare-and-swap against the ticket, on the copy stream beside the waiting kernels.
   std::vector<int> idx, val;
   for (size_t i = 0; i < after.size(); ++i)
-    if (after[i] != 0 && (idle || after[i] == before[i])) { idx.push_back((int)i); val.push_back(after[i]); }
+    if (after[i] != 0 && after[i] == before[i]) { idx.push_back((int)i); val.push_back(after[i]); }
   if (!idx.empty()) {
     int *d_idx = nullptr, *d_val = nullptr;
     HIP_TRY(hipMalloc(&d_idx, idx.size() * sizeof(int)));

@@ -41,7 +41,10 @@ static_assert(DCB_K <= DCB_KMAX && FB_K <= DCB_KMAX, "the scratch layout has DCB
 // workgroup has held for seconds -- leaked by a launch that died -- from sets that change hands (d377_ctx_reset_scratch).
 // A workgroup that finds no free set for DCB_STUCK_TICKS counts itself in health[1] and keeps waiting; after
 // DCB_GIVE_UP_TICKS it counts itself in health[2] and leaves without touching its elements, so that no launch spins
-// forever on a pool whose sets were leaked (d377_ctx_health reports both; outputs of such a launch are unwritten).
+// forever on a pool whose sets were leaked.  Outputs of such a launch are unwritten, and the call FAILS: the
+// host-pointer entry points read health[2] on their stream before and after their kernels and return
+// D377_ERR_STARVED when it moved (d377.hip: StarveCheck); a `_dev` caller does the same with the counter's device
+// address (d377_ctx_starved_counter_dev) or asks d377_ctx_health.
 struct DcbScratch {
   uint8_t* rec;        // [DCB_SLOTS][DCB_KMAX][lanes] 32-byte records, lanes = all the lane sets of the device x BLOCK
   int* pool;           // one word per lane set, 0 = free, else the holder's ticket (cleared at context creation; every workgroup frees what it claimed)
@@ -58,6 +61,8 @@ struct DcbIO {
   uint8_t* out32;
   size_t nlanes, lane, base;            // lane of the claimed set; the chunk's j-th element of this lane is record base + j * BLOCK
   int slot, per_lane, extra;
+  int* claim;                           // this workgroup's word of the pool (holds its ticket)
+  uint32_t* tickets;                    // the ticket counter (health[0])
   __device__ __forceinline__ size_t rec(int sl, int j) const { return (size_t)(sl * DCB_KMAX + j) * nlanes + lane; }
   __device__ __forceinline__ void put(int sl, int j, const uint32_t w[8]) { store32(scratch, rec(sl, j), w); }
   __device__ __forceinline__ void get(int sl, int j, uint32_t w[8]) const { load32(scratch, rec(sl, j), w); }
@@ -133,6 +138,10 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
   for (unsigned chunk = blockIdx.x; first < n;
        chunk += gridDim.x, per_lane = io.per_lane, first = ((size_t)chunk * (unsigned)io.per_lane + (unsigned)io.extra) * BLOCK) {
     io.base = first + threadIdx.x;
+    // A workgroup that walks several chunks draws a new ticket for each: the word in the pool then changes as long as its
+    // holder makes progress, however long the launch (d377_ctx_reset_scratch frees only sets whose ticket stood still).
+    if (chunk != blockIdx.x && threadIdx.x == 0)
+      atomicExch(io.claim, (int)(atomicAdd(io.tickets, 1u) & 0x7FFFFFFFu) + 1);
 #endif
     int cnt = 0;
 #pragma unroll 1
@@ -162,7 +171,8 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
   const int dcb_slot_ = dcb_claim(dcb);                                                           \
   if (dcb_slot_ < 0) return;                      /* no set for DCB_GIVE_UP_TICKS: counted in health[2] */ \
   DcbIO io{dcb.rec, reinterpret_cast<uint8_t*>(out_ptr), (size_t)dcb.lanes,                      \
-           (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_, dcb.per_lane, dcb.extra}
+           (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_, dcb.per_lane, dcb.extra,       \
+           dcb.pool + dcb_slot_, dcb.health}
 #define D377_DCB_END() dcb_release(dcb, dcb_slot_)
 
 }  // namespace d377

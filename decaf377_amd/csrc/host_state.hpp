@@ -110,6 +110,7 @@ struct DeviceState {
   uint8_t* dcb_scratch = nullptr;        // round records of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish)
   int* slot_pool = nullptr;              // which of the lane sets of the scratch areas are claimed, and by which ticket (dcb.hpp, DcbScratch)
   uint32_t* pool_health = nullptr;       // ticket counter, workgroups that waited long for a set, workgroups that gave up (dcb.hpp)
+  uint32_t* starve_host = nullptr;       // pinned: the gave-up counter before / after a host-pointer call's kernels (StarveCheck)
   int vb_blocks = 0;
   uint32_t* inv_fail = nullptr;          // device counter of the -DD377_CHECK_INVARIANTS build (always allocated)
   ScratchGuard vb_guard;
@@ -165,6 +166,25 @@ struct SyncOnError {
     if (a) (void)hipStreamSynchronize(a);
     if (b) (void)hipStreamSynchronize(b);
     memcpy(d377_g_err, saved, sizeof saved);
+  }
+};
+
+// A host-pointer call must not return D377_OK with records a starved workgroup never wrote (dcb.hpp: after
+// DCB_GIVE_UP_TICKS without a lane set a workgroup counts itself in health[2] and leaves).  The call copies the counter
+// to pinned memory on its stream before its first kernel and after its last; the call's own final synchronisation
+// covers both copies, and verdict() turns a counter that moved into D377_ERR_STARVED.  (A `_dev` launch of another
+// stream that starves during the call fails it too: the device's scratch pool is unhealthy either way.)
+struct StarveCheck {
+  DeviceState& d;
+  hipStream_t s;
+  int before() { HIP_TRY(hipMemcpyAsync(&d.starve_host[0], d.pool_health + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); return D377_OK; }
+  int after() { HIP_TRY(hipMemcpyAsync(&d.starve_host[1], d.pool_health + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s)); return D377_OK; }
+  int verdict() const {                                     // after the stream has been synchronised
+    if (d.starve_host[1] == d.starve_host[0]) return D377_OK;
+    snprintf(d377_g_err, sizeof d377_g_err,
+             "%u workgroup(s) found no free lane set for 10 s and left their output records unwritten (device %d): "
+             "d377_ctx_health / d377_ctx_reset_scratch", d.starve_host[1] - d.starve_host[0], d.id);
+    return D377_ERR_STARVED;
   }
 };
 

@@ -1478,6 +1478,8 @@ int msm_one(DeviceState& d, bool encoded, const uint8_t* pts_in, const uint8_t* 
     if ((r = ensure(d, 1, cnt * 32 + 16))) return r;
     if ((r = ensure(d, 2, 32 + 128))) return r;
     if ((r = ensure(d, 3, cnt + 16))) return r;
+    StarveCheck starve{d, d.stream};
+    if ((r = starve.before())) return r;
     if (cnt) {
       HIP_TRY(hipMemcpyAsync(d.buf[0], pts_in, cnt * rec, hipMemcpyHostToDevice, d.stream));
       HIP_TRY(hipMemcpyAsync(d.buf[1], scalars, cnt * 32, hipMemcpyHostToDevice, d.stream));
@@ -1486,8 +1488,9 @@ int msm_one(DeviceState& d, bool encoded, const uint8_t* pts_in, const uint8_t* 
     HIP_TRY(hipMemcpyAsync(partial_out, d.buf[2] + 32, 128, hipMemcpyDeviceToHost, d.stream));
     if (encoded && cnt) HIP_TRY(hipMemcpyAsync(status, d.buf[3], cnt, hipMemcpyDeviceToHost, d.stream));
     if (enc_out) HIP_TRY(hipMemcpyAsync(enc_out, d.buf[2], 32, hipMemcpyDeviceToHost, d.stream));
+    if ((r = starve.after())) return r;
     HIP_TRY(hipStreamSynchronize(d.stream));
-    return D377_OK;
+    return starve.verdict();
   };
   rc = body();
   return rc;

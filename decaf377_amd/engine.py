@@ -116,6 +116,18 @@ class Context:
         _native.check(self._lib.d377_ctx_reset_scratch(self._h, dev, ctypes.byref(a)))
         return int(a.value)
 
+    def starved_counter(self, dev=0):
+        """The gave-up counter as a 1-element uint32 CUDA tensor that aliases the library's word
+        (d377_ctx_starved_counter_dev): a `_dev` caller copies it on its stream before and after a call and compares
+        once the stream has been synchronised -- a call whose kernels starved has left output records unwritten."""
+        import torch
+        p = ctypes.c_void_p()
+        _native.check(self._lib.d377_ctx_starved_counter_dev(self._h, dev, ctypes.byref(p)))
+
+        class _Word:
+            __cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (int(p.value), True), "version": 2}
+        return torch.as_tensor(_Word(), device=torch.device("cuda", self.device_ids[dev]))
+
     def _debug_poison_pool(self, dev=0, sets=-1):
         _native.check(self._lib.d377_debug_poison_pool(self._h, dev, sets))
 

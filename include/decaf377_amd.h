@@ -67,6 +67,8 @@ extern "C" {
 #define D377_ERR_ARG (-2)        /* null / misaligned pointer, bad device index */
 #define D377_ERR_NO_DEVICE (-3)  /* no usable gfx950 device */
 #define D377_ERR_INIT (-4)       /* device table self-check failed at context creation */
+#define D377_ERR_STARVED (-5)    /* workgroups of this call found no free lane set for 10 s and wrote no output: the
+                                    output buffers are NOT valid (d377_ctx_health, d377_ctx_reset_scratch below) */
 
 typedef struct d377_ctx d377_ctx;
 
@@ -99,15 +101,26 @@ int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int
  * areas and frees it when it is done; a launch that dies mid-kernel (a fault in another kernel of the process, a killed
  * graph) would leave its sets claimed for the life of the context.  Later launches then wait: a workgroup that finds
  * no free set for 0.25 s is counted in *waited_long and keeps waiting; after 10 s it is counted in *gave_up and leaves
- * WITHOUT writing its output records (so no launch can spin forever; a nonzero gave_up means outputs are missing).
+ * WITHOUT writing its output records (so no launch can spin forever).  That is never a silent wrong answer -- the
+ * reference's fallible operations always return a Result (src/ark_curve/encoding.rs:34-60):
+ *   - every host-pointer entry point (d377_batch_*, d377_msm[_encoded]) reads the gave-up counter on its stream before
+ *     its first and after its last kernel and returns D377_ERR_STARVED when it moved; the output buffers are then invalid;
+ *   - a `_dev` call only enqueues, so its caller checks: d377_ctx_starved_counter_dev gives the DEVICE address of the
+ *     32-bit counter (valid for the life of the context, only ever incremented); copy it on the call's stream before and
+ *     after the call (two 4-byte copies, no synchronisation of their own) and compare once the stream has been
+ *     synchronised, or call d377_ctx_health afterwards.  Either check is MANDATORY after any `_dev` call that took
+ *     longer than 10 s before its outputs are trusted; a call that finishes sooner cannot have starved.
  * d377_ctx_health reports the sets claimed right now (0 on an idle device) and both counters since the context was created; it
- * does not wait for running kernels.  d377_ctx_reset_scratch frees leaked sets: it waits (up to 1.5 s) for the work this
- * context knows of, and frees every set still claimed then; if work is still running after the wait -- launches
- * starved by the leak -- it frees exactly the sets whose holder did not change during the wait (no chunk runs that
- * long) and waits for that work to finish.  *sets_released (may be NULL) = how many it freed; 0 on a healthy context.
- * d377_debug_poison_pool marks `sets` sets (< 0: all) as claimed by nobody: the test hook for the two calls above. */
+ * does not wait for running kernels.  d377_ctx_reset_scratch frees leaked sets: it reads the pool, waits for the work
+ * this context knows of (at least 0.25 s, at most 1.5 s), reads it again and frees exactly the sets whose ticket did
+ * not change in between -- a workgroup draws a new ticket for every chunk it starts (milliseconds of work), so a
+ * ticket that stood still belongs to no running workgroup, however long its launch and whether or not the context can
+ * see it (a replayed hipGraph) -- then waits for starved work to finish.  *sets_released (may be NULL) = how many it
+ * freed; 0 on a healthy context.
+ * d377_debug_poison_pool marks `sets` sets (< 0: all) as claimed by nobody: the test hook for the calls above. */
 int d377_ctx_health(d377_ctx* ctx, int dev, int* sets_claimed, uint64_t* waited_long, uint64_t* gave_up);
 int d377_ctx_reset_scratch(d377_ctx* ctx, int dev, int* sets_released);
+int d377_ctx_starved_counter_dev(d377_ctx* ctx, int dev, const uint32_t** counter_dev);
 int d377_debug_poison_pool(d377_ctx* ctx, int dev, int sets);
 /* Debug builds (-DD377_CHECK_INVARIANTS, the counterpart of the reference's debug assertions in
  * Element::new, src/min_curve/element.rs:104-110, and is_on_curve, src/ark_curve/on_curve.rs:14-39): how many

@@ -24,6 +24,8 @@ enum class EncodingError { InvalidEncoding, InvalidSliceLength };
 struct DeviceError : std::runtime_error {
   explicit DeviceError(int code) : std::runtime_error(std::string("decaf377_amd: ") + d377_last_error()), code(code) {}
   int code;
+  // D377_ERR_STARVED: workgroups found no free lane set for 10 s; the call wrote nothing usable (Context health / reset_scratch)
+  bool starved() const { return code == D377_ERR_STARVED; }
 };
 
 // Result<T, EncodingError>

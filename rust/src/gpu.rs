@@ -52,6 +52,13 @@ unsafe impl Sync for GpuContext {}
 
 #[derive(Debug)]
 pub struct GpuError(pub i32, pub String);
+impl GpuError {
+    /// `D377_ERR_STARVED`: workgroups of the call found no free lane set for 10 s and wrote no output -- the call
+    /// produced nothing usable (`GpuContext::health`, `GpuContext::reset_scratch`, then call again).
+    pub fn is_starved(&self) -> bool {
+        self.0 == ffi::D377_ERR_STARVED
+    }
+}
 
 fn check(rc: i32) -> Result<(), GpuError> {
     if rc == ffi::D377_OK {
@@ -83,6 +90,13 @@ impl GpuContext {
         let mut freed = 0i32;
         check(unsafe { ffi::d377_ctx_reset_scratch(self.0, dev, &mut freed) })?;
         Ok(freed)
+    }
+    /// Device address of the 32-bit gave-up counter of `dev` (for callers of the `_dev` entry points: copy it on the
+    /// call's stream before and after, compare once the stream is synchronised).
+    pub fn starved_counter_dev(&self, dev: i32) -> Result<*const u32, GpuError> {
+        let mut p: *const u32 = core::ptr::null();
+        check(unsafe { ffi::d377_ctx_starved_counter_dev(self.0, dev, &mut p) })?;
+        Ok(p)
     }
     /// Developer interface: override one launch rule (`ffi::D377_TUNE_*`); `None` restores the built-in rule.
     pub fn set_tuning(&self, key: i32, value: Option<i64>) -> Result<(), GpuError> {

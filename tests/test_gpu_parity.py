@@ -563,6 +563,51 @@ def test_lane_set_pool_health_and_reset(torch_mod, oracle):
         c.close()
 
 
+@pytest.mark.gpu
+def test_starved_call_is_an_error_not_a_silent_partial_output(torch_mod, oracle):
+    """A workgroup that finds no lane set for 10 s leaves without writing its records (dcb.hpp).  That must never read as
+    success -- the reference's fallible operations always return a Result (src/ark_curve/encoding.rs:34-60): a
+    HOST-POINTER call on a poisoned pool FAILS with D377_ERR_STARVED (StarvedError), the MSM of encodings likewise; a
+    `_dev` caller sees the gave-up counter move through the word d377_ctx_starved_counter_dev hands out; after
+    d377_ctx_reset_scratch the same calls give the oracle's bytes."""
+    import time
+    import decaf377_amd as d
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    c = d.Context([0])
+    try:
+        rng = np.random.default_rng(9107)
+        n = 70000                                       # above the quad kernels: the chunked route (claims lane sets), one generation of workgroups
+        r0 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        want = c.encode_to_curve(r0)                    # host-pointer call on a healthy context
+        word = c.starved_counter()
+        assert word.dtype == torch.int32 and int(word.item()) == 0
+        c._debug_poison_pool()
+        t0 = time.time()
+        with pytest.raises(d.StarvedError) as ei:
+            c.encode_to_curve(r0)
+        dt = time.time() - t0
+        assert 9.0 < dt < 40.0, dt                      # every workgroup waited its 10 s (they wait side by side)
+        assert "lane set" in str(ei.value)
+        claimed, waited, gave_up = c.health()
+        assert gave_up >= 1 and int(word.item()) == gave_up
+        # the `_dev` form cannot fail at the call (it only enqueues): its caller watches the counter on the stream
+        r0_d = torch.from_numpy(r0).to(dev)
+        before = word.clone()
+        out = c.encode_to_curve(r0_d)
+        after = word.clone()                            # torch's current stream: ordered behind the kernel
+        torch.cuda.synchronize()
+        assert int(after.item()) > int(before.item())
+        assert c.reset_scratch() == claimed
+        assert (c.encode_to_curve(r0) == want).all()
+        assert torch.equal(c.encode_to_curve(r0_d), torch.from_numpy(want).to(dev))
+        idx = np.arange(0, n, n // 64)
+        assert (want[idx] == oracle.encode_to_curve(r0[idx])).all()
+        assert c.health()[0] == 0
+    finally:
+        c.close()
+
+
 def test_small_batch_quad_kernel_matches_lane_kernel(ctx, oracle, torch_mod):
     """Batches that cannot fill the chip with one lane per element (up to 7 or 8 x 16 quads per CU) run one element per QUAD of
     lanes (d377.hip k_scalar_mul_var_small, quad_ops.hpp).  Same bytes as the one-lane-per-element kernel (forced with
@@ -1282,6 +1327,7 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_msm_dev": lambda f: f.msm,
         "d377_msm_encoded_dev": lambda f: f.msm,
         "d377_sum_elements_dev": None,
+        "d377_ctx_starved_counter_dev": None,          # test_starved_call_is_an_error_not_a_silent_partial_output
         "d377_batch_sharded_dev": None,
     }
     args = {

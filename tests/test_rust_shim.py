@@ -12,6 +12,7 @@ C_TO_RUST = {
     "const uint8_t*": "*const u8", "uint8_t*": "*mut u8", "const uint64_t*": "*const u64", "uint64_t*": "*mut u64",
     "const int*": "*const c_int", "int*": "*mut c_int", "int": "c_int", "size_t": "usize", "void*": "*mut c_void", "const void*": "*const c_void",
     "const char*": "*const c_char", "void": None, "int64_t": "i64", "int64_t*": "*mut i64",
+    "const uint32_t**": "*mut *const u32",
 }
 
 
