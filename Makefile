@@ -5,6 +5,8 @@
 #   make lib FB_BITS=14       options below; a non-default build goes to build/variants/<VARIANT>.so when VARIANT is set
 #   make check                the same sources with -DD377_CHECK_INVARIANTS (the reference's debug assertions)
 #   make oracle               test infrastructure (oracle/Makefile), never linked into the product
+#   make tools                the native pieces the kept developer tools load or run (tools/README.md): build/row_proto.so,
+#                             tools/clock_vs_traffic, tools/valu_mix, tools/valu_mix2
 #
 # Options ("config / flags"):
 #   ARCH              offload architecture (gfx950; the kernels are written for nothing else)
@@ -69,9 +71,22 @@ $(CHECK_LIB): $(UNITS:%=$(CHECK_OBJDIR)/%.o)
 oracle:
 	$(MAKE) -C oracle
 
+# developer tools (tools/README.md): what tools/row_proto.py, row_point_check.py, row_invert_check.py dlopen and what
+# clock_vs_traffic.sh / bench.py's MAC-ceiling note run
+tools: build/row_proto.so tools/clock_vs_traffic tools/valu_mix tools/valu_mix2
+build/row_proto.so: tools/row_proto.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -shared $< -o $@
+tools/clock_vs_traffic: tools/clock_vs_traffic.hip $(HDRS)
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 -I$(CSRC) $< -o $@
+tools/valu_mix: tools/valu_mix.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 $< -o $@
+tools/valu_mix2: tools/valu_mix2.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -std=c++17 $< -o $@
+
 clean:
 	rm -rf build/obj build/obj_check build/obj_* build/variants $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
 
 FORCE:
-.PHONY: all lib check oracle clean FORCE
+.PHONY: all lib check oracle tools clean FORCE

@@ -1545,7 +1545,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     case OP_AFFINE: {
       // ~AFFINE_PER_LANE elements per lane so that one inversion serves many, but never fewer lanes than one
-      // wave per SIMD.  Measured (tools/affine_bench.py, 2^20 elements): 0.28 / 0.40 / 0.65 / 1.14 ms at 1 / 2 / 4 / 8
+      // wave per SIMD.  Measured (tools/attic/affine_bench.py, 2^20 elements): 0.28 / 0.40 / 0.65 / 1.14 ms at 1 / 2 / 4 / 8
       // blocks per CU -- every extra lane is an extra 380-operation inversion -- against 2.7 ms for one inversion
       // per element.  D377_TUNE_AFFINE_BLOCKS_PER_CU is a developer override for that sweep.
       size_t lanes = (n + AFFINE_PER_LANE - 1) / AFFINE_PER_LANE;

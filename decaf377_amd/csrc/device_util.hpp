@@ -125,7 +125,7 @@ struct LdsPowTab {
 // A lane that loads its own 128-byte record issues eight 16-byte loads at a lane stride of 128 bytes: every instruction
 // touches 64 lines and uses an eighth of each.  The kernels that mostly move records (k_neg, k_add) load a wave's 64 records as
 // eight fully coalesced 1 KiB instructions into LDS instead (16-byte chunks, XOR-swizzled so that neither the chunk-order
-// writes nor the record-order reads conflict) and each lane picks its record up there; results go back the same way.  tools/record_io_bench.hip, 2^22 records: one input and one output stream 4.5 ->
+// writes nor the record-order reads conflict) and each lane picks its record up there; results go back the same way.  tools/attic/record_io_bench.hip, 2^22 records: one input and one output stream 4.5 ->
 // 5.7 TB/s, two inputs and one output 3.8 -> 5.5 TB/s.  In-place calls stay safe: a wave reads all of its tile before it
 // writes any of it.
 constexpr int REC_TILE_CHUNKS = 64 * 8;                 // 64 records x 8 chunks of 16 bytes: 8 KiB per wave

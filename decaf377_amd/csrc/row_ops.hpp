@@ -331,7 +331,7 @@ __device__ __forceinline__ RowPowers row_sqrt_powers_num(uint32_t num, uint32_t 
 //     form is the one libsecp256k1's modinv32 "var" uses), ~6 trips per 30 divsteps instead of 30.  At most 724 divsteps
 //     bring g to zero for inputs below 2^256: 25 rounds; the rounds after g = 0 pass in ~60 instructions each (f, g, d keep
 //     their values).
-// 31 us -> 11 us on a lone wave (tools/row_invert_test.py).  An inverse is a field value: same result as fe_invert.
+// 31 us -> 11 us on a lone wave (tools/row_invert_check.py).  An inverse is a field value: same result as fe_invert.
 // Every lane of the wave must call this; the value inverted is LANE 0's x, the result comes back in every lane.
 __device__ __forceinline__ int32_t divsteps_30_var(int32_t eta, uint32_t f0, uint32_t g0, trans30* t) {
   uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;

@@ -53,6 +53,6 @@ def test_row_ops_on_the_gpu():
     if not os.path.exists(so) or any(os.path.getmtime(d_) > os.path.getmtime(so) for d_ in deps):
         subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                                deps[0], "-o", so], timeout=900)
-    for tool, ok in (("row_proto.py", "0 differ from the model"), ("row_point_test.py", "ROW_POINT_OK"), ("row_invert_test.py", "ROW_INVERT_OK")):
+    for tool, ok in (("row_proto.py", "0 differ from the model"), ("row_point_check.py", "ROW_POINT_OK"), ("row_invert_check.py", "ROW_INVERT_OK")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert r.returncode == 0 and ok in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -5,7 +5,7 @@ signed 30-bit limbs with the kernel's two carry passes, no sign test, one lift b
 against the width the kernel gives it (int64 products, uint32 sums, int32 limbs), d and e against the range the comments
 claim, the exact divisions by 2^30 against the integers, and the result against pow(c, -1, q) -- on structured residues
 (powers of two, q minus them, small numbers, their inverses: the values whose inverses are SMALL, which is where a sign test
-on lazily carried limbs goes wrong) and random ones.  Prints INV_WAVE_MODEL_OK.  tools/row_invert_trace.py compares the same
+on lazily carried limbs goes wrong) and random ones.  Prints INV_WAVE_MODEL_OK.  tools/attic/row_invert_trace.py compares the same
 rounds with the GPU's."""
 import random
 import sys

@@ -42,8 +42,8 @@ timeout 600 python3 tools/size_sweep.py --sizes 16,256,1024,1025,4096,8192,11585
   --ops "msm (Elements),msm (Encodings)" > "$out/size_sweep_msm.txt" 2>&1
 mkdir -p build
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared tools/row_proto.hip -o build/row_proto.so > "$out/row_ops.txt" 2>&1
-{ timeout 200 python3 tools/row_model.py; timeout 200 python3 tools/row_proto.py; timeout 200 python3 tools/row_point_test.py;
-  timeout 200 python3 tools/inv_wave_model.py; timeout 200 python3 tools/row_invert_test.py; } >> "$out/row_ops.txt" 2>&1
+{ timeout 200 python3 tools/row_model.py; timeout 200 python3 tools/row_proto.py; timeout 200 python3 tools/row_point_check.py;
+  timeout 200 python3 tools/inv_wave_model.py; timeout 200 python3 tools/row_invert_check.py; } >> "$out/row_ops.txt" 2>&1
 echo "row ops: $(grep -c "OK\|DONE" "$out/row_ops.txt") of 5 legs"
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -Idecaf377_amd/csrc tools/clock_vs_traffic.hip -o tools/clock_vs_traffic > /dev/null 2>&1
 bash tools/clock_vs_traffic.sh "$out/clock_vs_traffic.txt" > /dev/null 2>&1
