@@ -220,6 +220,55 @@ def sqrt_ratio_zeta_min_curve(num, den):
     return False, _our_sqrt(ZETA * x % Q)
 
 
+
+# --- the raw root, pinned independently of the Sarkar text ------------------
+# src/min_curve/constants.rs:10-15: ZETA_TO_TRACE (Montgomery limbs as written there) = zeta^m; the reference never uses it.
+ZETA_TO_TRACE = from_mont_limbs(
+    [6282505393754313363, 14378628227555923904, 9804873068900332207, 302335131180501866]
+)
+
+
+def _ts_sqrt(x, seed):
+    """Tonelli-Shanks in the loop shape of src/min_curve/invsqrt.rs:11-57 with the seed (c5) a parameter."""
+    z = pow(x, SQRT_M_MINUS_ONE_DIV_TWO, Q)
+    t = z * z % Q * x % Q
+    z = z * x % Q
+    b = t
+    c = seed
+    for i in range(SQRT_N, 1, -1):
+        for _ in range(1, i - 1):
+            b = b * b % Q
+        if b != 1:
+            z = z * c % Q
+        c = c * c % Q
+        if b != 1:
+            t = t * c % Q
+        b = t
+    return z
+
+
+def sqrt_ratio_zeta_ts_zeta(num, den):
+    """The arkworks backend's root WITHOUT the Sarkar tables: Tonelli-Shanks seeded with zeta^m on num/den (or on
+    zeta num/den for a non-square), by way of a modular inverse and a Legendre symbol -- nothing of
+    src/ark_curve/invsqrt.rs:75-166 is used.  Theorem: write x = u^2 with x^m = g^(-2k) in the
+    2-Sylow subgroup, g = zeta^m of order 2^47; Tonelli-Shanks with seed g walks the bits of k from the bottom and
+    returns x^((m+1)/2) g^k, and so does the Sarkar method, which reads the same k eight bits at a time out of its
+    tables (t = 2k there, halved at invsqrt.rs:148).  The two differ from the min_curve backend's root (seed 11^m) by
+    a sign on about half of all inputs.  tests/test_oracle.py::test_raw_root_is_tonelli_shanks_with_zeta_seed and
+    tests/test_gpu_parity.py::test_raw_root_pinned_by_tonelli_shanks_zeta_seed hold the Sarkar statement above, the C
+    oracle and the GPU's D377_SQRT_ROOT_ARK output to this function."""
+    num %= Q
+    den %= Q
+    if num == 0:
+        return True, 0
+    if den == 0:
+        return False, 0
+    x = num * pow(den, -1, Q) % Q
+    if pow(x, (Q - 1) // 2, Q) == 1:
+        return True, _ts_sqrt(x, ZETA_TO_TRACE)
+    return False, _ts_sqrt(ZETA * x % Q, ZETA_TO_TRACE)
+
+
 # --- group (extended twisted Edwards, a=-1, d=3021) ------------------------
 IDENTITY = (0, 1, 1, 0)  # src/min_curve/element.rs:53-58 (x, y, z, t)
 GENERATOR = (B_X, B_Y, 1, B_T)

@@ -28,8 +28,14 @@
  * reference's tests hold for this path (16 basepoint multiples, generator/identity,
  * 8 Elligator KATs, sqrt edge cases, Fq/Fr byte examples, proptest regression seeds)
  * and against the independent big-integer model oracle/d377_model.py.
- * Raw sqrt_ratio_zeta root VALUES are not pinned by any reference vector (the
- * reference only tests res^2); the root choice follows invsqrt.rs:75-166 verbatim.
+ * Raw sqrt_ratio_zeta root VALUES are pinned by no reference vector (the reference tests
+ * res^2 only, invsqrt.rs:182-202); they are pinned by a theorem instead: the Sarkar root
+ * is Tonelli-Shanks seeded with zeta^m (ZETA_TO_TRACE, src/min_curve/constants.rs:10-15)
+ * applied to num/den -- an algorithm that shares nothing with invsqrt.rs:75-166
+ * (oracle/d377_model.py sqrt_ratio_zeta_ts_zeta).  This file, the big-integer Sarkar
+ * statement and the GPU's D377_SQRT_ROOT_ARK output are held to it on 2^12 seeded pairs:
+ * tests/test_oracle.py::test_raw_root_is_tonelli_shanks_with_zeta_seed,
+ * tests/test_gpu_parity.py::test_raw_root_pinned_by_tonelli_shanks_zeta_seed.
  *
  * Build: make -C oracle   (gcc -O3 -march=x86-64-v3 -fPIC -shared)
  */

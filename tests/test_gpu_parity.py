@@ -155,6 +155,22 @@ def test_sqrt_random_2_16(ctx, oracle):
     assert (ws == o_ws).all() and (root == o_root).all()
 
 
+def test_raw_root_pinned_by_tonelli_shanks_zeta_seed(ctx, oracle):
+    """Raw sqrt_ratio_zeta root VALUES against a definition that shares nothing with the Sarkar text the kernel and the
+    oracle both follow: Tonelli-Shanks seeded with zeta^m on num/den (oracle/d377_model.py sqrt_ratio_zeta_ts_zeta;
+    src/min_curve/constants.rs:10-15, loop of src/min_curve/invsqrt.rs:36-54).  2^12 seeded pairs, edge pairs first;
+    the D377_SQRT_ROOT_ARK output must equal it bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import d377_model as m
+    from test_oracle import _root_pin_pairs
+    n = 1 << 12
+    num, den = _root_pin_pairs(n)
+    root, ws = ctx.sqrt_ratio_zeta(num, den, root="ark")          # d377_batch_sqrt_ratio_zeta_ex, D377_SQRT_ROOT_ARK
+    for i in range(n):
+        fl, r = m.sqrt_ratio_zeta_ts_zeta(m.fq_from_le_bytes_mod_order(bytes(num[i])), m.fq_from_le_bytes_mod_order(bytes(den[i])))
+        assert (bool(ws[i]), int.from_bytes(bytes(root[i]), "little")) == (fl, r), i
+
+
 def test_roundtrip_random_raw(ctx, oracle):
     """2^16 raw strings (mostly invalid) + valid encodings: status and zero-output equal the oracle."""
     rng = np.random.default_rng(667)

@@ -341,6 +341,43 @@ def test_min_curve_root(oracle):
     assert 20 < differs < 76          # the two backends disagree on the sign about half the time
 
 
+def _root_pin_pairs(n):
+    """Seeded (num, den) pairs for the raw-root pin: edge pairs (zeros, 1/1, the 2^248 regression seed, small values,
+    squares and zeta multiples of squares), then random bytes (reduced mod q as from_le_bytes_mod_order does)."""
+    rng = np.random.default_rng(20260403)
+    num = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    den = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    edge = [(0, 1), (1, 0), (0, 0), (1, 1), (1 << 248, 1 << 248), (4, 1), (1, 4), (m.ZETA, 1), (1, m.ZETA),
+            (m.Q - 1, 1), (1, m.Q - 1), (m.ZETA * 9 % m.Q, 25), (2, 3), (m.Q - 2, m.Q - 3)]
+    for i, (u, v) in enumerate(edge):
+        num[i] = np.frombuffer(int(u).to_bytes(32, "little"), np.uint8)
+        den[i] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    return num, den
+
+
+def test_raw_root_is_tonelli_shanks_with_zeta_seed(oracle):
+    """The one output of the path the reference's tests do not pin by value (src/ark_curve/invsqrt.rs:182-202 checks
+    res^2 only), pinned by an algorithm-independent definition instead: Tonelli-Shanks seeded with zeta^m
+    (ZETA_TO_TRACE, src/min_curve/constants.rs:10-15; loop of src/min_curve/invsqrt.rs:36-54) on num/den, computed
+    with a modular inverse and a Legendre symbol -- no table, no statement of invsqrt.rs:75-166.  The big-integer
+    Sarkar statement and the C oracle must return exactly that root on 2^12 seeded pairs."""
+    assert m.ZETA_TO_TRACE == pow(m.ZETA, m.SQRT_M, m.Q)               # the constant the reference holds IS zeta^m
+    assert pow(m.ZETA_TO_TRACE, 1 << 46, m.Q) == m.Q - 1              # of exact order 2^47: a generator of the 2-Sylow subgroup
+    n = 1 << 12
+    num, den = _root_pin_pairs(n)
+    root, ws = oracle.sqrt_ratio_zeta(num, den)
+    min_differs = 0
+    for i in range(n):
+        u = m.fq_from_le_bytes_mod_order(bytes(num[i]))
+        v = m.fq_from_le_bytes_mod_order(bytes(den[i]))
+        fl, r = m.sqrt_ratio_zeta_ts_zeta(u, v)
+        assert (bool(ws[i]), int.from_bytes(bytes(root[i]), "little")) == (fl, r), i
+        if i < 512:
+            assert m.sqrt_ratio_zeta(u, v) == (fl, r), i
+            min_differs += m.sqrt_ratio_zeta_min_curve(u, v)[1] != r
+    assert 150 < min_differs < 362         # the 11^m seed of the min_curve backend gives the other sign half the time
+
+
 def test_neg_is_identity_fq_ops(oracle):
     """src/min_curve/element.rs:113-117,324-332 and src/fields/fq/u64/wrapper.rs:99-132 vs big integers."""
     rng = np.random.default_rng(9)
