@@ -564,59 +564,73 @@ def main():
         line["extra"] = extra
 
     # The CPU leg runs on rank 0 at every N (the other ranks wait at the barrier below): the same host cores, the same run.
+    cpu_leg_error = None
     if rank == 0 and not args.no_cpu_baseline and head_local and int(head_local[0].shape[0]) >= 4096:
-        orc = Oracle(native=True, build=False)
-        cores = usable_cores()
-        # pilot on one thread to size a sample worth ~12 s of wall time on all cores
-        pilot = 512
-        n_head = int(head_local[0].shape[0])
-        p_h = head_local[0].cpu().numpy()            # rank 0's last headline launch: inputs ...
-        k_h = head_local[1].cpu().numpy()
-        out, n = head_local[2], n_head               # ... and outputs, compared below on the sample
-        t0 = time.perf_counter()
-        orc.run_threads("scalar_mul_var", p_h[:pilot], k_h[:pilot], 1)
-        per_thread = pilot / (time.perf_counter() - t0)
-        one_thread_rate = per_thread
-        ns = int(min(n, max(4096, per_thread * cores * 12.0)))
-        p_h, k_h = p_h[:ns], k_h[:ns]
-        t0 = time.perf_counter()
-        o_out, o_st, used = orc.run_threads("scalar_mul_var", p_h, k_h, cores)
-        dt = time.perf_counter() - t0
-        same = bool((o_out == out[:ns].cpu().numpy()).all() and not o_st.any())
-        line["cpu_baseline"] = {
-            "value": ns / dt,
-            "unit": "scalar-mults/s",
-            "cores": used,
-            "kind": "port",
-            "sample": "first %d of the %d (point, scalar) pairs of this run, %d pthreads over contiguous slices; "
-                      "C restatement of the reference algorithm (Sarkar sqrt, 256-step double-and-add, 4x64 "
-                      "Montgomery), gcc %s" % (ns, n, used, orc.flags),
-            "seconds": dt,
-            "matches_gpu_output": same,
-            "value_1_thread": one_thread_rate,
-        }
-        assert same, "GPU output differs from the oracle on the cpu_baseline sample"
-        # BASELINE.json configs[0] (the reference's own CPU-runnable case, shape of benches/sqrt.rs):
-        # 2^16 Fq::sqrt_ratio_zeta on the CPU restatement, one thread, plus the GPU on the same pairs
-        nsq = min(1 << 16, int(r0.shape[0]))
-        num_h, den_h = r0[:nsq].cpu().numpy(), scalars[:nsq].cpu().numpy()
-        t0 = time.perf_counter()
-        o_root, o_ws, _ = orc.run_threads("sqrt_ratio_zeta", num_h, den_h, 1)
-        dts = time.perf_counter() - t0
-        g_root, g_ws = ctx.sqrt_ratio_zeta(r0[:nsq], scalars[:nsq])
-        ok = bool((g_root.cpu().numpy() == o_root).all() and (g_ws.cpu().numpy() == o_ws).all())
-        assert ok, "GPU sqrt_ratio_zeta differs from the oracle"
-        line["cpu_baseline"]["config0_sqrt_ratio_zeta_2^16"] = {
-            "cpu_ns_per_call_1_thread": dts / nsq * 1e9, "cpu_per_sec_1_thread": nsq / dts, "matches_gpu_output": ok}
+        try:
+            orc = Oracle(native=True, build=False)
+            cores = usable_cores()
+            # pilot on one thread to size a sample worth ~12 s of wall time on all cores
+            pilot = 512
+            n_head = int(head_local[0].shape[0])
+            p_h = head_local[0].cpu().numpy()            # rank 0's last headline launch: inputs ...
+            k_h = head_local[1].cpu().numpy()
+            out, n = head_local[2], n_head               # ... and outputs, compared below on the sample
+            t0 = time.perf_counter()
+            orc.run_threads("scalar_mul_var", p_h[:pilot], k_h[:pilot], 1)
+            per_thread = pilot / (time.perf_counter() - t0)
+            one_thread_rate = per_thread
+            ns = int(min(n, max(4096, per_thread * cores * 12.0)))
+            p_h, k_h = p_h[:ns], k_h[:ns]
+            t0 = time.perf_counter()
+            o_out, o_st, used = orc.run_threads("scalar_mul_var", p_h, k_h, cores)
+            dt = time.perf_counter() - t0
+            same = bool((o_out == out[:ns].cpu().numpy()).all() and not o_st.any())
+            line["cpu_baseline"] = {
+                "value": ns / dt,
+                "unit": "scalar-mults/s",
+                "cores": used,
+                "kind": "port",
+                "sample": "first %d of the %d (point, scalar) pairs of this run, %d pthreads over contiguous slices; "
+                          "C restatement of the reference algorithm (Sarkar sqrt, 256-step double-and-add, 4x64 "
+                          "Montgomery), gcc %s" % (ns, n, used, orc.flags),
+                "seconds": dt,
+                "matches_gpu_output": same,
+                "value_1_thread": one_thread_rate,
+            }
+            if not same:
+                raise AssertionError("GPU output differs from the oracle on the cpu_baseline sample")
+            # BASELINE.json configs[0] (the reference's own CPU-runnable case, shape of benches/sqrt.rs):
+            # 2^16 Fq::sqrt_ratio_zeta on the CPU restatement, one thread, plus the GPU on the same pairs
+            nsq = min(1 << 16, int(r0.shape[0]))
+            num_h, den_h = r0[:nsq].cpu().numpy(), scalars[:nsq].cpu().numpy()
+            t0 = time.perf_counter()
+            o_root, o_ws, _ = orc.run_threads("sqrt_ratio_zeta", num_h, den_h, 1)
+            dts = time.perf_counter() - t0
+            g_root, g_ws = ctx.sqrt_ratio_zeta(r0[:nsq], scalars[:nsq])
+            ok = bool((g_root.cpu().numpy() == o_root).all() and (g_ws.cpu().numpy() == o_ws).all())
+            if not ok:
+                raise AssertionError("GPU sqrt_ratio_zeta differs from the oracle")
+            line["cpu_baseline"]["config0_sqrt_ratio_zeta_2^16"] = {
+                "cpu_ns_per_call_1_thread": dts / nsq * 1e9, "cpu_per_sec_1_thread": nsq / dts, "matches_gpu_output": ok}
+        except Exception as e:                      # every rank must still reach the barrier below: report, then fail
+            cpu_leg_error = "%s: %s" % (type(e).__name__, e)
+            line["cpu_baseline_error"] = cpu_leg_error
+            parity_ok = False
 
     if dist.is_initialized() and world > 1:
-        dist.barrier()                               # rank 0 may have spent ~15 s in the CPU leg
+        # rank 0 may have spent ~15 s in the CPU leg; its verdict (a failed check there fails the job on every rank)
+        # travels with the MIN all-reduce, which is also the barrier
+        flag = torch.tensor([1 if parity_ok else 0], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        parity_ok = bool(flag.item())
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if cpu_leg_error:
+        raise SystemExit("bench.py: the CPU-baseline leg failed: " + cpu_leg_error)
     if not parity_ok:
-        raise SystemExit("bench.py: a rank's outputs differ from the oracle on its parity sample")
+        raise SystemExit("bench.py: a rank's outputs differ from the oracle on its parity sample (or rank 0's CPU leg failed)")
 
 
 if __name__ == "__main__":

@@ -37,7 +37,10 @@ def scatter_records(full, n, row_shape, dtype, device, src=0, group=None):
     chunks = None
     if rank == src:
         assert full is not None and full.shape[0] == n
-        if n % world == 0 and full.is_contiguous():
+        # views go to the collective as they are, so they must already be what the peers' `recv` is (the padded path
+        # converts through its copies)
+        if n % world == 0 and full.is_contiguous() and full.dtype == dtype and full.device == torch.device(device) \
+                and tuple(full.shape[1:]) == tuple(row_shape):
             chunks = [full[r * rows:(r + 1) * rows] for r in range(world)]
         else:
             chunks = []
