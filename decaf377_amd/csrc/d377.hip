@@ -1307,6 +1307,16 @@ int init_device(DeviceState& d) {
   d.cus = prop.multiProcessorCount;
   HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+  {
+    // The stream of d377_ctx_health / d377_ctx_reset_scratch, at the highest priority: the runtime keeps a pool of hardware
+    // queues per priority and lets streams share them when a process has more streams than queues (4), and a packet behind
+    // a starving kernel in the SAME hardware queue waits for it -- a health call on an ordinary stream blocked for the
+    // kernel's whole 10 s whenever the process held a second context (seen: 5 streams on 4 queues).  Only these short
+    // control operations ever run at this priority.
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&d.ctl_stream, hipStreamNonBlocking, greatest));
+  }
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(hipEventCreateWithFlags(&d.ev_in[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.ev_done[i], hipEventDisableTiming));
@@ -1336,6 +1346,9 @@ int init_device(DeviceState& d) {
   HIP_TRY(hipMemsetAsync(d.pool_health, 0, 4 * sizeof(uint32_t), d.stream));
   HIP_TRY(hipHostMalloc(&d.starve_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
   d.starve_host[0] = d.starve_host[1] = 0;
+  // pinned landing area of d377_ctx_health / d377_ctx_reset_scratch (pool words + the four health words): a copy into
+  // pageable memory may wait for work of other streams inside the runtime, and these calls must not wait for kernels
+  HIP_TRY(hipHostMalloc(&d.pool_host, ((size_t)d.dcb_sets + 4) * sizeof(int), hipHostMallocDefault));
   if ((rc = check_residency(d))) return rc;
   uint32_t* keys = nullptr;
   int* coll = nullptr;
@@ -1357,6 +1370,8 @@ void free_device(DeviceState& d) {
   (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.pool_health); (void)hipFree(d.inv_fail);
   if (d.starve_host) (void)hipHostFree(d.starve_host);
   d.starve_host = nullptr;
+  if (d.pool_host) (void)hipHostFree(d.pool_host);
+  d.pool_host = nullptr;
   for (int i = 0; i < 4; ++i) { (void)hipFree(d.buf[i]); (void)hipFree(d.buf2[i]); (void)hipFree(d.shard[i]); }
   for (int i = 0; i < 2; ++i) {
     if (d.ev_in[i]) (void)hipEventDestroy(d.ev_in[i]);
@@ -1366,6 +1381,7 @@ void free_device(DeviceState& d) {
   d.vb_guard.destroy();
   d.msm.guard.destroy();
   if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
+  if (d.ctl_stream) (void)hipStreamDestroy(d.ctl_stream);
   (void)hipFree(d.msm.mem);
   for (uint8_t* r : d.msm.retired) (void)hipFree(r);
   d.msm.retired.clear();
@@ -2018,9 +2034,11 @@ int d377_ctx_get_tuning(d377_ctx* ctx, int key, int64_t* value) {
 // ---- the lane-set pool's way back (dcb.hpp) ----
 static int read_pool(DeviceState& d, std::vector<int>& pool, uint32_t health[4]) {
   pool.resize((size_t)d.dcb_sets);
-  HIP_TRY(hipMemcpyAsync(pool.data(), d.slot_pool, pool.size() * sizeof(int), hipMemcpyDeviceToHost, d.copy_stream));
-  HIP_TRY(hipMemcpyAsync(health, d.pool_health, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d.copy_stream));
-  HIP_TRY(hipStreamSynchronize(d.copy_stream));             // the copy stream is idle between host-path calls (they hold ctx->mu)
+  HIP_TRY(hipMemcpyAsync(d.pool_host, d.slot_pool, pool.size() * sizeof(int), hipMemcpyDeviceToHost, d.ctl_stream));
+  HIP_TRY(hipMemcpyAsync(d.pool_host + d.dcb_sets, d.pool_health, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d.ctl_stream));
+  HIP_TRY(hipStreamSynchronize(d.ctl_stream));              // the control stream carries nothing else
+  memcpy(pool.data(), d.pool_host, pool.size() * sizeof(int));
+  memcpy(health, d.pool_host + d.dcb_sets, 4 * sizeof(uint32_t));
   return D377_OK;
 }
 int d377_ctx_health(d377_ctx* ctx, int dev, int* sets_claimed, uint64_t* waited_long, uint64_t* gave_up) {
@@ -2090,14 +2108,14 @@ int d377_ctx_reset_scratch(d377_ctx* ctx, int dev, int* sets_released) {
     int *d_idx = nullptr, *d_val = nullptr;
     HIP_TRY(hipMalloc(&d_idx, idx.size() * sizeof(int)));
     if (hipMalloc(&d_val, val.size() * sizeof(int)) != hipSuccess) { (void)hipFree(d_idx); return fail(D377_ERR_HIP, "%s", "hipMalloc failed"); }
-    hipError_t e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, d.copy_stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_val, val.data(), val.size() * sizeof(int), hipMemcpyHostToDevice, d.copy_stream);
+    hipError_t e = hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, d.ctl_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_val, val.data(), val.size() * sizeof(int), hipMemcpyHostToDevice, d.ctl_stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_pool_release, dim3((unsigned)((idx.size() + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.copy_stream, d.slot_pool, d_idx, d_val,
+      hipLaunchKernelGGL(k_pool_release, dim3((unsigned)((idx.size() + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.ctl_stream, d.slot_pool, d_idx, d_val,
                          (int)idx.size());
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(d.copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d.ctl_stream);
     (void)hipFree(d_idx); (void)hipFree(d_val);
     if (e != hipSuccess) return fail(D377_ERR_HIP, "reset_scratch: %s", hipGetErrorString(e));
     if (sets_released) *sets_released = (int)idx.size();

@@ -92,11 +92,23 @@ __device__ __forceinline__ void pt_store_affine(uint32_t* p, const gea& c) {
 #pragma unroll
   for (int i = 0; i < AP_WORDS / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-__device__ __forceinline__ gea pt_load_affine(const uint32_t* p, bool swap) {
-  uint32_t w[28];
+// The record as it lies in memory, and the cached point made of it.  A kernel that gathers the NEXT record while it adds
+// the current one keeps the raw words across the addition and converts them only when their turn comes: the conversion's
+// selects read the loaded registers, and placed right behind the loads (as pt_load_affine does) they make the wave wait for
+// the gather before the addition it was meant to hide behind (seen in k_msm_spans' code: s_waitcnt vmcnt(5) and eighteen
+// v_cndmask between the loads and the first product).
+struct gea_raw { uint4 v[7]; };
+__device__ __forceinline__ gea_raw pt_load_affine_raw(const uint32_t* p) {
+  gea_raw r;
   const uint4* q = reinterpret_cast<const uint4*>(p);
 #pragma unroll
-  for (int i = 0; i < 7; ++i) { const uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+  for (int i = 0; i < 7; ++i) r.v[i] = q[i];
+  return r;
+}
+__device__ __forceinline__ gea gea_from_raw(const gea_raw& r, bool swap) {
+  uint32_t w[28];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { w[4 * i] = r.v[i].x; w[4 * i + 1] = r.v[i].y; w[4 * i + 2] = r.v[i].z; w[4 * i + 3] = r.v[i].w; }
   gea c;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
@@ -105,6 +117,14 @@ __device__ __forceinline__ gea pt_load_affine(const uint32_t* p, bool swap) {
     c.kt.l[i] = w[2 * NL + i];
   }
   return c;
+}
+__device__ __forceinline__ gea pt_load_affine(const uint32_t* p, bool swap) { return gea_from_raw(pt_load_affine_raw(p), swap); }
+// "The cached point exists from here on, and no load moves above this line": placed between gea_from_raw and the reload of
+// the same raw buffer, it keeps the compiler from sinking the conversion's selects below the new loads -- which would need
+// the old and the new record in registers at once and a copy of words still in flight at the loop's back edge.
+__device__ __forceinline__ void gea_pin(gea& c) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(c.ypx.l[i]), "+v"(c.ymx.l[i]), "+v"(c.kt.l[i]) : : "memory");
 }
 
 // the 8 odd powers of the fixed exponentiation, one LDS column per lane (bank = lane: no conflicts)

@@ -102,6 +102,7 @@ struct DeviceState {
   int chunk_k[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};          // elements per lane per shared inversion
   int fb_narrow_lds = 0;                 // LDS padding of the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU)
   int msm_enc_chunked = -1;              // msm.hip: may the chunked decoding pass run (its residency matches the lane sets)?  -1 = not asked yet
+  int msm_span_blocks = -1;              // msm.hip: workgroups of k_msm_spans a CU holds (occupancy query), -1 = not asked yet
   int dcb_sets = 0;                      // lane sets of the round-record area and its pool (the largest chunk_sets x CUs)
   uint32_t* gtab = nullptr;
   uint8_t* s_lookup = nullptr;
@@ -110,12 +111,14 @@ struct DeviceState {
   uint8_t* dcb_scratch = nullptr;        // round records of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish)
   int* slot_pool = nullptr;              // which of the lane sets of the scratch areas are claimed, and by which ticket (dcb.hpp, DcbScratch)
   uint32_t* pool_health = nullptr;       // ticket counter, workgroups that waited long for a set, workgroups that gave up (dcb.hpp)
+  int* pool_host = nullptr;              // pinned: where d377_ctx_health / reset_scratch read the pool and the health words
   uint32_t* starve_host = nullptr;       // pinned: the gave-up counter before / after a host-pointer call's kernels (StarveCheck)
   int vb_blocks = 0;
   uint32_t* inv_fail = nullptr;          // device counter of the -DD377_CHECK_INVARIANTS build (always allocated)
   ScratchGuard vb_guard;
   hipStream_t stream = nullptr;          // compute stream of the host-pointer entry points
   hipStream_t copy_stream = nullptr;     // PCIe copies of the pipelined host path
+  hipStream_t ctl_stream = nullptr;      // highest priority: d377_ctx_health / d377_ctx_reset_scratch (a hardware queue no kernel of ours waits in)
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
   // grow-only staging buffers for the host-pointer entry points (set 1 = second half of the
   // double buffer used when a large batch is pipelined chunk by chunk)

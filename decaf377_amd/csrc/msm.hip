@@ -9,14 +9,15 @@
 //   k_msm_count     counting sort, pass 1: workgroup (window, slice) builds the histogram of |digit| over
 //                   its slice of the points in LDS (the whole histogram of a window, <= 2^13 + 1 counters,
 //                   fits) and writes it out
-//   k_msm_scan1/2   per-bucket prefix over the slices, then the exclusive prefix sums over the buckets of a window
-//                   (bucket sizes, and segment / group counts for the reduction levels, and each level's largest count)
+//   k_msm_scan1/2/3 per-bucket prefix over the slices, the exclusive prefix sums over the buckets of a window, and the plan of
+//                   the bucket sums: entries per span lane, partials per bucket, groups of the reduction levels
 //   k_msm_place1    pass 2, level 1: the same workgroup scatters each point's index (sign in bit 31) into the
 //                   super-bucket (128 consecutive buckets) it belongs to; LDS atomics hand out the positions
 //   k_msm_place2    level 2: workgroup (window, super-bucket) spreads its entries over the 128 bucket runs
-//   k_msm_segments  one lane per segment (8 / 16 / 32 points) of a bucket run: mixed additions (7 M each)
-//   k_msm_reduce    the same again on the partial sums (groups of 8, 8, 32): every level decides on the device whether
-//                   it runs; a bucket that holds most of the points (many equal scalars) is cut down level by level
+//   k_msm_spans     one lane per span of L consecutive sorted entries, L = entries / resident lanes: mixed additions (7 M
+//                   each), one partial per bucket the span touches -- one generation of lanes with equal work
+//   k_msm_reduce    groups of 8, 8, 32 partial sums of a bucket: every level decides on the device whether it runs; a
+//                   bucket that holds most of the points (many equal scalars) is cut down level by level
 //   k_msm_buckets   one lane per bucket: sum of what is left of it (a few partials with random scalars)
 //   k_msm_wsum_*    sum_b b * B_b per window by a pairwise tree of bit-sums, then Horner over the bits on four lanes
 //                   (k_msm_chunks / k_msm_fold, the chunked running sums, remain for windows wider than 14 bits)
@@ -61,8 +62,6 @@ constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a seri
 // level of its own costs: 16 -- and 32 since four lanes share a bucket's partials (k_msm_buckets): up to eight additions per lane.
 struct RedSizes { int g[3]; uint32_t skip; };
 constexpr RedSizes RED_DEFAULT = {{8, 8, 32}, 32};
-// Points per lane in k_msm_segments (`seg`, a launch parameter): 8 .. 64 by batch size and window width -- pick_seg() below.
-constexpr int MAX_SEG = 128;
 
 // Every input point is normalised to affine form once (Z = 1 already after decompression; one batched inversion
 // per lane for Element inputs) and stored as a cached AFFINE record (device_util.hpp: pt_store_affine, 128 bytes,
@@ -83,27 +82,41 @@ using row::rq_store_point;
 using row::rq_store_cached;
 using row::rq_load_point;
 
-// signed digit w of k (c bits per window, W windows): the top window is not wrapped
-__device__ __forceinline__ int msm_digit(const uint32_t k[8], int w, int c, int W, uint32_t& carry) {
-  const int bit = w * c;
+// The windows of the 252 scalar bits: W = ceil(252 / c) of them, the first `nwide` c bits wide and the rest c - 1, so that they
+// tile the 252 bits exactly whatever c is (c = 16: twelve 16-bit and four 15-bit windows; 14 and 12 tile by themselves).  A
+// uniform width with a ragged top window -- 12 significant bits at c = 16 -- would pile n / 2^10 points on each of a few
+// hundred buckets; here the top window is at most one bit narrower than the others, and because k / 2 mod r < r < 2^250.23 its
+// UNSIGNED digits (the top window is not wrapped) stay below 2^(width - 1.77) + 1: inside the 2^(width-1) buckets of its width.
+struct WinShape {
+  int c, W, nwide;
+  __host__ __device__ __forceinline__ int width(int w) const { return w < nwide ? c : c - 1; }
+  __host__ __device__ __forceinline__ int first_bit(int w) const { return w * c - (w > nwide ? w - nwide : 0); }
+};
+inline WinShape win_shape(int c) {
+  const int W = (252 + c - 1) / c;
+  return WinShape{c, W, W - (W * c - 252)};
+}
+// signed digit w of k: the top window is not wrapped
+__device__ __forceinline__ int msm_digit(const uint32_t k[8], int w, const WinShape& ws, uint32_t& carry) {
+  const int bit = ws.first_bit(w), cw = ws.width(w);
   const int wi = bit >> 5, sh = bit & 31;
   uint64_t v = k[wi];
   if (wi + 1 < 8) v |= (uint64_t)k[wi + 1] << 32;
-  uint32_t d = (uint32_t)((v >> sh) & ((1u << c) - 1u)) + carry;
+  uint32_t d = (uint32_t)((v >> sh) & ((1u << cw) - 1u)) + carry;
   carry = 0;
-  if (w + 1 < W && d >= (1u << (c - 1))) { carry = 1; return (int)d - (1 << c); }
+  if (w + 1 < ws.W && d >= (1u << (cw - 1))) { carry = 1; return (int)d - (1 << cw); }
   return (int)d;
 }
 
-__device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t i, size_t n, int c, int W, bool skip, int16_t* digits) {
+__device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t i, size_t n, const WinShape& ws, bool skip, int16_t* digits) {
   uint32_t k[8];
   load32(scalar32, i, k);
   fr_reduce_words(k);
   fr_half_words(k);                                     // the sum is formed with k/2 mod r and doubled at the end (k_msm_final)
   uint32_t carry = 0;
 #pragma unroll 1
-  for (int w = 0; w < W; ++w) {
-    int d = msm_digit(k, w, c, W, carry);
+  for (int w = 0; w < ws.W; ++w) {
+    int d = msm_digit(k, w, ws, carry);
     if (skip) d = 0;                                    // invalid points contribute nothing
     digits[(size_t)w * n + i] = (int16_t)d;
   }
@@ -111,7 +124,7 @@ __device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t
 
 // Encodings: one lane per point; decompression leaves Z = 1, so the affine record costs nothing extra.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, int c, int W,
+k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, WinShape ws,
                   uint32_t* pts, int16_t* digits, uint8_t* status) {
   D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
@@ -122,7 +135,7 @@ k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, s
     status[i] = (uint8_t)bad;
     const fe x = fe_select(bad != 0, fe_zero(), g.x), y = fe_select(bad != 0, fe_const(FE_ONE), g.y);
     pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
-    msm_write_digits(scalar32, i, n, c, W, bad != 0, digits);
+    msm_write_digits(scalar32, i, n, ws, bad != 0, digits);
   }
 }
 
@@ -131,7 +144,7 @@ k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, s
 // generations, which is where msm_launch uses it.
 constexpr int MSM_ENC_CHUNKED_GENERATIONS = 2;      // from this many generations of full chunks (x DCB_K x the resident lanes: 2^21 points on 256 CUs)
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, int c, int W,
+k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, WinShape ws,
                           uint32_t* pts, int16_t* digits, uint8_t* status, DcbScratch dcb) {
   D377_POW_LDS();
   D377_DCB_BEGIN(status);
@@ -150,7 +163,7 @@ k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* sca
       status[i] = (uint8_t)bad;
       const fe x = fe_select(bad != 0, fe_zero(), g.x), y = fe_select(bad != 0, fe_const(FE_ONE), g.y);
       pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
-      msm_write_digits(scalar32, i, n, c, W, bad != 0, digits);
+      msm_write_digits(scalar32, i, n, ws, bad != 0, digits);
     });
   D377_DCB_END();
 }
@@ -162,7 +175,7 @@ k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* sca
 // once otherwise.  (Round 2 made the choice per wave inside the 32-per-lane kernel, which left the common Z = 1 case
 // on a grid sized for sharing inversions it did not need: 0.48 ms per 2^22 points.)
 __global__ void __launch_bounds__(BLOCK, 4)
-k_msm_prepare_affine(SqrtTables T, const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c, int W, uint32_t* pts, int16_t* digits,
+k_msm_prepare_affine(SqrtTables T, const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinShape ws, uint32_t* pts, int16_t* digits,
                      uint32_t* flag) {
   const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
   (void)T;
@@ -189,7 +202,7 @@ k_msm_prepare_affine(SqrtTables T, const uint64_t* xyzt, const uint8_t* scalar32
     load32(b, 4 * i + 1, w);
     const fe y = fe_from_mont256_words(w);
     pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
-    msm_write_digits(scalar32, i, n, c, W, false, digits);
+    msm_write_digits(scalar32, i, n, ws, false, digits);
   }
 }
 
@@ -198,7 +211,7 @@ k_msm_prepare_affine(SqrtTables T, const uint64_t* xyzt, const uint8_t* scalar32
 // the backward pass peels 1/z_i off, writes the affine record and the digits.  A record with z = 0 is no group
 // element: it becomes the identity with digits 0.
 __global__ void __launch_bounds__(BLOCK, 4)
-k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c, int W, uint32_t* pts, int16_t* digits,
+k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinShape ws, uint32_t* pts, int16_t* digits,
                  const uint32_t* flag) {
   if (*flag == 0) return;
   const size_t Tn = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -234,7 +247,7 @@ k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, int c,
     x = fe_select(zz, fe_zero(), x);
     y = fe_select(zz, fe_const(FE_ONE), y);
     pt_store_affine(pts + i * AP_WORDS, gea_from_affine(x, y));
-    msm_write_digits(scalar32, i, n, c, W, zz, digits);
+    msm_write_digits(scalar32, i, n, ws, zz, digits);
     if (i == t) break;
   }
 }
@@ -283,28 +296,40 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digit
   for (int j = threadIdx.x; j < nb; j += SORT_THREADS) out[j] = h[j];
 }
 
-// Prefix sums of the sort, two small kernels over workgroups (window, 1024 buckets).
+// Prefix sums of the sort and the plan of the bucket sums, three small kernels over workgroups (window, 1024 buckets).
 // In: blockhist[w][s][b] = points of slice s in bucket b.  Out: blockhist[w][s][b] = points of the slices before s in
-// bucket b; offs[w][0..nb] = exclusive prefix of the bucket sizes (offs[w][nb] = total); segoff[l][w][0..nb],
-// l = 0..REDUCE_LEVELS-1 = the same for ceil(size / seg), ceil(that / red.g[0]), ...: the number of seg-point segments per
-// bucket, of groups of segments, ... (the levels of the bucket reduction).  k_msm_scan1 leaves prefixes local to its 1024 buckets
-// and the four totals of the workgroup in tot[w][chunk][]; k_msm_scan2 adds the totals of the chunks before.  (One
-// workgroup per window walking its buckets 1024 at a time took 0.12 ms at every size: 18 workgroups on 256 CUs.)
+// bucket b; offs[w][0..nb] = exclusive prefix of the bucket sizes (offs[w][nb] = the window's entries); bsz[w][b] = the sizes.
+//
+// THE SPANS.  The sorted entries of a window lie in bucket order, and the lanes that sum them take SPANS of L consecutive
+// entries whatever buckets those belong to (k_msm_spans): lane k of window w takes entries [k L, (k + 1) L) and leaves one
+// partial sum per bucket its span touches.  Every lane has the same L additions to do -- no lane waits for a longer run,
+// no half-full last segment per bucket, and with L = entries / resident lanes the whole sum is ONE generation of lanes that
+// end together (one lane per <= seg points of ONE bucket, as before, ran in 5-10 generations of which the last was part
+// empty, plus half a segment of idle additions per bucket: 11-18 % of the kernel at 2^20 and 2^22 points).  It also leaves
+// few partials: a bucket touches 1 + size / L spans.  Bucket b of window w (entries [o, o + size)) has its partials in
+// slots  lane0[w] + ne0[w] + ne[w][b] + (o / L) ...  + ((o + size - 1) / L)  where lane0 counts the lanes of the windows
+// before, ne0 / ne[w][b] the non-empty buckets before b: slot = lane + rank of the bucket among the non-empty ones, a
+// closed form (both grow by one along the entries), so the level needs no prefix array of its own.
+// segoff[0][w][0..nb] = ne (exclusive prefix of "bucket is not empty" within the window); segoff[l][w][0..nb], l = 1..3 =
+// exclusive prefix of ceil(partials / red.g[0]), ceil(that / red.g[1]), ...: the groups of the further reduction levels.
+// k_msm_scan1: sizes, their prefix local to 1024 buckets, chunk totals; k_msm_scan2: the final offs, L from the total
+// number of entries, the plan (partials per bucket, groups per level, the levels' maxima) with chunk-local prefixes;
+// k_msm_scan3: adds the chunk carries and writes the per-window bases.
 constexpr int REDUCE_LEVELS = 4;
 // lvlmax (zeroed by the host before the launch) receives, per reduction level l and WINDOW w, the largest number of
 // level-(l+1) partials any bucket of that window has -- lvlmax[l * LVL_STRIDE + w] -- and per level the largest over all
 // windows, lvlmax[REDUCE_LEVELS * LVL_STRIDE + l].  A level returns at once when no window needs it, and leaves the
 // windows alone whose buckets are down to `skip` partials: the lane that finishes the bucket adds those (k_msm_buckets).
-// The decision is per window because the TOP window is not like the others: k / 2 mod r < 2^250.2 leaves it 10.2 (12-bit
-// windows) or 12.2 (14-bit) unsigned bits, so its points spread over 0.58 of the buckets the sign-folded windows use and
-// its runs are 1.7 times as long -- one window in 18 that used to switch a level on for all of them.
 constexpr int LVL_STRIDE = 64;
 constexpr int LVL_WORDS = REDUCE_LEVELS * LVL_STRIDE + REDUCE_LEVELS;
-__global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_t* offs, uint32_t* segoff, uint32_t* tot, int nb,
-                                                    int S, int W, int nchunk, int seg, RedSizes red, uint32_t* lvlmax) {
-  __shared__ uint32_t part[1 + REDUCE_LEVELS][1024];
-  __shared__ uint32_t bmax[REDUCE_LEVELS];
-  if (threadIdx.x < REDUCE_LEVELS) bmax[threadIdx.x] = 0;
+constexpr int SEG_BLOCKS_PER_CU = 4;             // workgroups of k_msm_spans per CU (128 VGPRs: tests/test_codegen.py)
+constexpr uint32_t SPAN_MIN = 8;                 // entries per lane at least (a lane's locate + store are worth ~1 addition)
+// the plan's scalars: [0] L, [1] entries of all windows, [2] lanes of all windows
+constexpr int META_WORDS = 4;
+struct WinInfo { uint32_t len, lane0, ne0, lanes; };     // per window; entry [W] holds the totals in lane0 / ne0
+__global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_t* offs, uint32_t* bsz, uint32_t* tot, int nb, int S,
+                                                    int nchunk) {
+  __shared__ uint32_t part[1024];
   const int w = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk, t = threadIdx.x;
   const int len = nb + 1;
   const int j = chunk * 1024 + t;
@@ -316,11 +341,58 @@ __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_
       bh[(size_t)sl * nb + j] = c;
       c += v;
     }
-  uint32_t own[1 + REDUCE_LEVELS];
-  own[0] = c;
-  own[1] = (own[0] + (uint32_t)seg - 1) / (uint32_t)seg;
+  part[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = (t >= off) ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  if (j < len) {                                                  // slot nb is the sentinel: total
+    offs[(size_t)w * len + j] = part[t] - c;
+    bsz[(size_t)w * len + j] = c;
+  }
+  if (t == 1023) tot[(size_t)w * nchunk + chunk] = part[1023];
+}
+__global__ void __launch_bounds__(1024) k_msm_scan2(uint32_t* offs, const uint32_t* bsz, uint32_t* segoff, const uint32_t* tot, uint32_t* tot2,
+                                                    int nb, int W, int nchunk, uint32_t lanes_target, uint32_t forced_L, RedSizes red,
+                                                    uint32_t* lvlmax, uint32_t* meta) {
+  __shared__ uint32_t part[REDUCE_LEVELS][1024];
+  __shared__ uint32_t bmax[REDUCE_LEVELS];
+  __shared__ uint32_t s_E, s_carry;
+  const int w = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk, t = threadIdx.x;
+  const int len = nb + 1;
+  const int j = chunk * 1024 + t;
+  if (t < REDUCE_LEVELS) bmax[t] = 0;
+  if (t == 0) {                                                   // W x nchunk <= 63 x 33 words: every workgroup sums them itself
+    uint32_t E = 0, carry = 0;
+    for (int k = 0; k < W * nchunk; ++k) {
+      const uint32_t v = tot[k];
+      E += v;
+      if (k / nchunk == w && k % nchunk < chunk) carry += v;
+    }
+    s_E = E; s_carry = carry;
+  }
+  __syncthreads();
+  const uint32_t E = s_E;
+  // one generation: L = entries / lanes the kernel keeps resident (a window's last lane is part full: W lanes spare)
+  uint32_t L = forced_L ? forced_L : (E + lanes_target - 1) / lanes_target;
+  if (L < SPAN_MIN && !forced_L) L = SPAN_MIN;
+  if (L < 1) L = 1;
+  if (blockIdx.x == 0 && t == 0) { meta[0] = L; meta[1] = E; }
+  uint32_t start = 0, size = 0;
+  if (j < len) {
+    start = offs[(size_t)w * len + j] + s_carry;
+    size = bsz[(size_t)w * len + j];
+    offs[(size_t)w * len + j] = start;
+  }
+  uint32_t own[1 + REDUCE_LEVELS];                               // [0] non-empty, [1] partials after the spans, [2..] groups per level
+  own[0] = size != 0 ? 1u : 0u;
+  own[1] = size != 0 ? (start + size - 1) / L - start / L + 1 : 0u;
   for (int l = 2; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + (uint32_t)red.g[l - 2] - 1) / (uint32_t)red.g[l - 2];
-  for (int l = 0; l <= REDUCE_LEVELS; ++l) part[l][t] = own[l];
+  part[0][t] = own[0];
+  for (int l = 1; l < REDUCE_LEVELS; ++l) part[l][t] = own[l + 1];
   __syncthreads();
   for (int l = 1; l <= REDUCE_LEVELS; ++l)
     if (own[l] > 1) atomicMax(&bmax[l - 1], own[l]);
@@ -330,30 +402,43 @@ __global__ void __launch_bounds__(1024) k_msm_scan1(uint32_t* blockhist, uint32_
     atomicMax(&lvlmax[REDUCE_LEVELS * LVL_STRIDE + t], bmax[t]);
   }
   for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v[1 + REDUCE_LEVELS];
-    for (int l = 0; l <= REDUCE_LEVELS; ++l) v[l] = (t >= off) ? part[l][t - off] : 0u;
+    uint32_t v[REDUCE_LEVELS];
+    for (int l = 0; l < REDUCE_LEVELS; ++l) v[l] = (t >= off) ? part[l][t - off] : 0u;
     __syncthreads();
-    for (int l = 0; l <= REDUCE_LEVELS; ++l) part[l][t] += v[l];
+    for (int l = 0; l < REDUCE_LEVELS; ++l) part[l][t] += v[l];
     __syncthreads();
   }
-  if (j < len) {                                                  // slot nb is the sentinel: total
-    offs[(size_t)w * len + j] = part[0][t] - own[0];
-    for (int l = 1; l <= REDUCE_LEVELS; ++l) segoff[((size_t)(l - 1) * W + w) * len + j] = part[l][t] - own[l];
+  if (j < len) {
+    segoff[((size_t)0 * W + w) * len + j] = part[0][t] - own[0];
+    for (int l = 1; l < REDUCE_LEVELS; ++l) segoff[((size_t)l * W + w) * len + j] = part[l][t] - own[l + 1];
   }
   if (t == 1023)
-    for (int l = 0; l <= REDUCE_LEVELS; ++l) tot[((size_t)w * nchunk + chunk) * (1 + REDUCE_LEVELS) + l] = part[l][1023];
+    for (int l = 0; l < REDUCE_LEVELS; ++l) tot2[((size_t)w * nchunk + chunk) * REDUCE_LEVELS + l] = part[l][1023];
 }
-__global__ void __launch_bounds__(1024) k_msm_scan2(uint32_t* offs, uint32_t* segoff, const uint32_t* tot, int nb, int W, int nchunk) {
+__global__ void __launch_bounds__(1024) k_msm_scan3(const uint32_t* offs, uint32_t* segoff, const uint32_t* tot2, int nb, int W, int nchunk,
+                                                    uint32_t* meta, WinInfo* winfo) {
   const int w = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk, t = threadIdx.x;
   const int len = nb + 1;
   const int j = chunk * 1024 + t;
+  if (blockIdx.x == 0 && t == 0) {                                // the windows' bases: lanes and non-empty buckets before each
+    const uint32_t L = meta[0];
+    uint32_t lane0 = 0, ne0 = 0;
+    for (int k = 0; k < W; ++k) {
+      const uint32_t lw = offs[(size_t)k * len + nb], lanes = (lw + L - 1) / L;
+      uint32_t ne = 0;
+      for (int cch = 0; cch < nchunk; ++cch) ne += tot2[((size_t)k * nchunk + cch) * REDUCE_LEVELS + 0];
+      winfo[k] = WinInfo{lw, lane0, ne0, lanes};
+      lane0 += lanes; ne0 += ne;
+    }
+    winfo[W] = WinInfo{0u, lane0, ne0, 0u};
+    meta[2] = lane0;
+  }
   if (chunk == 0 || j >= len) return;
-  uint32_t carry[1 + REDUCE_LEVELS];
-  for (int l = 0; l <= REDUCE_LEVELS; ++l) carry[l] = 0;
+  uint32_t carry[REDUCE_LEVELS];
+  for (int l = 0; l < REDUCE_LEVELS; ++l) carry[l] = 0;
   for (int k = 0; k < chunk; ++k)
-    for (int l = 0; l <= REDUCE_LEVELS; ++l) carry[l] += tot[((size_t)w * nchunk + k) * (1 + REDUCE_LEVELS) + l];
-  offs[(size_t)w * len + j] += carry[0];
-  for (int l = 1; l <= REDUCE_LEVELS; ++l) segoff[((size_t)(l - 1) * W + w) * len + j] += carry[l];
+    for (int l = 0; l < REDUCE_LEVELS; ++l) carry[l] += tot2[((size_t)w * nchunk + k) * REDUCE_LEVELS + l];
+  for (int l = 0; l < REDUCE_LEVELS; ++l) segoff[((size_t)l * W + w) * len + j] += carry[l];
 }
 
 // Placement in two levels.  Scattering straight into the nb (8193 at c = 14) bucket runs of a window keeps
@@ -535,57 +620,110 @@ __device__ __forceinline__ size_t msm_window_base(const uint32_t* so_all, int w,
   for (int k = 0; k < w; ++k) base += so_all[(size_t)k * (nb + 1) + nb];
   return base;
 }
-
-// One lane per seg-point segment of a bucket run (runs are Poisson-distributed around n / 2^(c-1);
-// one lane per whole bucket left lanes of a wave waiting for the longest run and quantised the
-// grid to ~1.1 residency rounds).  Lane gi finds its (window, bucket, segment), adds its <= seg cached points
-// (next record in flight while the current one is added) and writes one partial sum.
-__global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_segments(const uint32_t* pts, const uint32_t* idx, const uint32_t* offs, const uint32_t* segoff, size_t n, int W,
-               int nb, size_t max_segs, int seg, uint32_t* partial) {
+// The span partials of bucket b of window w (the closed form above): first slot and count.
+struct SpanPlan {
+  const uint32_t* offs;          // [W][nb + 1]
+  const uint32_t* ne;            // segoff level 0: non-empty buckets before b, within the window
+  const WinInfo* winfo;
+  uint32_t L;
+};
+__device__ __forceinline__ void span_partials_of(const SpanPlan& sp, int w, int b, int nb, size_t* first_slot, uint32_t* count) {
   const int len = nb + 1;
-  for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_segs; gi += (size_t)gridDim.x * BLOCK) {
-    int w, b;
-    uint32_t k;
-    size_t base;
-    if (!msm_locate(gi, segoff, W, nb, &w, &b, &k, &base)) break;   // beyond the last real segment
-    const uint32_t run_lo = offs[(size_t)w * len + b], run_hi = offs[(size_t)w * len + b + 1];
-    uint32_t lo = run_lo + k * (uint32_t)seg, hi = lo + (uint32_t)seg;
-    if (hi > run_hi) hi = run_hi;
-    ge acc = ge_identity();
-    if (lo < hi) {
-      uint32_t e = idx[(size_t)w * n + lo];
-      gea q = pt_load_affine(pts + (size_t)(e & 0x7FFFFFFFu) * AP_WORDS, (e >> 31) != 0);
-      const bool neg0 = (e >> 31) != 0;
-      const gea first = q;
-      if (lo + 1 < hi) {
-        e = idx[(size_t)w * n + lo + 1];
-        q = pt_load_affine(pts + (size_t)(e & 0x7FFFFFFFu) * AP_WORDS, (e >> 31) != 0);
-      }
-      acc = ge_from_cached_affine(first, neg0);
-#pragma unroll 1
-      for (uint32_t j = lo + 1; j < hi; ++j) {
-        const bool neg = (e >> 31) != 0;
-        const gea cur = q;
-        if (j + 1 < hi) {
-          e = idx[(size_t)w * n + j + 1];
-          q = pt_load_affine(pts + (size_t)(e & 0x7FFFFFFFu) * AP_WORDS, (e >> 31) != 0);
-        }
-        acc = ge_add_affine(acc, cur, neg, true);
-      }
+  const uint32_t o = sp.offs[(size_t)w * len + b], e = sp.offs[(size_t)w * len + b + 1];
+  if (e == o) { *first_slot = 0; *count = 0; return; }
+  const WinInfo wi = sp.winfo[w];
+  const uint32_t f = o / sp.L, l = (e - 1) / sp.L;
+  *first_slot = (size_t)wi.lane0 + wi.ne0 + sp.ne[(size_t)w * len + b] + f;
+  *count = l - f + 1;
+}
+
+// One lane per span of L consecutive sorted entries of a window (see THE SPANS above): mixed additions (7 products each),
+// the next record in flight while the current one is added, one partial sum stored per bucket the span touches.  A lane's
+// first point is lifted from its record (4 products); after a bucket boundary inside the span the sum restarts from the
+// identity with a full addition -- a branch there would have every wave that holds such a lane walk both paths.
+__global__ void __launch_bounds__(BLOCK, SEG_BLOCKS_PER_CU)
+k_msm_spans(const uint32_t* pts, const uint32_t* idx, SpanPlan sp, const uint32_t* meta, size_t n, int W, int nb, uint32_t* partial) {
+  const int len = nb + 1;
+  const uint32_t L = meta[0], lanes = meta[2];
+  for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < lanes; gi += (size_t)gridDim.x * BLOCK) {
+    int w = 0;
+    while (w + 1 < W && sp.winfo[w + 1].lane0 <= gi) ++w;
+    const WinInfo wi = sp.winfo[w];
+    const uint32_t pos = (uint32_t)(gi - wi.lane0) * L;
+    uint32_t end = pos + L;
+    if (end > wi.len) end = wi.len;
+    if (pos >= end) continue;                            // (cannot happen: a window has ceil(len / L) lanes)
+    const uint32_t* ow = sp.offs + (size_t)w * len;
+    int lo_b = 0, hi_b = nb;                             // the bucket that holds entry pos: the largest b with ow[b] <= pos
+    while (hi_b - lo_b > 1) {
+      const int mid = (lo_b + hi_b) >> 1;
+      if (ow[mid] <= pos) lo_b = mid; else hi_b = mid;
     }
-    pt_store_ext(partial + gi * PT_WORDS, acc);
+    int b = lo_b;
+    size_t slot = (size_t)gi + wi.ne0 + sp.ne[(size_t)w * len + b];
+    uint32_t bend = ow[b + 1];
+    const uint32_t* iw = idx + (size_t)w * n;
+    // One record ahead, RAW: at the top of a step the buffer's words (entry j, requested a whole addition ago) are turned
+    // into the cached point, the same registers are reloaded with entry j + 1 -- whose index was fetched an addition
+    // earlier -- and the index of entry j + 2 is fetched; then the addition.  Nothing in flight is copied or looked at
+    // before its turn.  (With the next record converted right behind its loads, as pt_load_affine does, the wave waited for
+    // every gather before the addition that was to hide it: s_waitcnt vmcnt(5) and eighteen v_cndmask in front of the products.)
+    uint32_t e_cur = iw[pos];
+    uint32_t e_nxt = iw[pos + 1 < end ? pos + 1 : end - 1];
+    gea_raw r = pt_load_affine_raw(pts + (size_t)(e_cur & 0x7FFFFFFFu) * AP_WORDS);
+    uint32_t j = pos;                                    // entries [pos, j) are in acc (or flushed); r holds entry j
+    ge acc;
+    {                                                    // the lane's first entry is lifted from its record (4 products)
+      const bool neg = (e_cur >> 31) != 0;
+      gea cur = gea_from_raw(r, neg);
+      gea_pin(cur);
+      e_cur = e_nxt;
+      const uint32_t* rec = pts + (size_t)(e_nxt & 0x7FFFFFFFu) * AP_WORDS;
+      // (unconditional, clamped to the span: loads under a branch leave the compiler's wait counters unknown at the join and
+      // it waits for everything; the index first: the loop's back edge needs it, not the record behind it)
+      e_nxt = iw[j + 2 < end ? j + 2 : end - 1];
+      r = pt_load_affine_raw(rec);
+      asm volatile("" ::: "memory");                     // ... and no load sinks below this line, to its first use after the addition
+      acc = ge_from_cached_affine(cur, neg);
+      ++j;
+    }
+#pragma unroll 1
+    while (true) {
+      if (j == bend || j == end) {                       // the bucket, or the span, ends here
+        pt_store_ext(partial + slot * PT_WORDS, acc);
+        if (j == end) break;
+        ++b;
+        while (ow[b + 1] <= j) ++b;                      // empty buckets in between (j < end <= ow[nb]: this stops)
+        bend = ow[b + 1];
+        ++slot;
+        acc = ge_identity();
+      }
+      const bool neg = (e_cur >> 31) != 0;
+      gea cur = gea_from_raw(r, neg);
+      gea_pin(cur);
+      e_cur = e_nxt;
+      const uint32_t* rec = pts + (size_t)(e_nxt & 0x7FFFFFFFu) * AP_WORDS;
+      // (unconditional, clamped to the span: loads under a branch leave the compiler's wait counters unknown at the join and
+      // it waits for everything; the index first: the loop's back edge needs it, not the record behind it)
+      e_nxt = iw[j + 2 < end ? j + 2 : end - 1];
+      r = pt_load_affine_raw(rec);
+      asm volatile("" ::: "memory");                     // ... and no load sinks below this line, to its first use after the addition
+      acc = ge_add_affine(acc, cur, neg, true);
+      ++j;
+    }
   }
 }
 
-// A further level of the same reduction: one lane per group of <= `red` partial sums of one bucket (so_in: prefix of
-// the partials per bucket, so_out: of the groups).  With random scalars a bucket has a handful of partials and one
-// level finishes it; with many equal scalars (all coefficients 1, say) a run holds most of the n points, and every
-// level cuts its partials by `red` instead of leaving them to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
+// A further level of the same reduction: one lane per group of <= `red` partial sums of one bucket (so_out: prefix of the
+// groups; the inputs of level 0 are the span partials, found by the closed form, those of later levels lie packed by
+// so_in).  With random scalars a bucket has a handful of partials and no level runs; with many equal scalars (all
+// coefficients 1, say) a run holds most of the n points, and every level cuts its partials by `red` instead of leaving them
+// to one lane of k_msm_buckets (245 ms at 2^20 equal scalars).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, int W, int nb, size_t max_groups, uint32_t* out,
-             int red, const uint32_t* lvlmax, int level, uint32_t skip) {
+k_msm_reduce(const uint32_t* in, SpanPlan sp, const uint32_t* so_in, const uint32_t* so_out, int W, int nb, size_t max_groups, uint32_t* out,
+             int red, const uint32_t* lvlmax, int level, uint32_t skip, const uint32_t* meta) {
   if (lvlmax[REDUCE_LEVELS * LVL_STRIDE + level] <= skip) return;   // every bucket is down to a few partials: k_msm_buckets adds those itself
+  sp.L = meta[0];
   const int len = nb + 1;
   for (size_t gi = (size_t)blockIdx.x * BLOCK + threadIdx.x; gi < max_groups; gi += (size_t)gridDim.x * BLOCK) {
     int w, b;
@@ -593,19 +731,28 @@ k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, 
     size_t base;
     if (!msm_locate(gi, so_out, W, nb, &w, &b, &k, &base, lvlmax + level * LVL_STRIDE, skip)) break;
     if (w < 0) continue;                              // a window whose buckets need no further level
-    const size_t in_base = msm_window_base(so_in, w, nb);
-    const uint32_t s0 = so_in[(size_t)w * len + b], s1 = so_in[(size_t)w * len + b + 1];
-    uint32_t lo = s0 + k * (uint32_t)red, hi = lo + (uint32_t)red;
-    if (hi > s1) hi = s1;
+    size_t lo, hi;
+    if (level == 0) {
+      size_t first;
+      uint32_t cnt;
+      span_partials_of(sp, w, b, nb, &first, &cnt);
+      lo = first + (size_t)k * (uint32_t)red; hi = lo + (uint32_t)red;
+      if (hi > first + cnt) hi = first + cnt;
+    } else {
+      const size_t in_base = msm_window_base(so_in, w, nb);
+      const uint32_t s0 = so_in[(size_t)w * len + b], s1 = so_in[(size_t)w * len + b + 1];
+      lo = in_base + s0 + (size_t)k * (uint32_t)red; hi = lo + (uint32_t)red;
+      if (hi > in_base + s1) hi = in_base + s1;
+    }
     ge acc = ge_identity();
     if (lo < hi) {                                       // a group of one is copied, not added to the identity
-      acc = pt_load_ext(in + (in_base + lo) * PT_WORDS);
+      acc = pt_load_ext(in + lo * PT_WORDS);
       ge nx = acc;
-      if (lo + 1 < hi) nx = pt_load_ext(in + (in_base + lo + 1) * PT_WORDS);
+      if (lo + 1 < hi) nx = pt_load_ext(in + (lo + 1) * PT_WORDS);
 #pragma unroll 1
-      for (uint32_t j = lo + 1; j < hi; ++j) {           // the next partial is in flight while this one is added
+      for (size_t j = lo + 1; j < hi; ++j) {             // the next partial is in flight while this one is added
         const ge cur = nx;
-        if (j + 1 < hi) nx = pt_load_ext(in + (in_base + j + 1) * PT_WORDS);
+        if (j + 1 < hi) nx = pt_load_ext(in + (j + 1) * PT_WORDS);
         acc = ge_add(acc, cur);
       }
     }
@@ -616,15 +763,12 @@ k_msm_reduce(const uint32_t* in, const uint32_t* so_in, const uint32_t* so_out, 
 // one lane per bucket: sum of what the last level that ran left of it (a few partials at most with random scalars).
 // Level l + 1 ran for window w iff lvlmax[(l - 1) * LVL_STRIDE + w] > skip; the levels that ran for a window are a prefix.
 struct MsmLevels {
-  const uint32_t* buf[REDUCE_LEVELS];                     // partial sums after level 1 (segments), 2, ...
+  const uint32_t* buf[REDUCE_LEVELS];                     // partial sums after level 1 (the spans), 2, ...
 };
-// A PAIR of lanes per bucket (BKT_LANES; a quad was measured too).  With random scalars a bucket is left with 4-30 partials (n / 2^(c-1) points in segments of 8-32;
-// the top window's runs are 1.7 times as long), and one lane per bucket walking them was the slowest way to add a million
-// points: 2.25 waves per SIMD of 7-15 dependent additions each, two generations on a kernel that holds two (129 us for
-// 1.03 M additions at 2^20, 2.4 times the time the segment sums take per addition; a reduction level in front of it costs
-// the same additions in the same shape).  Here lane q of the group sums the partials q, q + L, q + 2L, ... of the bucket, the
-// group adds its sums in one (pair) or two (quad) exchange steps (DPP quad_perm moves of the 36 limbs), and lane 0 stores:
-// shorter chains, more waves to fill the SIMDs with.
+// A PAIR of lanes per bucket (BKT_LANES; a quad was measured too): lane q of the group sums the partials q, q + L, q + 2L, ...
+// of the bucket, the group adds its sums in one (pair) or two (quad) exchange steps (DPP quad_perm moves of the 36 limbs),
+// and lane 0 stores: shorter chains, more waves to fill the SIMDs with.  (With segments of 8-32 points a bucket was left with
+// 4-30 partials and this kernel with a million additions; the spans leave 1 + size / L.)
 template <int P0, int P1, int P2, int P3>
 __device__ __forceinline__ ge ge_quad_perm(const ge& g) {
   ge r;
@@ -639,8 +783,10 @@ constexpr int BKT_LANES = D377_MSM_BUCKET_LANES;             // lanes that share
 constexpr int BKT_SHIFT = BKT_LANES == 4 ? 2 : 1;
 static_assert(BKT_LANES == 2 || BKT_LANES == 4, "a bucket is shared by a pair or a quad of lanes");
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_msm_buckets(MsmLevels lv, const uint32_t* segoff_all, const uint32_t* lvlmax, uint32_t skip, int W, int nb, uint32_t* buckets) {
+k_msm_buckets(MsmLevels lv, SpanPlan sp, const uint32_t* segoff_all, const uint32_t* lvlmax, uint32_t skip, int W, int nb, uint32_t* buckets,
+              const uint32_t* meta) {
   const int len = nb + 1;
+  sp.L = meta[0];
   const size_t total = (size_t)W * nb;                      // buckets = groups of BKT_LANES lanes
   const int q = threadIdx.x & (BKT_LANES - 1);
   const size_t nquads = ((size_t)gridDim.x * BLOCK) >> BKT_SHIFT;
@@ -654,18 +800,26 @@ k_msm_buckets(MsmLevels lv, const uint32_t* segoff_all, const uint32_t* lvlmax, 
     int last = 0;
     while (last + 1 < REDUCE_LEVELS && lvlmax[last * LVL_STRIDE + w] > skip) ++last;
     const uint32_t* partial = lv.buf[last];
-    const uint32_t* segoff = segoff_all + (size_t)last * W * len;
-    const size_t base = msm_window_base(segoff, w, nb);
-    const uint32_t s0 = segoff[(size_t)w * len + b] + (uint32_t)q, s1 = segoff[(size_t)w * len + b + 1];
+    size_t s0, s1;
+    if (last == 0) {
+      uint32_t cnt;
+      span_partials_of(sp, w, b, nb, &s0, &cnt);
+      s1 = s0 + cnt;
+    } else {
+      const uint32_t* segoff = segoff_all + (size_t)last * W * len;
+      const size_t base = msm_window_base(segoff, w, nb);
+      s0 = base + segoff[(size_t)w * len + b]; s1 = base + segoff[(size_t)w * len + b + 1];
+    }
+    s0 += (size_t)q;
     ge acc = ge_identity();
     if (s0 < s1) {
-      acc = pt_load_ext(partial + (base + s0) * PT_WORDS);
+      acc = pt_load_ext(partial + s0 * PT_WORDS);
       ge nx = acc;
-      if (s0 + BKT_LANES < s1) nx = pt_load_ext(partial + (base + s0 + BKT_LANES) * PT_WORDS);
+      if (s0 + BKT_LANES < s1) nx = pt_load_ext(partial + (s0 + BKT_LANES) * PT_WORDS);
 #pragma unroll 1
-      for (uint32_t j = s0 + BKT_LANES; j < s1; j += BKT_LANES) {   // the next partial is in flight while this one is added
+      for (size_t j = s0 + BKT_LANES; j < s1; j += BKT_LANES) {   // the next partial is in flight while this one is added
         const ge cur = nx;
-        if (j + BKT_LANES < s1) nx = pt_load_ext(partial + (base + j + BKT_LANES) * PT_WORDS);
+        if (j + BKT_LANES < s1) nx = pt_load_ext(partial + (j + BKT_LANES) * PT_WORDS);
         acc = ge_add(acc, cur);
       }
     }
@@ -869,13 +1023,21 @@ k_msm_wsum_block2(const uint32_t* buckets, int nb, int m, int nblk, uint32_t* no
 // The block nodes of one window -> S_w.  Levels m .. c-1 (none when one block covers the window), then Horner over the
 // bit-sums with the cooperative doubling / addition of the tail below.
 constexpr int WSB_THREADS = 512;
-constexpr int WSB_CAP0 = 32 * (WS_M + 2), WSB_CAP1 = 16 * (WS_M + 3);   // points after the first / second level at c = 14 (320, 176)
+// The two point buffers of k_msm_wsum_window (dynamic LDS): the level that merges the block nodes leaves 2^(depth-m-1) nodes
+// of m + 2 points, the next half as many of m + 3, and from there the levels shrink; the second buffer also carries the
+// depth + 1 row records of the Horner chain.  Depth 13 (14-bit windows): 160 + 88 points, 35 KB; depth 15 (16-bit): 640 + 352, 140 KB.
+inline int wsb_cap0(int depth, int m) { return depth > m ? (1 << (depth - m - 1)) * (m + 2) : m + 1; }
+inline int wsb_cap1(int depth, int m) {
+  int pts = depth > m + 1 ? (1 << (depth - m - 2)) * (m + 3) : 0;
+  const int rec = ((depth + 1) * RQ_WORDS + LP_WORDS - 1) / LP_WORDS;       // the Horner chain's records, in points
+  return pts > rec ? pts : rec;
+}
 __global__ void __launch_bounds__(WSB_THREADS)
-k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, uint32_t* sums) {
+k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, int cap0, int cap1, uint32_t* sums) {
   // c here: the DEPTH of the window's tree, log2 of its leaves (the window width less one: see the leaves' numbering above)
-  __shared__ uint32_t lds[(WSB_CAP0 + WSB_CAP1) * LP_WORDS];
+  extern __shared__ uint32_t lds[];
   const int w = blockIdx.x, t = threadIdx.x;
-  LdsPts X{lds, WSB_CAP0}, Y{lds + WSB_CAP0 * LP_WORDS, WSB_CAP1};
+  LdsPts X{lds, cap0}, Y{lds + (size_t)cap0 * LP_WORDS, cap1};
   const uint32_t* wn = nodes + (size_t)w * nblk * (WS_M + 1) * PT_WORDS;
   LdsPts cur = X, nxt = Y;
   if (c == m) {                                                // the block node is the window's node
@@ -959,7 +1121,8 @@ __device__ __forceinline__ void msm_emit_doubled(const ge& r, bool first, uint8_
 
 // Horner over the window sums S_w (lanes 0-3 of one wave), result as Element record and as encoding
 __global__ void __launch_bounds__(64, 1)
-k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, uint64_t* xyzt_out) {
+k_msm_final(SqrtTables T, const uint32_t* sums, WinShape ws, uint8_t* enc_out, uint64_t* xyzt_out) {
+  const int W = ws.W;
   if (blockIdx.x != 0) return;
   // cached forms of the window sums as row records, one lane each (W <= 63), then the chain in the lane-spread form
   // (row_ops.hpp): the running sum lies across the four rows of this wave, ~250 doublings at ~0.5 us instead of ~1 us on
@@ -975,6 +1138,7 @@ k_msm_final(SqrtTables T, const uint32_t* sums, int W, int c, uint8_t* enc_out, 
   bool negated = false;                                          // v holds minus the running sum
 #pragma unroll 1
   for (int w = W - 2; w >= 0; --w) {
+    const int c = ws.width(w);                                   // the running sum moves up by the width of the window it takes in
 #pragma unroll 1
     for (int j = 0; j < c; ++j) v = row::rq_double_neg(v, S, K);
     if (c & 1) negated = !negated;                               // an odd number of sign-folded doublings
@@ -1196,33 +1360,9 @@ int pick_window(const DeviceState& d, size_t n) {
   return (int)d.tuned(D377_TUNE_MSM_WINDOW, c);              // developer override: 4 .. 16 (>= 4: at most 63 windows, k_msm_final's table of cached sums)
 }
 
-// Points per segment lane.  The segment sums run in GENERATIONS of lanes -- k_msm_segments holds 4 waves per SIMD (128 VGPRs:
-// tests/test_codegen.py), 1 024 lanes per CU -- and a call waits for whole generations: at 2^18 points 16-point segments
-// are 366 000 lanes, two generations of 16 additions, and 32-point segments 194 000 lanes, one generation of 32 -- the
-// same additions, one generation's start-up and drain less (761 -> 741 us).  So: of the candidate lengths the one with the
-// least  generations x (length + ~2 additions of overhead per generation) [+ length / 2 when there are several],  with
-// lanes = buckets x (run length / length + 1/2)  (the last segment of a run is half full on average) against 0.8 of the
-// resident lanes (the run lengths scatter).  A fit to measurements, not a derivation: against fixed lengths, runs within 1 %
-// of each other (tools/msm_tune_sweep.py), best fixed length / this rule's: 2^16 8 / 8, 2^17 16 / 16 (582 against 602 us
-// with 8), 2^18 32 / 32 (741 against 758 with 16), 2^19 32-64 depending on the box / 64, 2^20 16 or 48 / 16, 2^21 16-32 / 24,
-// 2^22 32 / 32.  The window width decides the buckets, hence `c`.
-constexpr int SEG_BLOCKS_PER_CU = 4;
-int pick_seg(const DeviceState& d, size_t n, int W, int c) {
-  const double buckets = (double)W * (double)((size_t)1 << (c - 1)), run = (double)n * (double)W / buckets;
-  const double cap = 0.8 * (double)d.cus * SEG_BLOCKS_PER_CU * BLOCK;
-  static const int cand[] = {8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
-  int best = 8;
-  double best_cost = 0.0;
-  for (int s : cand) {
-    const double lanes = buckets * (run / s + 0.5);
-    double gens = lanes / cap;
-    gens = gens <= 1.0 ? 1.0 : (double)(size_t)(gens + 0.999999);
-    const double cost = gens * (s + 2.0) + (gens > 1.0 ? 0.5 * s : 0.0);   // (with generations behind it, a long last segment holds its wave's slot)
-    if (best_cost == 0.0 || cost < best_cost) { best = s; best_cost = cost; }
-  }
-  return (int)d.tuned(D377_TUNE_MSM_SEG, best);              // developer override (sweeps): 1 .. MAX_SEG
-}
-
+// Lanes of the span sums (k_msm_spans): as many as the device keeps resident at once -- what the runtime says the kernel's
+// registers allow (4 workgroups per CU at 128 VGPRs: tests/test_codegen.py) -- less one per window (a window's last lane
+// is part full).  k_msm_scan2 turns it into L = entries / lanes on the device, where the entries are known.
 int grid_of(const DeviceState& d, size_t n) {
   size_t blocks = (n + BLOCK - 1) / BLOCK;
   size_t cap = (size_t)d.cus * 32;
@@ -1297,7 +1437,8 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   if (n >= ((size_t)1 << 31)) return fail(D377_ERR_ARG, "%s", "msm: n must be below 2^31");
   if (n && n <= msm_small_max(d) && n < ((size_t)1 << 24)) return msm_launch_small(d, s, encoded, pts_in, scalars, n, enc_out, xyzt_out, status);
   const int c = pick_window(d, n);
-  const int W = (252 + c - 1) / c;
+  const WinShape wshape = win_shape(c);                      // W windows of c or c - 1 bits that tile the 252 scalar bits
+  const int W = wshape.W;
   const int nb = (1 << (c - 1)) + 1;                         // bucket indices 0 .. 2^(c-1)
   const int nchunks = (nb - 1 + CHUNK - 1) / CHUNK;
   // workspace carve-up
@@ -1316,11 +1457,26 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t o_bh = carve((size_t)W * S * nb * 4);
   const size_t o_off = carve((size_t)W * (nb + 1) * 4);
   const size_t o_seg = carve((size_t)REDUCE_LEVELS * W * (nb + 1) * 4);
+  const size_t o_bsz = carve((size_t)W * (nb + 1) * 4);
   const int scan_chunks = (nb + 1 + 1023) / 1024;
-  const size_t o_tot = carve((size_t)W * scan_chunks * (1 + REDUCE_LEVELS) * 4);
-  const int seg = pick_seg(d, n, W, c);
-  const size_t max_segs = ((size_t)n * W) / (size_t)seg + (size_t)W * nb;      // sum of ceil(run / seg) never exceeds this
-  // the level-1 index array of the sort (W * n words) borrows the segment partials' area, which is free until k_msm_segments
+  const size_t o_tot = carve((size_t)W * scan_chunks * 4);
+  const size_t o_tot2 = carve((size_t)W * scan_chunks * REDUCE_LEVELS * 4);
+  const size_t o_meta = carve(META_WORDS * sizeof(uint32_t));
+  const size_t o_winfo = carve((size_t)(W + 1) * sizeof(WinInfo));
+  // the span sums: lanes resident at once (asked once per device), entries per lane when a developer forces them
+  if (d.msm_span_blocks < 0) {
+    int nblk = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(k_msm_spans), BLOCK, 0));
+    d.msm_span_blocks = nblk < 1 ? 1 : (nblk > SEG_BLOCKS_PER_CU ? SEG_BLOCKS_PER_CU : nblk);
+  }
+  const size_t span_resident = (size_t)d.cus * d.msm_span_blocks * BLOCK;
+  const uint32_t lanes_target = (uint32_t)(span_resident - (size_t)W);
+  const uint32_t forced_L = (uint32_t)d.tuned(D377_TUNE_MSM_SEG, 0);             // developer override: entries per span lane
+  // partial slots: one per lane and one per non-empty bucket (a lane stores one partial per bucket its span touches)
+  const size_t span_lanes_max = forced_L ? ((size_t)n * W) / forced_L + (size_t)W + 1 : (((size_t)n * W) / SPAN_MIN + (size_t)W + 1 < span_resident
+                                                                                          ? ((size_t)n * W) / SPAN_MIN + (size_t)W + 1 : span_resident);
+  const size_t max_segs = span_lanes_max + (size_t)W * nb + 1;
+  // the level-1 index array of the sort (W * n words) borrows the span partials' area, which is free until k_msm_spans
   const size_t par_bytes = max_segs * PT_WORDS * 4, tmp_bytes = (size_t)W * n * 4;
   const size_t o_par = carve(par_bytes > tmp_bytes ? par_bytes : tmp_bytes);
   const size_t o_idx = carve((size_t)W * n * 4);
@@ -1345,9 +1501,9 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t m1 = (size_t)(nchunks + FOLD - 1) / FOLD, m2 = (m1 + FOLD - 1) / FOLD;
   const size_t o_f0 = carve((size_t)W * m1 * PT_WORDS * 4);
   const size_t o_f1 = carve((size_t)W * m2 * PT_WORDS * 4);
-  // weighted bucket sums by the pairwise tree (c <= 14: every width pick_window chooses); wider windows -- developer
-  // override only -- keep the chunked running sums
-  const bool tree = c <= 14 && d.tuned(D377_TUNE_MSM_CHUNKED_SUMS, 0) == 0;
+  // weighted bucket sums by the pairwise tree (every width: c <= 16); the chunked running sums remain as a developer
+  // override (D377_TUNE_MSM_CHUNKED_SUMS), the tree's cross-check
+  const bool tree = d.tuned(D377_TUNE_MSM_CHUNKED_SUMS, 0) == 0;
   // the tree's leaves are buckets 1 .. 2^(c-1) (bucket 0 is empty): depth c - 1, a whole number of blocks
   const int ws_depth = c - 1;
   const int ws_m = ws_depth < WS_M ? ws_depth : WS_M;        // >= 2: window widths start at 4 here
@@ -1363,7 +1519,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   uint32_t *bh = (uint32_t*)(m + o_bh), *offs = (uint32_t*)(m + o_off);
   uint32_t *segoff = (uint32_t*)(m + o_seg), *partial = (uint32_t*)(m + o_par);
   uint32_t* idx = (uint32_t*)(m + o_idx);
-  uint32_t* tmp_idx = partial;                                // free until k_msm_segments writes it
+  uint32_t* tmp_idx = partial;                                // free until k_msm_spans writes it
   uint8_t* tmp_sub = m + o_sub;
   uint32_t *bkt = (uint32_t*)(m + o_bkt), *ch = (uint32_t*)(m + o_ch), *f0 = (uint32_t*)(m + o_f0), *f1 = (uint32_t*)(m + o_f1);
   const SqrtTables T = d.tables();
@@ -1391,50 +1547,54 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
         const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)per_lane, d.dcb_sets * BLOCK, 0, d.pool_health};
         GuardScope vb{d.vb_guard, s};                       // the lane-set areas: queue behind their last user
         if ((rc = vb.acquire())) return rc;
-        hipLaunchKernelGGL(k_msm_prepare_enc_chunked, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, c, W,
+        hipLaunchKernelGGL(k_msm_prepare_enc_chunked, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, wshape,
                            pts, dig, status, dcb);
         if ((rc = vb.finish())) return rc;
       } else {
-        hipLaunchKernelGGL(k_msm_prepare_enc, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, c, W, pts,
+        hipLaunchKernelGGL(k_msm_prepare_enc, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, wshape, pts,
                            dig, status);
       }
     } else {
       uint32_t* zflag = (uint32_t*)(m + o_flag);
       HIP_TRY(hipMemsetAsync(zflag, 0, sizeof(uint32_t), s));
-      hipLaunchKernelGGL(k_msm_prepare_affine, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint64_t*)pts_in, scalars, n, c, W, pts,
+      hipLaunchKernelGGL(k_msm_prepare_affine, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint64_t*)pts_in, scalars, n, wshape, pts,
                          dig, zflag);
       // ~32 elements per lane share one inversion, but never fewer lanes than one wave per SIMD (see k_to_affine)
       size_t lanes = (n + 31) / 32;
       const size_t fill = (size_t)d.cus * BLOCK;
       if (lanes < fill) lanes = fill < n ? fill : n;
       hipLaunchKernelGGL(k_msm_prepare_el, dim3((unsigned)((lanes + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, (const uint64_t*)pts_in,
-                         scalars, n, c, W, pts, dig, zflag);
+                         scalars, n, wshape, pts, dig, zflag);
     }
   }
   hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
   uint32_t* tot = (uint32_t*)(m + o_tot);
   uint32_t* lvlmax = (uint32_t*)(m + o_lvl);
   HIP_TRY(hipMemsetAsync(lvlmax, 0, LVL_WORDS * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, segoff, tot, nb, S, W, scan_chunks, seg, red, lvlmax);
-  hipLaunchKernelGGL(k_msm_scan2, dim3(W * scan_chunks), dim3(1024), 0, s, offs, segoff, tot, nb, W, scan_chunks);
+  uint32_t *bsz = (uint32_t*)(m + o_bsz), *tot2 = (uint32_t*)(m + o_tot2), *meta = (uint32_t*)(m + o_meta);
+  WinInfo* winfo = (WinInfo*)(m + o_winfo);
+  hipLaunchKernelGGL(k_msm_scan1, dim3(W * scan_chunks), dim3(1024), 0, s, bh, offs, bsz, tot, nb, S, scan_chunks);
+  hipLaunchKernelGGL(k_msm_scan2, dim3(W * scan_chunks), dim3(1024), 0, s, offs, bsz, segoff, tot, tot2, nb, W, scan_chunks, lanes_target,
+                     forced_L, red, lvlmax, meta);
+  hipLaunchKernelGGL(k_msm_scan3, dim3(W * scan_chunks), dim3(1024), 0, s, offs, segoff, tot2, nb, W, scan_chunks, meta, winfo);
   hipLaunchKernelGGL(k_msm_place1, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
   hipLaunchKernelGGL(k_msm_place2, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
-  hipLaunchKernelGGL(k_msm_segments, dim3(grid_of(d, max_segs)), dim3(BLOCK), 0, s, pts, idx, offs, segoff, n, W, nb,
-                     max_segs, seg, partial);
+  const SpanPlan sp{offs, segoff, winfo, 0u};                  // (L travels in meta: the kernels read it there)
+  hipLaunchKernelGGL(k_msm_spans, dim3(grid_of(d, span_lanes_max)), dim3(BLOCK), 0, s, pts, idx, sp, meta, n, W, nb, partial);
   const size_t so_stride = (size_t)W * (nb + 1);
   MsmLevels lv;
   lv.buf[0] = partial;
   for (int l = 1; l < REDUCE_LEVELS; ++l) {
     uint32_t* r = (uint32_t*)(m + o_r[l]);
-    // (levels 3 and 4 only ever run for runs that hold most of the points: a small grid that strides, so that the launch that
+    // (the levels only ever run for runs that hold most of the points: a small grid that strides, so that the launch that
     // finds nothing to do costs a few hundred workgroups, not thousands)
     int gr = grid_of(d, max_g[l]);
-    if (l >= 2 && gr > d.cus * 4) gr = d.cus * 4;
-    hipLaunchKernelGGL(k_msm_reduce, dim3(gr), dim3(BLOCK), 0, s, lv.buf[l - 1], segoff + (size_t)(l - 1) * so_stride,
-                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax, l - 1, red.skip);
+    if (gr > d.cus * 4) gr = d.cus * 4;
+    hipLaunchKernelGGL(k_msm_reduce, dim3(gr), dim3(BLOCK), 0, s, lv.buf[l - 1], sp, segoff + (size_t)(l - 1) * so_stride,
+                       segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax, l - 1, red.skip, meta);
     lv.buf[l] = r;
   }
-  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb * BKT_LANES)), dim3(BLOCK), 0, s, lv, segoff, lvlmax, red.skip, W, nb, bkt);
+  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb * BKT_LANES)), dim3(BLOCK), 0, s, lv, sp, segoff, lvlmax, red.skip, W, nb, bkt, meta);
   const uint32_t* cur_in;
   if (tree) {
     uint32_t *nodes = (uint32_t*)(m + o_nodes), *sums = (uint32_t*)(m + o_sums);
@@ -1442,7 +1602,11 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
       hipLaunchKernelGGL(k_msm_wsum_block2, dim3(W * ws_nblk), dim3(WS2_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
     else
       hipLaunchKernelGGL(k_msm_wsum_block, dim3(W * ws_nblk), dim3(WS_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
-    hipLaunchKernelGGL(k_msm_wsum_window, dim3(W), dim3(WSB_THREADS), 0, s, nodes, ws_depth, ws_m, ws_nblk, sums);
+    const int cap0 = wsb_cap0(ws_depth, ws_m), cap1 = wsb_cap1(ws_depth, ws_m);
+    const size_t wsb_lds = (size_t)(cap0 + cap1) * LP_WORDS * sizeof(uint32_t);
+    if (wsb_lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_wsum_window), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsb_lds));
+    hipLaunchKernelGGL(k_msm_wsum_window, dim3(W), dim3(WSB_THREADS), wsb_lds, s, nodes, ws_depth, ws_m, ws_nblk, cap0, cap1, sums);
     cur_in = sums;
   } else {
     hipLaunchKernelGGL(k_msm_chunks, dim3(grid_of(d, (size_t)W * nchunks)), dim3(BLOCK), 0, s, bkt, W, nb, nchunks, ch);
@@ -1460,7 +1624,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
       cur_in = o; mcur = mout; which ^= 1;
     }
   }
-  hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, T, cur_in, W, c, enc_out, xyzt_out);
+  hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, T, cur_in, wshape, enc_out, xyzt_out);
   HIP_TRY(hipGetLastError());
   return held.finish();
 }

@@ -125,7 +125,7 @@ class Context:
         _native.check(self._lib.d377_ctx_starved_counter_dev(self._h, dev, ctypes.byref(p)))
 
         class _Word:
-            __cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (int(p.value), True), "version": 2}
+            __cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (int(p.value), False), "version": 2}
         return torch.as_tensor(_Word(), device=torch.device("cuda", self.device_ids[dev]))
 
     def _debug_poison_pool(self, dev=0, sets=-1):

@@ -560,7 +560,8 @@ def test_lane_set_pool_health_and_reset(torch_mod, oracle):
         while c.health()[1] == 0:
             assert time.time() - t0 < 8.0, "no workgroup reported a long wait"
             time.sleep(0.05)
-        assert c.health()[2] == 0                             # nobody has given up yet (10 s)
+        h = c.health()
+        assert h[2] == 0, (h, time.time() - t0)                # nobody has given up yet (10 s)
         freed = c.reset_scratch()                              # waits 1.5 s, sees the same tickets, frees them, waits for the kernel
         assert freed == sets_total, (freed, sets_total)
         torch.cuda.synchronize()

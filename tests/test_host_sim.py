@@ -513,7 +513,7 @@ print("BOUNDS_OK")
 
 
 def test_msm_bucket_chain_matches_oracle(sim, oracle):
-    """The per-lane chain of the MSM's bucket sums (msm.hip k_msm_segments / k_msm_reduce): cached affine records, the
+    """The per-lane chain of the MSM's bucket sums (msm.hip k_msm_spans / k_msm_reduce): cached affine records, the
     first point of a run converted instead of added to the identity, mixed additions, full additions of partial sums --
     the same group element as the oracle's fold, for every sign pattern of a short run."""
     rng = np.random.default_rng(29)

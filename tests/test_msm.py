@@ -178,7 +178,7 @@ def test_msm_on_elements_from_every_producer(ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window", [4, 5, 6, 7, 9, 12, 14, 16])
+@pytest.mark.parametrize("window", [4, 5, 6, 7, 9, 12, 13, 14, 15, 16])
 def test_msm_every_window_width(ctx, oracle, window):
     """Same inputs through different bucket widths (developer override) give the same bytes."""
     c = ctx
