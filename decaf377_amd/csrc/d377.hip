@@ -2002,7 +2002,7 @@ static bool tuning_range(int key, long long* lo, long long* hi) {
     // thresholds FROM which a route is taken: a huge value means never
     case D377_TUNE_DECOMPRESS_CHUNKED_MIN:
     case D377_TUNE_MSM_ENC_CHUNKED_MIN: *lo = 0; *hi = big; return true;
-    case D377_TUNE_FB_WIDE: case D377_TUNE_MSM_CHUNKED_SUMS: *lo = 0; *hi = 1; return true;
+    case D377_TUNE_FB_WIDE: case D377_TUNE_MSM_CHUNKED_SUMS: case D377_TUNE_MSM_SORT_PACKED: *lo = 0; *hi = 1; return true;
     case D377_TUNE_FB_K: *lo = 1; *hi = DCB_KMAX; return true;
     case D377_TUNE_AFFINE_BLOCKS_PER_CU: *lo = 1; *hi = 64; return true;
     case D377_TUNE_MSM_WINDOW: *lo = 4; *hi = 16; return true;

@@ -365,14 +365,17 @@ __global__ void __launch_bounds__(1024) k_msm_scan2(uint32_t* offs, const uint32
   const int len = nb + 1;
   const int j = chunk * 1024 + t;
   if (t < REDUCE_LEVELS) bmax[t] = 0;
-  if (t == 0) {                                                   // W x nchunk <= 63 x 33 words: every workgroup sums them itself
-    uint32_t E = 0, carry = 0;
-    for (int k = 0; k < W * nchunk; ++k) {
+  if (t == 0) { s_E = 0; s_carry = 0; }
+  __syncthreads();
+  {                                                               // W x nchunk <= 63 x 33 words: every workgroup sums them itself
+    uint32_t e = 0, cy = 0;
+    for (int k = t; k < W * nchunk; k += 1024) {
       const uint32_t v = tot[k];
-      E += v;
-      if (k / nchunk == w && k % nchunk < chunk) carry += v;
+      e += v;
+      if (k / nchunk == w && k % nchunk < chunk) cy += v;
     }
-    s_E = E; s_carry = carry;
+    if (e) atomicAdd(&s_E, e);
+    if (cy) atomicAdd(&s_carry, cy);
   }
   __syncthreads();
   const uint32_t E = s_E;
@@ -420,18 +423,25 @@ __global__ void __launch_bounds__(1024) k_msm_scan3(const uint32_t* offs, uint32
   const int w = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk, t = threadIdx.x;
   const int len = nb + 1;
   const int j = chunk * 1024 + t;
-  if (blockIdx.x == 0 && t == 0) {                                // the windows' bases: lanes and non-empty buckets before each
+  if (blockIdx.x == 0) {                                          // the windows' bases: lanes and non-empty buckets before each
+    __shared__ uint32_t s_len[64], s_lanes[64], s_ne[64];
     const uint32_t L = meta[0];
-    uint32_t lane0 = 0, ne0 = 0;
-    for (int k = 0; k < W; ++k) {
-      const uint32_t lw = offs[(size_t)k * len + nb], lanes = (lw + L - 1) / L;
+    if (t < W) {
+      const uint32_t lw = offs[(size_t)t * len + nb];
       uint32_t ne = 0;
-      for (int cch = 0; cch < nchunk; ++cch) ne += tot2[((size_t)k * nchunk + cch) * REDUCE_LEVELS + 0];
-      winfo[k] = WinInfo{lw, lane0, ne0, lanes};
-      lane0 += lanes; ne0 += ne;
+      for (int cch = 0; cch < nchunk; ++cch) ne += tot2[((size_t)t * nchunk + cch) * REDUCE_LEVELS + 0];
+      s_len[t] = lw; s_lanes[t] = (lw + L - 1) / L; s_ne[t] = ne;
     }
-    winfo[W] = WinInfo{0u, lane0, ne0, 0u};
-    meta[2] = lane0;
+    __syncthreads();
+    if (t == 0) {
+      uint32_t lane0 = 0, ne0 = 0;
+      for (int k = 0; k < W; ++k) {
+        winfo[k] = WinInfo{s_len[k], lane0, ne0, s_lanes[k]};
+        lane0 += s_lanes[k]; ne0 += s_ne[k];
+      }
+      winfo[W] = WinInfo{0u, lane0, ne0, 0u};
+      meta[2] = lane0;
+    }
   }
   if (chunk == 0 || j >= len) return;
   uint32_t carry[REDUCE_LEVELS];
@@ -534,6 +544,11 @@ __device__ __forceinline__ void tile_scatter(TileLds& L, size_t lo, size_t hi, i
   }
 }
 
+// PACKED (batches of up to 2^24 points): the level-1 entry is ONE word -- sign, the 7 bits of the bucket within its
+// super-bucket, 24 bits of point index -- instead of a word and a byte in two arrays (the byte stores came in runs of a few
+// dozen bytes: 5 bytes written and 5 read per entry became 4 and 4).
+constexpr size_t PACKED_MAX_POINTS = (size_t)1 << 24;
+template <bool PACKED>
 __global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const int16_t* digits, size_t n, int nb, int S, size_t per,
                                                              const uint32_t* blockhist, const uint32_t* offs,
                                                              uint32_t* tmp_idx, uint8_t* tmp_sub) {
@@ -552,13 +567,14 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const int16_t* digi
   __syncthreads();
   const size_t lo = (size_t)sl * per, hi = (lo + per < n) ? lo + per : n;
   const int16_t* dw = digits + (size_t)w * n;
-  tile_scatter<true>(L, lo, hi, nsuper,
+  tile_scatter<!PACKED>(L, lo, hi, nsuper,
                      [dw](size_t i) { return (uint64_t)(uint16_t)dw[i]; },
                      [](uint64_t raw, size_t i, uint32_t* pay, int* bin, uint32_t* sub) {
                        const int d = (int16_t)(uint16_t)raw;
                        if (d == 0) return false;
                        const int b = d < 0 ? -d : d;
                        *pay = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+                       if (PACKED) *pay |= (uint32_t)(b & (SUPER - 1)) << 24;
                        *bin = b >> SUPER_BITS;
                        *sub = (uint32_t)(b & (SUPER - 1));
                        return true;
@@ -567,6 +583,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const int16_t* digi
 }
 
 // workgroup (window, super-bucket): its entries are contiguous in tmp_*, at the positions the bucket runs will occupy
+template <bool PACKED>
 __global__ void __launch_bounds__(SORT_THREADS) k_msm_place2(const uint32_t* tmp_idx, const uint8_t* tmp_sub, size_t n, int nb,
                                                              const uint32_t* offs, uint32_t* idx) {
   __shared__ TileLds L;
@@ -579,10 +596,15 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place2(const uint32_t* tmp
   const uint32_t* ti = tmp_idx + (size_t)w * n;
   const uint8_t* ts = tmp_sub + (size_t)w * n;
   tile_scatter<false>(L, ow[first], ow[last], SUPER,
-                      [ti, ts](size_t i) { return (uint64_t)ti[i] | ((uint64_t)ts[i] << 32); },
+                      [ti, ts](size_t i) { return PACKED ? (uint64_t)ti[i] : ((uint64_t)ti[i] | ((uint64_t)ts[i] << 32)); },
                       [](uint64_t raw, size_t, uint32_t* pay, int* bin, uint32_t* sub) {
-                        *pay = (uint32_t)raw;
-                        *bin = (int)(raw >> 32);
+                        if (PACKED) {
+                          *pay = (uint32_t)raw & 0x80FFFFFFu;
+                          *bin = (int)(((uint32_t)raw >> 24) & (SUPER - 1));
+                        } else {
+                          *pay = (uint32_t)raw;
+                          *bin = (int)(raw >> 32);
+                        }
                         *sub = 0;
                         return true;
                       },
@@ -888,7 +910,9 @@ k_msm_fold(const uint32_t* in, int W, int m, int mout, uint32_t* out) {
 // The tree's LEAVES are the buckets 1 .. 2^(c-1), numbered from 0 (bucket 0 is always empty: digit 0 places nothing), so
 // the tree is c - 1 levels deep, a whole number of blocks, and S_w = sum_i (i + 1) L_i = sum_j 2^j V_j + T.  (Numbered
 // by bucket index it was 2^(c-1) + 1 leaves: a level, a Horner step and a block per window for the one top bucket.)
-constexpr int WS_M = 8;                          // at most 2^WS_M buckets per block workgroup
+constexpr int WS_M = 8;                          // 2^WS_M buckets per workgroup of k_msm_wsum_block / block2
+constexpr int WS_M8 = 9;                         // 2^WS_M8 per workgroup of k_msm_wsum_block8 (eight buckets per lane)
+constexpr int NODE_STRIDE = WS_M8 + 1;           // points per block node in global memory (a node of depth m uses m + 1)
 constexpr int WS_THREADS = 1 << (WS_M - 2);      // one wave: a lane takes FOUR buckets through levels 0 and 1 in registers
 constexpr int LP_WORDS = 4 * NL;
 struct LdsPts {
@@ -986,7 +1010,7 @@ k_msm_wsum_block(const uint32_t* buckets, int nb, int m, int nblk, uint32_t* nod
     __syncthreads();
     const LdsPts tmp = cur; cur = nxt; nxt = tmp;
   }
-  if (t <= m) pt_store_ext(nodes + (((size_t)w * nblk + blk) * (WS_M + 1) + t) * PT_WORDS, cur.load(t));
+  if (t <= m) pt_store_ext(nodes + (((size_t)w * nblk + blk) * NODE_STRIDE + t) * PT_WORDS, cur.load(t));
 }
 
 // The same with TWO waves per workgroup and two buckets per lane, for launches that leave every wave a SIMD of its own even so
@@ -1017,7 +1041,74 @@ k_msm_wsum_block2(const uint32_t* buckets, int nb, int m, int nblk, uint32_t* no
     __syncthreads();
     const LdsPts tmp = cur; cur = nxt; nxt = tmp;
   }
-  if (t <= m) pt_store_ext(nodes + (((size_t)w * nblk + blk) * (WS_M + 1) + t) * PT_WORDS, cur.load(t));
+  if (t <= m) pt_store_ext(nodes + (((size_t)w * nblk + blk) * NODE_STRIDE + t) * PT_WORDS, cur.load(t));
+}
+
+// EIGHT buckets per lane, 512 per one-wave workgroup, the levels in place: for the wide windows of large batches (c = 15, 16:
+// 2^14 or 2^15 leaves per window).  k_msm_wsum_block keeps two point buffers, 46 KB of LDS -- three workgroups per CU -- and at
+// c = 16 its 2 048 workgroups ran in 2.7 generations (190 us against 63 at c = 14).  Here a lane takes eight leaves through
+// levels 0-2 in registers (11 additions, at most five points live) and leaves the node's four points in LDS; the levels above
+// read their operands, wait for everybody, and write the merged nodes over them (a merged node is never longer than its two
+// halves): ONE buffer of 256 points, 36 KB, four workgroups per CU -- one wave per SIMD, 1 024 workgroups at c = 16 in one
+// generation.
+constexpr int WS8_THREADS = 64, WS8_CAP = 4 * WS8_THREADS;
+// level j in place: 2 * merges nodes of (j + 1) points -> merges nodes of (j + 2); at most two rounds of lanes
+__device__ __forceinline__ void wsum_level_inplace(LdsPts& buf, int j, int merges, int t) {
+  const int per = j + 1, total = merges * per;
+  ge r0 = ge_identity(), r1 = ge_identity(), c0 = ge_identity(), c1 = ge_identity();
+  const int l0 = t, l1 = t + WS8_THREADS;
+  const int mu0 = l0 / per, tt0 = l0 - mu0 * per, mu1 = l1 / per, tt1 = l1 - mu1 * per;
+  if (l0 < total) {
+    const ge a = buf.load((2 * mu0) * per + tt0), b = buf.load((2 * mu0 + 1) * per + tt0);
+    r0 = ge_add(a, b);
+    c0 = b;
+  }
+  if (l1 < total) {
+    const ge a = buf.load((2 * mu1) * per + tt1), b = buf.load((2 * mu1 + 1) * per + tt1);
+    r1 = ge_add(a, b);
+    c1 = b;
+  }
+  __syncthreads();                                             // every operand has been read
+  if (l0 < total) {
+    buf.store(mu0 * (per + 1) + tt0, r0);
+    if (tt0 == 0) buf.store(mu0 * (per + 1) + per, c0);        // V_j of the merged node = the right node's total
+  }
+  if (l1 < total) {
+    buf.store(mu1 * (per + 1) + tt1, r1);
+    if (tt1 == 0) buf.store(mu1 * (per + 1) + per, c1);
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(WS8_THREADS)
+k_msm_wsum_block8(const uint32_t* buckets, int nb, int m, int nblk, uint32_t* nodes) {
+  __shared__ uint32_t lds[WS8_CAP * LP_WORDS];
+  const int w = blockIdx.x / nblk, blk = blockIdx.x % nblk, t = threadIdx.x;
+  LdsPts A{lds, WS8_CAP};
+  {
+    const int b0 = (blk << m) + 8 * t + 1;                     // leaf i is bucket i + 1 (m == WS_M8 here: 8 x 64 leaves)
+    const uint32_t* src = buckets + ((size_t)w * nb + b0) * PT_WORDS;
+    auto leaf = [&](int i) { return b0 + i < nb ? pt_load_ext(src + (size_t)i * PT_WORDS) : ge_identity(); };
+    // T = sum of the eight, V_0 = odd leaves, V_1 = leaves 2 3 6 7, V_2 = leaves 4..7: 11 additions, leaves streamed
+    ge s, a23;
+    {
+      const ge p1 = leaf(1), p3 = leaf(3);
+      const ge o13 = ge_add(p1, p3);
+      const ge a01 = ge_add(leaf(0), p1);
+      a23 = ge_add(leaf(2), p3);
+      s = ge_add(a01, a23);
+      const ge p5 = leaf(5), p7 = leaf(7);
+      A.store(4 * t + 1, ge_add(o13, ge_add(p5, p7)));
+      const ge a45 = ge_add(leaf(4), p5), a67 = ge_add(leaf(6), p7);
+      A.store(4 * t + 2, ge_add(a23, a67));
+      const ge v2 = ge_add(a45, a67);
+      A.store(4 * t + 3, v2);
+      A.store(4 * t, ge_add(s, v2));
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int j = 3; j < m; ++j) wsum_level_inplace(A, j, WS8_THREADS >> (j - 2), t);
+  if (t <= m) pt_store_ext(nodes + (((size_t)w * nblk + blk) * NODE_STRIDE + t) * PT_WORDS, A.load(t));
 }
 
 // The block nodes of one window -> S_w.  Levels m .. c-1 (none when one block covers the window), then Horner over the
@@ -1038,7 +1129,7 @@ k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, int cap0, int c
   extern __shared__ uint32_t lds[];
   const int w = blockIdx.x, t = threadIdx.x;
   LdsPts X{lds, cap0}, Y{lds + (size_t)cap0 * LP_WORDS, cap1};
-  const uint32_t* wn = nodes + (size_t)w * nblk * (WS_M + 1) * PT_WORDS;
+  const uint32_t* wn = nodes + (size_t)w * nblk * NODE_STRIDE * PT_WORDS;
   LdsPts cur = X, nxt = Y;
   if (c == m) {                                                // the block node is the window's node
     if (t <= m) X.store(t, pt_load_ext(wn + (size_t)t * PT_WORDS));
@@ -1046,8 +1137,8 @@ k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, int cap0, int c
     const int per = m + 1, merges = 1 << (c - m - 1);         // level m, operands in global memory
     for (int l = t; l < merges * per; l += WSB_THREADS) {
       const int mu = l / per, tt = l - mu * per;
-      const ge a = 2 * mu < nblk ? pt_load_ext(wn + ((size_t)(2 * mu) * (WS_M + 1) + tt) * PT_WORDS) : ge_identity();
-      const ge b = 2 * mu + 1 < nblk ? pt_load_ext(wn + ((size_t)(2 * mu + 1) * (WS_M + 1) + tt) * PT_WORDS) : ge_identity();
+      const ge a = 2 * mu < nblk ? pt_load_ext(wn + ((size_t)(2 * mu) * NODE_STRIDE + tt) * PT_WORDS) : ge_identity();
+      const ge b = 2 * mu + 1 < nblk ? pt_load_ext(wn + ((size_t)(2 * mu + 1) * NODE_STRIDE + tt) * PT_WORDS) : ge_identity();
       X.store(mu * (per + 1) + tt, ge_add(a, b));
       if (tt == 0) X.store(mu * (per + 1) + per, b);
     }
@@ -1356,7 +1447,10 @@ int pick_window(const DeviceState& d, size_t n) {
   // bit-sums (two kernels whose depth is the window width) a wide window costs little even when most of its buckets are
   // empty, and fewer windows are fewer additions per point and fewer chains side by side (the Horner doublings are 252
   // either way).  So: 12 bits below 2^20 points, 14 from there.
-  const int c = n >= ((size_t)1 << 20) ? 14 : 12;
+  // Round 5 (span sums, the tree to 16 bits, windows of mixed widths: no ragged top), 14 / 15 / 16 bits, one box: 2^20 1575 /
+  // 1744 / 1734 us, 2^21 2844 / 2861 / 2959, 2^22 5585 / 5414 / 5299, 2^23 10713 / 10296 / 10013, 2^24 20966 / 20046 / 19203
+  // (profiles/r05_msm_window_sweep.txt): 16 bits from 3 x 2^20 points.
+  const int c = n >= ((size_t)3 << 20) ? 16 : (n >= ((size_t)1 << 20) ? 14 : 12);
   return (int)d.tuned(D377_TUNE_MSM_WINDOW, c);              // developer override: 4 .. 16 (>= 4: at most 63 windows, k_msm_final's table of cached sums)
 }
 
@@ -1506,9 +1600,11 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const bool tree = d.tuned(D377_TUNE_MSM_CHUNKED_SUMS, 0) == 0;
   // the tree's leaves are buckets 1 .. 2^(c-1) (bucket 0 is empty): depth c - 1, a whole number of blocks
   const int ws_depth = c - 1;
-  const int ws_m = ws_depth < WS_M ? ws_depth : WS_M;        // >= 2: window widths start at 4 here
+  // 512 leaves per workgroup (k_msm_wsum_block8) where 256 per workgroup would not fit the chip at once: three of those per CU
+  const bool ws8 = ws_depth >= WS_M8 && (size_t)W * ((size_t)1 << (ws_depth - WS_M)) > (size_t)d.cus * 3;
+  const int ws_m = ws8 ? WS_M8 : (ws_depth < WS_M ? ws_depth : WS_M);        // >= 2: window widths start at 4 here
   const int ws_nblk = 1 << (ws_depth - ws_m);
-  const size_t o_nodes = carve(tree ? (size_t)W * ws_nblk * (WS_M + 1) * PT_WORDS * 4 : 0);
+  const size_t o_nodes = carve(tree ? (size_t)W * ws_nblk * NODE_STRIDE * PT_WORDS * 4 : 0);
   const size_t o_sums = carve((size_t)W * PT_WORDS * 4);
   int rc;
   MsmHeld held{d.msm.guard, s, false};
@@ -1577,8 +1673,13 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   hipLaunchKernelGGL(k_msm_scan2, dim3(W * scan_chunks), dim3(1024), 0, s, offs, bsz, segoff, tot, tot2, nb, W, scan_chunks, lanes_target,
                      forced_L, red, lvlmax, meta);
   hipLaunchKernelGGL(k_msm_scan3, dim3(W * scan_chunks), dim3(1024), 0, s, offs, segoff, tot2, nb, W, scan_chunks, meta, winfo);
-  hipLaunchKernelGGL(k_msm_place1, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
-  hipLaunchKernelGGL(k_msm_place2, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
+  if (n <= PACKED_MAX_POINTS && d.tuned(D377_TUNE_MSM_SORT_PACKED, 1) != 0) {
+    hipLaunchKernelGGL(k_msm_place1<true>, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
+    hipLaunchKernelGGL(k_msm_place2<true>, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
+  } else {
+    hipLaunchKernelGGL(k_msm_place1<false>, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
+    hipLaunchKernelGGL(k_msm_place2<false>, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
+  }
   const SpanPlan sp{offs, segoff, winfo, 0u};                  // (L travels in meta: the kernels read it there)
   hipLaunchKernelGGL(k_msm_spans, dim3(grid_of(d, span_lanes_max)), dim3(BLOCK), 0, s, pts, idx, sp, meta, n, W, nb, partial);
   const size_t so_stride = (size_t)W * (nb + 1);
@@ -1598,7 +1699,9 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const uint32_t* cur_in;
   if (tree) {
     uint32_t *nodes = (uint32_t*)(m + o_nodes), *sums = (uint32_t*)(m + o_sums);
-    if ((size_t)2 * W * ws_nblk <= (size_t)d.cus * 4)          // two waves per block still leave every wave its own SIMD
+    if (ws8)
+      hipLaunchKernelGGL(k_msm_wsum_block8, dim3(W * ws_nblk), dim3(WS8_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
+    else if ((size_t)2 * W * ws_nblk <= (size_t)d.cus * 4)     // two waves per block still leave every wave its own SIMD
       hipLaunchKernelGGL(k_msm_wsum_block2, dim3(W * ws_nblk), dim3(WS2_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
     else
       hipLaunchKernelGGL(k_msm_wsum_block, dim3(W * ws_nblk), dim3(WS_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);

@@ -46,7 +46,7 @@ SQRT_ROOT = {"ark": 0, "arkworks": 0, "min_curve": 1}
 # D377_TUNE_* keys of d377_ctx_set_tuning (include/decaf377_amd.h, "Developer interface")
 TUNE_KEYS = {"small_max": 0, "decompress_chunked_min": 1, "fb_wide": 2, "fb_k": 3, "affine_blocks_per_cu": 4, "msm_window": 5,
              "msm_seg": 6, "msm_small_max": 7, "msm_slices": 8, "msm_red": 9, "msm_skip": 10, "msm_chunked_sums": 11,
-             "msm_enc_chunked_min": 12, "chunk_per_lane": 13, "msm_tiny_max": 14, "tiny_max": 15}
+             "msm_enc_chunked_min": 12, "chunk_per_lane": 13, "msm_tiny_max": 14, "tiny_max": 15, "msm_sort_packed": 16}
 SHARD_OPS = {"sqrt_ratio_zeta": 0, "decompress": 1, "compress": 2, "roundtrip": 3, "scalar_mul_base": 4,
              "scalar_mul_var": 5, "encode_to_curve": 6, "hash_to_curve": 7, "scalar_mul_var_element": 8,
              "scalar_mul_base_element": 9}

@@ -145,6 +145,8 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
  *   MSM_SEG                msm: sorted entries per span lane, 1..128 (built-in: entries / resident lanes, at least 8)
  *   MSM_SMALL_MAX          msm: batches up to this many points skip the buckets (0 = never)
  *   MSM_SLICES             msm: slices per window of the counting sort, 1..4096
+ *   MSM_SORT_PACKED        msm: 0 = the sort's level-1 entries as a word and a byte (the form batches above 2^24 points take), 1 = one
+ *                          packed word (refused above 2^24 points)
  *   MSM_RED / MSM_SKIP     msm: group size of the second reduction level (2..64) / leftovers a bucket lane sums itself (1..64)
  *   MSM_CHUNKED_SUMS       msm: 1 = weighted bucket sums by chunked running sums instead of the tree of bit-sums
  *   MSM_ENC_CHUNKED_MIN    msm_encoded: batches from this many points decode with shared inversions
@@ -170,7 +172,8 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
 #define D377_TUNE_CHUNK_PER_LANE 13
 #define D377_TUNE_MSM_TINY_MAX 14
 #define D377_TUNE_TINY_MAX 15
-#define D377_TUNE_COUNT 16
+#define D377_TUNE_MSM_SORT_PACKED 16
+#define D377_TUNE_COUNT 17
 #define D377_TUNE_DEFAULT (-1)
 int d377_ctx_set_tuning(d377_ctx* ctx, int key, int64_t value);
 int d377_ctx_get_tuning(d377_ctx* ctx, int key, int64_t* value);

@@ -195,9 +195,40 @@ def test_msm_every_window_width(ctx, oracle, window):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_n", [20, 22])
+def test_msm_sort_forms_and_span_lengths_agree(ctx, oracle):
+    """The counting sort's level-1 entries packed into one word (up to 2^24 points) or as a word and a byte (beyond), and the
+    span sums with a forced number of entries per lane (1, 3, 8, 57, 128: spans that end inside, at and across bucket and window
+    boundaries; the built-in rule is entries / resident lanes), with random, equal and short scalars: same bytes as the
+    oracle's fold."""
+    rng = np.random.default_rng(7051)
+    n = 20000
+    P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    ks = {"random": rng.integers(0, 256, (n, 32), dtype=np.uint8)}
+    ks["equal"] = np.tile(ks["random"][:1], (n, 1))
+    short = ks["random"].copy()
+    short[:, 8:] = 0                                              # 64-bit scalars: the upper windows hold nothing
+    ks["short"] = short
+    few = np.zeros((n, 32), np.uint8)
+    few[:, 0] = rng.integers(0, 3, n)                             # scalars 0, 1, 2: three buckets of one window, most entries dropped
+    ks["few"] = few
+    for name, k in ks.items():
+        want = bytes(oracle.msm(P, k, threads=8)[0])
+        with ctx.tuning(msm_small_max=0):
+            assert bytes(ctx.msm(P, k)[0]) == want, name
+            with ctx.tuning(msm_sort_packed=0):
+                assert bytes(ctx.msm(P, k)[0]) == want, name
+            for L in (1, 3, 8, 57, 128):
+                with ctx.tuning(msm_seg=L):
+                    assert bytes(ctx.msm(P, k)[0]) == want, (name, L)
+            with ctx.tuning(msm_window=16, msm_seg=5):
+                assert bytes(ctx.msm(P, k)[0]) == want, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [20, 22, 23, 24])
 def test_msm_full_size_properties(ctx, oracle, log_n):
-    """2^20 and 2^22 (the advertised size) points on the device path: (1) all points equal P ->
+    """2^20, 2^22 (the advertised size), 2^23 and 2^24 points on the device path (14-bit windows below 3 x 2^20 points, 16-bit
+    from there; above 2^24 points the sort's level-1 entries are no longer packed: not reached here): (1) all points equal P ->
     [sum k_i] P; (2) linearity: MSM(A u B) == MSM(A) + MSM(B); (3) a 2^14 prefix against the oracle fold."""
     import torch
     dev = torch.device("cuda:0")
