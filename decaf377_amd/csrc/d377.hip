@@ -287,24 +287,40 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtT
 // sum, so the encoding needs no third square root (curve.hpp, ge_dcb_from_jacobi_sum): 1.8e8 -> 2.5e8 /s at 2^20.  A pair
 // that hits the addition law's exceptional case (s1 s2 = +-1) goes the reference's way, Edwards addition and generic
 // compression, and enters the batch as a finished encoding; the branch is taken by a wave only if one of its lanes needs it.
-// (Out of line, and handed nothing but the pair's index: it maps both inputs again, in the reference's inversion-free form.
-// References to the caller's (s, t) values would put those in scratch memory for EVERY element -- 144 bytes of stores per
-// element on the hot path, which is what the first version did -- to save four square roots on a route no known input
-// takes.  What the compiler still spills is live state around the call, inside the branch.)
+// (Out of line, and handed nothing but the pair's input words BY VALUE: it maps both inputs again, in the reference's
+// inversion-free form.  References to the caller's (s, t) values would put those in scratch memory for EVERY element -- 144
+// bytes of stores per element on the hot path, which is what the first version did -- to save four square roots on a route
+// no known input takes.)
+struct Words8 { uint32_t w[8]; };
 template <class PT>
-__device__ __noinline__ void hash_exceptional_pair(SqrtTables T, PT pt, const uint8_t* r1, const uint8_t* r2, size_t i, uint32_t w[8]) {
-  uint32_t a[8];
+__device__ __noinline__ Words8 hash_exceptional_words(SqrtTables T, PT pt, Words8 a1, Words8 a2) {
   fe s1, t1, s2, t2, unused = fe_zero();
-  load32(r1, i, a);
-  ge_elligator_st(T, pt, fe_from_words_mod_order(a), &s1, &t1, &unused, false);
-  load32(r2, i, a);
-  ge_elligator_st(T, pt, fe_from_words_mod_order(a), &s2, &t2, &unused, false);
-  ge_compress(T, pt, ge_add(ge_from_jacobi_st(s1, t1), ge_from_jacobi_st(s2, t2)), w);
+  ge_elligator_st(T, pt, fe_from_words_mod_order(a1.w), &s1, &t1, &unused, false);
+  ge_elligator_st(T, pt, fe_from_words_mod_order(a2.w), &s2, &t2, &unused, false);
+  Words8 r;
+  ge_compress(T, pt, ge_add(ge_from_jacobi_st(s1, t1), ge_from_jacobi_st(s2, t2)), r.w);
+  return r;
 }
+template <class PT>
+__device__ __forceinline__ void hash_exceptional_pair(SqrtTables T, PT pt, const uint8_t* r1, const uint8_t* r2, size_t i, uint32_t w[8]) {
+  Words8 a1, a2;
+  load32(r1, i, a1.w);
+  load32(r2, i, a2.w);
+  const Words8 r = hash_exceptional_words(T, pt, a1, a2);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = r.w[k];
+}
+// The exceptional pair in the chunked kernel: NOT in the per-element loop (a call there made the compiler spill 22 VGPRs
+// around it and shaped the register allocation of the loop that every element walks).  An element that needs the route
+// enters the chunk's compressor as the neutral state, its two input records are parked in the records of the state's
+// numerators (slots 2, 3: read by the compressor for this element only, and its output is overwritten) -- the inputs
+// themselves may be gone by then: a caller may hash in place -- and after the chunk's encodings have been written the
+// lanes that flagged an element redo it the reference's way.  A wave enters only if one of its lanes flagged something.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTables T, const uint8_t* r1, const uint8_t* r2,
                                                          size_t n, uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();
   D377_DCB_BEGIN(out32);
+  uint32_t flagged = 0;                              // bit j: element j of the current chunk takes the exceptional route
   dcb_rounds<2, true>(n, io, pt,
     [&](size_t i, int j) {
       uint32_t w[8];
@@ -330,14 +346,32 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_hash_to_curve(SqrtTab
       exceptional |= (i & 3) == 3;                  // the debug build sends every fourth pair down the exceptional route, so that
                                                    // the GPU suite runs it (no input pair is known that takes it by itself)
 #endif
-      if (__any(exceptional)) {
-        uint32_t we[8];
-        hash_exceptional_pair(T, pt, r1, r2, i, we);
-        const dcb_state se = dcb_from_encoding_words(we);
-        st.p = fe_select(exceptional, se.p, st.p); st.w = fe_select(exceptional, se.w, st.w);
-        st.n0 = fe_select(exceptional, se.n0, st.n0); st.n1 = fe_select(exceptional, se.n1, st.n1);
-      }
+      const dcb_state ne = dcb_neutral();
+      st.p = fe_select(exceptional, ne.p, st.p); st.w = fe_select(exceptional, ne.w, st.w);
+      st.n0 = fe_select(exceptional, ne.n0, st.n0); st.n1 = fe_select(exceptional, ne.n1, st.n1);
       dcb_put(io, j, st);
+      if (exceptional) {                            // (a few loads and stores under a branch no known input takes)
+        flagged |= 1u << j;
+        load32(r1, i, w);
+        io.put(2, j, w);
+        load32(r2, i, w);
+        io.put(3, j, w);
+      }
+    },
+    [&](DcbIO& io2, int cnt) {
+      if (__any(flagged != 0)) {
+#pragma unroll 1
+        for (int j = 0; j < cnt; ++j) {
+          const bool mine = ((flagged >> j) & 1u) != 0;
+          if (!__any(mine)) continue;
+          Words8 a1, a2;
+          io2.get(2, j, a1.w);                      // (the other lanes of the wave: whatever their records hold -- any words are inputs)
+          io2.get(3, j, a2.w);
+          const Words8 r = hash_exceptional_words(T, pt, a1, a2);
+          if (mine) io2.emit(j, r.w);
+        }
+      }
+      flagged = 0;
     });
   D377_DCB_END();
 }

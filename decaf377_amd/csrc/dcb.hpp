@@ -117,8 +117,10 @@ __device__ __forceinline__ void dcb_release(const DcbScratch& sc, int slot) {
 // and at those batch sizes (n <= 2 x the resident lanes) its latency is the whole call.  SMALL_OK = false keeps a
 // kernel on the always-assisted form (k_scalar_mul_var: its codegen is left exactly as it was measured).
 constexpr int DCB_ASSIST_MIN = 3;
-template <int NINV, bool FINISH, bool SMALL_OK = true, class PT, class P0, class P1>
-__device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1) {
+// post(io, cnt): runs after a chunk's outputs have been written (a kernel's rare fix-ups: k_hash_to_curve).
+struct DcbNoPost { __device__ __forceinline__ void operator()(DcbIO&, int) const {} };
+template <int NINV, bool FINISH, bool SMALL_OK = true, class PT, class P0, class P1, class PF = DcbNoPost>
+__device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1, PF post = PF()) {
   constexpr int NW = NINV > 0 ? NINV : 1;
   // chunk c covers the elements from BLOCK x (c x per_lane + min(c, extra)): the first `extra` chunks are one round longer
 #ifdef D377_DCB_UNIFORM_AB                                                          // A/B only: round 3's loop (uniform chunks)
@@ -165,6 +167,7 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
       phase1(io.base + (size_t)j * BLOCK, j, cur, assist);
     }
     if (FINISH) dcb_finish(pt, io, cnt);
+    post(io, cnt);
   }
 }
 #define D377_DCB_BEGIN(out_ptr)                                                                   \

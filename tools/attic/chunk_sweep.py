@@ -2,7 +2,7 @@
 """Elements per lane per chunk (tuning key chunk_per_lane) for the chunked kernels at chosen sizes: us per call.  Dev tool.
 usage: python tools/chunk_sweep.py <log2n,...> [per_lane,...]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import decaf377_amd as d
 
