@@ -477,18 +477,38 @@ struct TileLds {
 // The tile's TILE_PER_THREAD loads of a thread are issued together, before anything looks at their values: with the load
 // inside the per-entry branch (as at first) each of the eight was its own dependent round trip to memory -- 15-24 us per
 // 8 192-entry tile (level 2: 290 -> 228 us at 2^22 with the loads hoisted).  cur[] holds the output cursors.
-template <bool HAS_SUB, class Load, class Decode>
+// AHEAD (level 1: sixteen and more tiles per workgroup): the next tile's loads before this tile's stores, stores
+// unconditional; without it (level 2: a super-bucket is two or three tiles) a tile fetches its own entries and only its
+// real entries are stored -- there the clamped repeats of a part-filled last tile cost more than the order saves (measured:
+// 155 -> 190 us at 2^22 with AHEAD, against 334 -> 250 us for level 1).
+template <bool HAS_SUB, bool AHEAD, class Load, class Decode>
 __device__ __forceinline__ void tile_scatter(TileLds& L, size_t lo, size_t hi, int nbins, Load load, Decode decode, uint32_t* out_idx, uint8_t* out_sub) {
   const int t = threadIdx.x;
+  if (lo >= hi) return;
+  // The NEXT tile's entries are requested before this tile's stores go out, and every access is unconditional (clamped to
+  // the range): the kernels spend three quarters of their wave cycles waiting for memory (SQ_WAIT_ANY 0.76 / 0.65 of
+  // SQ_WAVE_CYCLES, VALU busy 0.05: profiles/r05_stall_reasons_msm_2^22.txt), and a tile that starts by fetching its
+  // entries first waits for the previous tile's scattered stores to drain -- the wait counter is in order -- and then for its
+  // own loads.  With the loads ahead of the stores the counter lets the stores stay in flight.
+  uint64_t raw[TILE_PER_THREAD];
+  if (AHEAD) {
+#pragma unroll
+    for (int r = 0; r < TILE_PER_THREAD; ++r) {
+      const size_t i = lo + (size_t)r * SORT_THREADS + t;
+      raw[r] = load(i < hi ? i : hi - 1);
+    }
+  }
   for (size_t tile_lo = lo; tile_lo < hi; tile_lo += TILE) {
     uint32_t pay[TILE_PER_THREAD], rank[TILE_PER_THREAD];
     int bin[TILE_PER_THREAD];
     uint32_t sub[TILE_PER_THREAD];
-    uint64_t raw[TILE_PER_THREAD];
+    if (!AHEAD) {
+      // the tile's loads of a thread are issued together, before anything looks at their values
 #pragma unroll
-    for (int r = 0; r < TILE_PER_THREAD; ++r) {
-      const size_t i = tile_lo + (size_t)r * SORT_THREADS + t;
-      raw[r] = i < hi ? load(i) : 0;
+      for (int r = 0; r < TILE_PER_THREAD; ++r) {
+        const size_t i = tile_lo + (size_t)r * SORT_THREADS + t;
+        raw[r] = i < hi ? load(i) : 0;
+      }
     }
     // (Ranking the lanes of a wave that share a bin with one ballot per bin bit and a single LDS atomic per group was
     // built and measured: 318 -> 468 us and 228 -> 420 us for the two levels at 2^22 -- the returning atomics are not what
@@ -530,14 +550,37 @@ __device__ __forceinline__ void tile_scatter(TileLds& L, size_t lo, size_t hi, i
       }
     __syncthreads();
     const uint32_t total = L.total;
+    // the next tile's entries: in flight from here, across this tile's stores
+    const size_t next_lo = tile_lo + TILE;
+    if (AHEAD && next_lo < hi) {
 #pragma unroll
-    for (int r = 0; r < TILE_PER_THREAD; ++r) {
-      const uint32_t p = (uint32_t)r * SORT_THREADS + t;
-      if (p < total) {
-        const int b = L.bin[p];
-        const uint32_t dst = L.gbase[b] + (p - L.start[b]);
-        out_idx[dst] = L.idx[p];
-        if (HAS_SUB) out_sub[dst] = L.sub[p];
+      for (int r = 0; r < TILE_PER_THREAD; ++r) {
+        const size_t i = next_lo + (size_t)r * SORT_THREADS + t;
+        raw[r] = load(i < hi ? i : hi - 1);
+      }
+    }
+    if (AHEAD) {
+      if (total) {
+#pragma unroll
+        for (int r = 0; r < TILE_PER_THREAD; ++r) {
+          uint32_t p = (uint32_t)r * SORT_THREADS + t;
+          if (p >= total) p = total - 1;                            // (a repeat of the tile's last entry: the same word to the same place)
+          const int b = L.bin[p];
+          const uint32_t dst = L.gbase[b] + (p - L.start[b]);
+          out_idx[dst] = L.idx[p];
+          if (HAS_SUB) out_sub[dst] = L.sub[p];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < TILE_PER_THREAD; ++r) {
+        const uint32_t p = (uint32_t)r * SORT_THREADS + t;
+        if (p < total) {
+          const int b = L.bin[p];
+          const uint32_t dst = L.gbase[b] + (p - L.start[b]);
+          out_idx[dst] = L.idx[p];
+          if (HAS_SUB) out_sub[dst] = L.sub[p];
+        }
       }
     }
     __syncthreads();
@@ -567,7 +610,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const int16_t* digi
   __syncthreads();
   const size_t lo = (size_t)sl * per, hi = (lo + per < n) ? lo + per : n;
   const int16_t* dw = digits + (size_t)w * n;
-  tile_scatter<!PACKED>(L, lo, hi, nsuper,
+  tile_scatter<!PACKED, true>(L, lo, hi, nsuper,
                      [dw](size_t i) { return (uint64_t)(uint16_t)dw[i]; },
                      [](uint64_t raw, size_t i, uint32_t* pay, int* bin, uint32_t* sub) {
                        const int d = (int16_t)(uint16_t)raw;
@@ -595,7 +638,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place2(const uint32_t* tmp
   __syncthreads();
   const uint32_t* ti = tmp_idx + (size_t)w * n;
   const uint8_t* ts = tmp_sub + (size_t)w * n;
-  tile_scatter<false>(L, ow[first], ow[last], SUPER,
+  tile_scatter<false, false>(L, ow[first], ow[last], SUPER,
                       [ti, ts](size_t i) { return PACKED ? (uint64_t)ti[i] : ((uint64_t)ti[i] | ((uint64_t)ts[i] << 32)); },
                       [](uint64_t raw, size_t, uint32_t* pay, int* bin, uint32_t* sub) {
                         if (PACKED) {
