@@ -830,10 +830,8 @@ k_msm_reduce(const uint32_t* in, SpanPlan sp, const uint32_t* so_in, const uint3
 struct MsmLevels {
   const uint32_t* buf[REDUCE_LEVELS];                     // partial sums after level 1 (the spans), 2, ...
 };
-// A PAIR of lanes per bucket (BKT_LANES; a quad was measured too): lane q of the group sums the partials q, q + L, q + 2L, ...
-// of the bucket, the group adds its sums in one (pair) or two (quad) exchange steps (DPP quad_perm moves of the 36 limbs),
-// and lane 0 stores: shorter chains, more waves to fill the SIMDs with.  (With segments of 8-32 points a bucket was left with
-// 4-30 partials and this kernel with a million additions; the spans leave 1 + size / L.)
+// (With segments of 8-32 points a bucket was left with 4-30 partials and this kernel with a million additions -- a pair, and in
+// one experiment a quad, of lanes per bucket shortened its chains; the spans leave 1 + size / L.)
 template <int P0, int P1, int P2, int P3>
 __device__ __forceinline__ ge ge_quad_perm(const ge& g) {
   ge r;
@@ -841,25 +839,26 @@ __device__ __forceinline__ ge ge_quad_perm(const ge& g) {
   r.z = fe_quad_perm<P0, P1, P2, P3>(g.z); r.t = fe_quad_perm<P0, P1, P2, P3>(g.t);
   return r;
 }
-#ifndef D377_MSM_BUCKET_LANES
-#define D377_MSM_BUCKET_LANES 2
-#endif
-constexpr int BKT_LANES = D377_MSM_BUCKET_LANES;             // lanes that share a bucket: 2 (a pair) or 4 (a quad)
-constexpr int BKT_SHIFT = BKT_LANES == 4 ? 2 : 1;
-static_assert(BKT_LANES == 2 || BKT_LANES == 4, "a bucket is shared by a pair or a quad of lanes");
+// LANES = 2: a PAIR of lanes per bucket (lane q sums the partials q, q + 2, ...; one exchange step adds the two sums) -- for
+// buckets that are left with many partials.  LANES = 1: one lane per bucket, no exchange -- when the spans leave a bucket one
+// to three partials (L >= the run length: the usual case), where the pair's second lane and the exchange addition were more
+// work than the sum itself (118 -> ~45 us at 2^22, 58 -> ~35 at 2^20).  msm_launch chooses by the expected partials per bucket.
+template <int LANES>
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_buckets(MsmLevels lv, SpanPlan sp, const uint32_t* segoff_all, const uint32_t* lvlmax, uint32_t skip, int W, int nb, uint32_t* buckets,
               const uint32_t* meta) {
+  static_assert(LANES == 1 || LANES == 2, "a bucket is summed by one lane or by a pair");
+  constexpr int SHIFT = LANES == 2 ? 1 : 0;
   const int len = nb + 1;
   sp.L = meta[0];
-  const size_t total = (size_t)W * nb;                      // buckets = groups of BKT_LANES lanes
-  const int q = threadIdx.x & (BKT_LANES - 1);
-  const size_t nquads = ((size_t)gridDim.x * BLOCK) >> BKT_SHIFT;
-  // every quad of a wave takes the same number of trips: the DPP exchanges below need all four lanes of a quad active,
-  // so a quad past the end redoes the last bucket and does not store
-  const size_t trips = (total + nquads - 1) / nquads;
-  size_t gq = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> BKT_SHIFT;
-  for (size_t trip = 0; trip < trips; ++trip, gq += nquads) {
+  const size_t total = (size_t)W * nb;                      // buckets = groups of LANES lanes
+  const int q = threadIdx.x & (LANES - 1);
+  const size_t ngroups = ((size_t)gridDim.x * BLOCK) >> SHIFT;
+  // every pair of a wave takes the same number of trips: the DPP exchange below needs both lanes active, so a pair past the
+  // end redoes the last bucket and does not store
+  const size_t trips = (total + ngroups - 1) / ngroups;
+  size_t gq = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> SHIFT;
+  for (size_t trip = 0; trip < trips; ++trip, gq += ngroups) {
     const size_t gi = gq < total ? gq : total - 1;
     const int w = (int)(gi / nb), b = (int)(gi % nb);
     int last = 0;
@@ -880,16 +879,15 @@ k_msm_buckets(MsmLevels lv, SpanPlan sp, const uint32_t* segoff_all, const uint3
     if (s0 < s1) {
       acc = pt_load_ext(partial + s0 * PT_WORDS);
       ge nx = acc;
-      if (s0 + BKT_LANES < s1) nx = pt_load_ext(partial + (s0 + BKT_LANES) * PT_WORDS);
+      if (s0 + LANES < s1) nx = pt_load_ext(partial + (s0 + LANES) * PT_WORDS);
 #pragma unroll 1
-      for (size_t j = s0 + BKT_LANES; j < s1; j += BKT_LANES) {   // the next partial is in flight while this one is added
+      for (size_t j = s0 + LANES; j < s1; j += LANES) {   // the next partial is in flight while this one is added
         const ge cur = nx;
-        if (j + BKT_LANES < s1) nx = pt_load_ext(partial + (j + BKT_LANES) * PT_WORDS);
+        if (j + LANES < s1) nx = pt_load_ext(partial + (j + LANES) * PT_WORDS);
         acc = ge_add(acc, cur);
       }
     }
-    acc = ge_add(acc, ge_quad_perm<1, 0, 3, 2>(acc));        // neighbours: sums 0 + 1 (and 2 + 3)
-    if (BKT_LANES == 4) acc = ge_add(acc, ge_quad_perm<2, 3, 0, 1>(acc));   // every lane: the bucket
+    if (LANES == 2) acc = ge_add(acc, ge_quad_perm<1, 0, 3, 2>(acc));        // neighbours: sums 0 + 1
     if (q == 0 && gq < total) pt_store_ext(buckets + gi * PT_WORDS, acc);
   }
 }
@@ -1738,7 +1736,16 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
                        segoff + (size_t)l * so_stride, W, nb, max_g[l], r, red.g[l - 1], lvlmax, l - 1, red.skip, meta);
     lv.buf[l] = r;
   }
-  hipLaunchKernelGGL(k_msm_buckets, dim3(grid_of(d, (size_t)W * nb * BKT_LANES)), dim3(BLOCK), 0, s, lv, sp, segoff, lvlmax, red.skip, W, nb, bkt, meta);
+  {
+    // partials a bucket is left with when the scalars are random: 1 + its run / the entries per span lane
+    const double run = (double)n / (double)(nb - 1);
+    double Lest = forced_L ? (double)forced_L : (double)n * W / (double)lanes_target;
+    if (!forced_L && Lest < (double)SPAN_MIN) Lest = (double)SPAN_MIN;
+    if (1.0 + run / Lest <= 4.0)
+      hipLaunchKernelGGL(k_msm_buckets<1>, dim3(grid_of(d, (size_t)W * nb)), dim3(BLOCK), 0, s, lv, sp, segoff, lvlmax, red.skip, W, nb, bkt, meta);
+    else
+      hipLaunchKernelGGL(k_msm_buckets<2>, dim3(grid_of(d, (size_t)W * nb * 2)), dim3(BLOCK), 0, s, lv, sp, segoff, lvlmax, red.skip, W, nb, bkt, meta);
+  }
   const uint32_t* cur_in;
   if (tree) {
     uint32_t *nodes = (uint32_t*)(m + o_nodes), *sums = (uint32_t*)(m + o_sums);
