@@ -18,7 +18,7 @@ timeout 600 python3 bench.py > "$out/bench_line.json" 2> "$out/bench_line.err"
 echo "bench done: $(tail -c 300 "$out/bench_line.json" | head -c 120)"
 timeout 600 python3 tools/size_sweep.py > "$out/size_sweep.txt" 2>&1
 echo "sweep done"
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$out/msmtrace" -- python3 "$ROOT/tools/msm_profile.py" 8 12 16 18 20 22 > "$ROOT/$out/msmtrace.log" 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$ROOT/$out/msmtrace" -- python3 "$ROOT/tools/msm_profile.py" 8 12 16 18 20 22 24 > "$ROOT/$out/msmtrace.log" 2>&1)
 python3 tools/msm_breakdown.py "$(find "$out/msmtrace" -name '*kernel_trace.csv' | head -1)" > "$out/msm_kernel_breakdown.txt" 2>&1
 echo "msm breakdown done"
 bash tools/pmc_ops.sh "$out/pmc_ops20" "sqrt_ratio_zeta,decompress,compress,roundtrip,encode_to_curve,hash_to_curve,scalar_mul_base,msm (Elements)" 1048576 > "$out/pmc_ops_2^20.txt" 2>&1
@@ -38,7 +38,7 @@ echo "route stress: $(tail -1 "$out/route_stress.txt")"
 # arithmetic's microbenchmarks, clock against table traffic, the release check of the PMC record
 timeout 600 python3 tools/size_sweep.py --sizes 65536,77936,92682,110218,131072,155872,185364,220436,262144,311744,370728,440872,524288,623487,741455,881744,1048576 \
   --ops sqrt_ratio_zeta,encode_to_curve,hash_to_curve,scalar_mul_base,decompress,scalar_mul_var > "$out/size_sweep_quarter.txt" 2>&1
-timeout 600 python3 tools/size_sweep.py --sizes 16,256,1024,1025,4096,8192,11585,16384,23170,32768,46341,65536,92682,131072,185364,262144,370728,524288,1048576,4194304 \
+timeout 600 python3 tools/size_sweep.py --sizes 16,256,1024,1025,4096,8192,11585,16384,23170,32768,46341,65536,92682,131072,185364,262144,370728,524288,1048576,2097152,3145727,3145728,4194304,8388608,16777216 \
   --ops "msm (Elements),msm (Encodings)" > "$out/size_sweep_msm.txt" 2>&1
 mkdir -p build
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared tools/row_proto.hip -o build/row_proto.so > "$out/row_ops.txt" 2>&1
