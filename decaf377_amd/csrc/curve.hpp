@@ -1048,13 +1048,15 @@ D377_HD void fr_recode_signed256(const uint32_t k[8], int digits[32]) {
 }
 
 // [k]B from the shared table FB[i][j] = affine cached j * 2^(FB_BITS i) * B (i < FB_WINDOWS, j <= 2^(FB_BITS-1)):
-// FB_WINDOWS mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.  FB_BITS: 18 (14 windows x 131073 entries, 235 MB in
-// HBM), 16 (16 x 32769, 67 MB: inside the Infinity Cache), 14 (18 x 8193, 19 MB), 12 (21 x 2049, 5.5 MB) or, as at
-// first, 8 with FB_WINDOWS = 32 (528 KB); the static_asserts below say what a width has to satisfy.  With the square root gone the additions are the element, so the width pays: measured at
-// 2^20 scalars, 7.8e8/s with 12 bits, 8.6e8/s with 14 (same build), and 9.7e8 -> 11.2e8/s from 14 to 18 (the gathers of
-// 144-byte entries from HBM hide behind the previous addition).  The host simulation builds its tables with 12 or 8.
+// FB_WINDOWS mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.  FB_BITS: 21 (12 windows x 1 048 577 entries,
+// 1.6 GB in HBM: the default), 18 (14 x 131 073, 235 MB), 16 (16 x 32 769, 67 MB: inside the Infinity Cache), 14 (18 x 8 193,
+// 19 MB), 12 (21 x 2 049) or 8 (32 windows, 528 KB); the static_asserts below say what a width has to satisfy.  The
+// kernel is instruction-bound and its gathers are covered (profiles/r05_ab_fixed_base_raw_gather.txt), so every addition a
+// wider comb saves is time saved, cache or no cache: 12 / 14 / 18 bits 7.8 / 8.6 / 11.2e8 /s (rounds 2-3); 16 / 18: 18 ahead
+// by 7-8 % (r05_fixed_base_ab.txt); 18 / 20 / 21 bits at 2^20: 953 / 942 / 920 us, at 2^22: 3579 / 3530 / 3370 us
+// (r05_ab_fixed_base_wide.txt).  The host simulation builds its tables with 12 or 8.
 #ifndef D377_FB_BITS
-#define D377_FB_BITS 18
+#define D377_FB_BITS 21
 #endif
 constexpr int FB_BITS = D377_FB_BITS;
 constexpr int FB_WINDOWS = (252 + FB_BITS - 1) / FB_BITS;

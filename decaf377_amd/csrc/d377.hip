@@ -127,27 +127,64 @@ __global__ void __launch_bounds__(BLOCK) k_init_slookup(uint8_t* s_lookup, uint3
   }
 }
 
-// FB[i][j] = j * 2^(FB_BITS i) * B in affine cached form, i < FB_WINDOWS, j < FB_ENTRIES (one thread per entry)
-__global__ void __launch_bounds__(BLOCK) k_init_fbase(uint32_t* fb) {
-  const int idx = blockIdx.x * BLOCK + threadIdx.x;
-  if (idx >= FB_WINDOWS * FB_ENTRIES) return;
-  const int i = idx / FB_ENTRIES, j = idx % FB_ENTRIES;
-  ge pi = ge_generator();
+// FB[i][j] = j * 2^(FB_BITS i) * B in affine cached form, i < FB_WINDOWS, j < FB_ENTRIES.  A thread builds a RUN of
+// FB_RUN consecutive multiples of one window: j0 * base by double-and-add, then one addition of the base per entry; the
+// projective coordinates are parked in the entries' own records (27 limbs = a record's 27 words) and the run's Z's are
+// inverted together (Montgomery's trick: one divsteps inversion per FB_RUN entries).  ~9 000 instructions per entry;
+// one thread per entry with its own ladder from B and its own inversion was ~420 000 at 21-bit windows (12.6 M entries).
+constexpr int FB_RUN = 16;
+__global__ void k_init_fbase_bases(uint32_t* bases) {          // bases[i] = 2^(FB_BITS i) * B as X, Y, Z, T: one thread
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  ge p = ge_generator();
 #pragma unroll 1
-  for (int k = 0; k < FB_BITS * i; ++k) pi = ge_double(pi);
+  for (int i = 0; i < FB_WINDOWS; ++i) {
+    slot_store(bases + (size_t)i * 4 * SLOT, p.x); slot_store(bases + (size_t)i * 4 * SLOT + SLOT, p.y);
+    slot_store(bases + (size_t)i * 4 * SLOT + 2 * SLOT, p.z); slot_store(bases + (size_t)i * 4 * SLOT + 3 * SLOT, p.t);
+#pragma unroll 1
+    for (int k = 0; k < FB_BITS; ++k) p = ge_double(p);
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_init_fbase(const uint32_t* bases, uint32_t* fb) {
+  constexpr int RUNS = (FB_ENTRIES + FB_RUN - 1) / FB_RUN;
+  const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (idx >= (size_t)FB_WINDOWS * RUNS) return;
+  const int i = (int)(idx / RUNS), j0 = (int)(idx % RUNS) * FB_RUN;
+  ge base;
+  base.x = slot_load(bases + (size_t)i * 4 * SLOT); base.y = slot_load(bases + (size_t)i * 4 * SLOT + SLOT);
+  base.z = slot_load(bases + (size_t)i * 4 * SLOT + 2 * SLOT); base.t = slot_load(bases + (size_t)i * 4 * SLOT + 3 * SLOT);
   ge acc = ge_identity();
 #pragma unroll 1
-  for (int b = FB_BITS - 1; b >= 0; --b) {
+  for (int b = FB_BITS - 1; b >= 0; --b) {                     // acc = j0 * base
     acc = ge_double(acc);
-    if ((j >> b) & 1) acc = ge_add(acc, pi);
+    if ((j0 >> b) & 1) acc = ge_add(acc, base);
   }
-  const fe zi = fe_invert(acc.z);
-  const fe x = fe_mul(acc.x, zi), y = fe_mul(acc.y, zi);
-  gea c;
-  c.ypx = fe_carry(fe_add(y, x));
-  c.ymx = fe_sub(y, x);
-  c.kt = fe_mul(fe_mul(fe_const(FE_K), x), y);
-  pt_store_affine(fb + (size_t)idx * FBW_ENTRY_WORDS, c);
+  uint32_t* rec0 = fb + ((size_t)i * FB_ENTRIES + j0) * FBW_ENTRY_WORDS;
+  fe prefix[FB_RUN];
+  fe c = fe_const(FE_ONE);
+#pragma unroll
+  for (int r = 0; r < FB_RUN; ++r) {
+    if (j0 + r < FB_ENTRIES) {
+      uint32_t* q = rec0 + (size_t)r * FBW_ENTRY_WORDS;
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { q[k] = acc.x.l[k]; q[NL + k] = acc.y.l[k]; q[2 * NL + k] = acc.z.l[k]; }
+      prefix[r] = c;
+      c = fe_mul(c, acc.z);
+      acc = ge_add(acc, base);
+    }
+  }
+  fe inv = fe_invert(c);
+#pragma unroll
+  for (int r = FB_RUN - 1; r >= 0; --r) {
+    if (j0 + r < FB_ENTRIES) {
+      uint32_t* q = rec0 + (size_t)r * FBW_ENTRY_WORDS;
+      fe X, Y, Z;
+#pragma unroll
+      for (int k = 0; k < NL; ++k) { X.l[k] = q[k]; Y.l[k] = q[NL + k]; Z.l[k] = q[2 * NL + k]; }
+      const fe zi = fe_mul(inv, prefix[r]);
+      inv = fe_mul(inv, Z);
+      pt_store_affine(q, gea_from_affine(fe_mul(X, zi), fe_mul(Y, zi)));
+    }
+  }
 }
 
 // --------------------------------------------------------------------------- batch kernels ---
@@ -1270,7 +1307,13 @@ int grid_for(const DeviceState& d, size_t n) {
 int init_tables(DeviceState& d, uint32_t* keys, int* coll) {
   hipLaunchKernelGGL(k_init_gtab, dim3(6), dim3(BLOCK), 0, d.stream, d.gtab);
   hipLaunchKernelGGL(k_init_slookup, dim3(1), dim3(BLOCK), 0, d.stream, d.s_lookup, keys, coll);
-  hipLaunchKernelGGL(k_init_fbase, dim3((FB_WINDOWS * FB_ENTRIES + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, d.stream, d.fbase);
+  {
+    // the window bases go through the first words of the lane-set scratch (free until the first batch call)
+    uint32_t* bases = reinterpret_cast<uint32_t*>(d.dcb_scratch);
+    hipLaunchKernelGGL(k_init_fbase_bases, dim3(1), dim3(64), 0, d.stream, bases);
+    const size_t runs = (size_t)FB_WINDOWS * ((FB_ENTRIES + FB_RUN - 1) / FB_RUN);
+    hipLaunchKernelGGL(k_init_fbase, dim3((unsigned)((runs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, bases, d.fbase);
+  }
   HIP_TRY(hipGetLastError());
   int h_coll = -1;
   HIP_TRY(hipMemcpyAsync(&h_coll, coll, sizeof(int), hipMemcpyDeviceToHost, d.stream));

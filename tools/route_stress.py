@@ -50,11 +50,11 @@ def main():
     # variable base, both forms
     cnt = 0
     for n in sizes(1, 3 * one_gen, [16, one_gen, 7 * cus * 16, 8 * cus * 16]):
-        with ctx.tuning(small_max=10**9, tiny_max=0):
+        with ctx.tuning(small_max=1 << 24, tiny_max=0):
             q = ctx.scalar_mul_var(enc_all[:n], k[:n])
             qe = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
         if n <= 2500:                                              # one wave per element, forced beyond its size
-            with ctx.tuning(small_max=10**9, tiny_max=10**9):
+            with ctx.tuning(small_max=1 << 24, tiny_max=1 << 24):
                 qw = ctx.scalar_mul_var(enc_all[:n], k[:n])
                 qwe = ctx.compress(ctx.scalar_mul_var_element(P_all[:n], k[:n]))
             if not (torch.equal(qw[0], q[0]) and torch.equal(qw[1], q[1]) and torch.equal(qwe, qe)):
@@ -76,11 +76,11 @@ def main():
     # MSM, both input forms
     bad0, cnt = bad, 0
     for n in sizes(1, 5 * one_gen, [16, 17, 128 * 16, one_gen]):
-        with ctx.tuning(msm_small_max=10**9, msm_tiny_max=0):
+        with ctx.tuning(msm_small_max=1 << 24, msm_tiny_max=0):
             a = bytes(ctx.msm(P_all[:n], k[:n])[0])
             ae = ctx.msm(enc_all[:n], k[:n])
         if n <= 3000:                                              # one wave per point (lane-spread arithmetic), forced beyond its size
-            with ctx.tuning(msm_small_max=10**9, msm_tiny_max=10**9):
+            with ctx.tuning(msm_small_max=1 << 24, msm_tiny_max=1 << 24):
                 aw = bytes(ctx.msm(P_all[:n], k[:n])[0])
                 awe = ctx.msm(enc_all[:n], k[:n])
             if aw != a or bytes(awe[0]) != bytes(ae[0]) or not torch.equal(torch.as_tensor(awe[2]), torch.as_tensor(ae[2])):
@@ -124,7 +124,7 @@ def main():
         if n > 6000:
             continue
         res = []
-        for kv in (dict(small_max=0), dict(tiny_max=0, small_max=10**9), dict(tiny_max=10**9)):   # lanes, quads (fixed base), waves
+        for kv in (dict(small_max=0), dict(tiny_max=0, small_max=1 << 24), dict(tiny_max=1 << 24)):   # lanes, quads (fixed base), waves
             with ctx.tuning(**kv):
                 P, st = ctx.decompress(enc_all[:n])
                 res.append([ctx.scalar_mul_base(k[:n]), *ctx.sqrt_ratio_zeta(r0[:n], r1[:n]), *ctx.sqrt_ratio_zeta(r0[:n], r1[:n], root="min_curve"),
