@@ -10,14 +10,14 @@
 #
 # Options ("config / flags"):
 #   ARCH              offload architecture (gfx950; the kernels are written for nothing else)
-#   FB_BITS           comb width of the fixed-base table: 21 (default), 18, 16, 14, 12 or 8   -> -DD377_FB_BITS
+#   FB_BITS           comb width of the fixed-base table: 23 (default: 5.9 GB), 21 (1.6 GB), 18 (235 MB), 16, 14, 12 or 8   -> -DD377_FB_BITS
 #   DCB_K             elements per lane per batched inversion: 8 (default), 4, 16      -> -DD377_DCB_K
 #   WAVES_PER_SIMD    occupancy the chunked kernels are built for: 2 (default)         -> -DD377_WAVES_PER_SIMD
 #   CHECK_INVARIANTS  1: curve-equation checks on the device in the product library too
 #   EXTRA             further -D flags (A/B builds: tools/build_variant.sh)
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
-FB_BITS ?= 21
+FB_BITS ?= 23
 DCB_K ?= 8
 WAVES_PER_SIMD ?= 2
 CHECK_INVARIANTS ?= 0

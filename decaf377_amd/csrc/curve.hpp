@@ -1048,15 +1048,16 @@ D377_HD void fr_recode_signed256(const uint32_t k[8], int digits[32]) {
 }
 
 // [k]B from the shared table FB[i][j] = affine cached j * 2^(FB_BITS i) * B (i < FB_WINDOWS, j <= 2^(FB_BITS-1)):
-// FB_WINDOWS mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.  FB_BITS: 21 (12 windows x 1 048 577 entries,
-// 1.6 GB in HBM: the default), 18 (14 x 131 073, 235 MB), 16 (16 x 32 769, 67 MB: inside the Infinity Cache), 14 (18 x 8 193,
-// 19 MB), 12 (21 x 2 049) or 8 (32 windows, 528 KB); the static_asserts below say what a width has to satisfy.  The
-// kernel is instruction-bound and its gathers are covered (profiles/r05_ab_fixed_base_raw_gather.txt), so every addition a
-// wider comb saves is time saved, cache or no cache: 12 / 14 / 18 bits 7.8 / 8.6 / 11.2e8 /s (rounds 2-3); 16 / 18: 18 ahead
-// by 7-8 % (r05_fixed_base_ab.txt); 18 / 20 / 21 bits at 2^20: 953 / 942 / 920 us, at 2^22: 3579 / 3530 / 3370 us
-// (r05_ab_fixed_base_wide.txt).  The host simulation builds its tables with 12 or 8.
+// FB_WINDOWS mixed additions, no doublings.  FTab::load(i, j, swap) -> gea.  FB_BITS: 23 (11 windows x 4 194 305 entries,
+// 5.9 GB in HBM: the default -- 2 % of the device's 288 GB), 21 (12 x 1 048 577, 1.6 GB), 18 (14 x 131 073, 235 MB), 16 (16 x
+// 32 769, 67 MB: inside the Infinity Cache), 14, 12 or 8 (32 windows, 528 KB); the static_asserts below say what a width has
+// to satisfy.  The kernel is instruction-bound and its gathers are covered (profiles/r05_ab_fixed_base_raw_gather.txt), so
+// every addition a wider comb saves is time saved, cache or no cache: 12 / 14 / 18 bits 7.8 / 8.6 / 11.2e8 /s (rounds 2-3);
+// 16 / 18: 18 ahead by 7-8 % (r05_fixed_base_ab.txt); 18 / 20 / 21 / 23 bits at 2^20: 953 / 942 / 920 / 864 us, at 2^22:
+// 3579 / 3530 / 3370 / 3156 us (r05_ab_fixed_base_wide.txt).  The next step down in windows (10) would be 26 bits: 43 GB.
+// The host simulation builds its tables with 12 or 8.
 #ifndef D377_FB_BITS
-#define D377_FB_BITS 21
+#define D377_FB_BITS 23
 #endif
 constexpr int FB_BITS = D377_FB_BITS;
 constexpr int FB_WINDOWS = (252 + FB_BITS - 1) / FB_BITS;
@@ -1066,7 +1067,7 @@ constexpr int FB_ENTRIES = (1 << (FB_BITS - 1)) + 1;
 // the widths that tile the 252 bits (18, 14, 12) and for ragged tops (8: 32 windows; 16: 16 windows, 11 bits in the last).
 constexpr unsigned long long FB_R_TOP = 0x4aad95ull;                        // r >> 228
 constexpr int FB_TOP_BIT = FB_BITS * (FB_WINDOWS - 1);
-static_assert(FB_BITS >= 4 && FB_BITS <= 21 && FB_TOP_BIT >= 228 && FB_BITS * FB_WINDOWS >= 252, "comb width");
+static_assert(FB_BITS >= 4 && FB_BITS <= 23 && FB_TOP_BIT >= 228 && FB_BITS * FB_WINDOWS >= 252, "comb width");
 static_assert((FB_R_TOP >> (FB_TOP_BIT - 228)) + 1 < (1ull << (FB_BITS - 1)), "the top digit of a scalar below r must not carry out");
 // signed digit i of k (FB_BITS wide), with the running carry of the recoding
 D377_HD int fb_digit(const uint32_t k[8], int i, uint32_t& carry) {

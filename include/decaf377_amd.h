@@ -80,8 +80,9 @@ const char* d377_last_error(void);
 
 /* Builds the read-only device tables (Sarkar square-root tables of
  * src/ark_curve/invsqrt.rs:14-66, fixed-base table of Element::GENERATOR) once per device
- * and allocates the per-device scratch (about 2.4 GB of HBM per device: window tables, the records of the
- * batched inversions, the 1.6 GB fixed-base comb of 21-bit windows).  device_ids == NULL, n_dev == 0 -> device 0. */
+ * and allocates the per-device scratch (about 6.7 GB of HBM per device: window tables, the records of the
+ * batched inversions, the 5.9 GB fixed-base comb of 23-bit windows; `make lib FB_BITS=18` builds a 235 MB comb that
+ * is 9-12 % slower on the fixed-base multiplication).  device_ids == NULL, n_dev == 0 -> device 0. */
 int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out);
 void d377_ctx_destroy(d377_ctx* ctx);
 int d377_ctx_num_devices(const d377_ctx* ctx);
