@@ -1267,9 +1267,10 @@ D377_HD fe dcb_get_inv(const IO& io, int slot, int j) {
   io.get(slot, j, w);
   return fe_from_words(w);
 }
-template <class IO>
-D377_HD void dcb_invert_slot(IO& io, int slot, int cnt) {
-  if (cnt <= 0) return;
+// `invert`: fe -> fe, the inversion of the lane's product.  A lane without elements (cnt = 0) still takes part with the
+// product 1: the device passes an inversion that the whole wave does together (row_ops.hpp fe_invert_lanes).
+template <class IO, class INV>
+D377_HD void dcb_invert_slot_with(IO& io, int slot, int cnt, INV invert) {
   uint32_t w[8];
   fe c = fe_const(FE_ONE);
 #pragma unroll 1
@@ -1279,7 +1280,7 @@ D377_HD void dcb_invert_slot(IO& io, int slot, int cnt) {
     io.get(slot, j, w);
     c = fe_mul_strict(c, fe_from_words(w));
   }
-  fe inv = fe_invert(c);
+  fe inv = invert(c);
 #pragma unroll 1
   for (int j = cnt - 1; j >= 0; --j) {
     io.get(DCB_TMP_SLOT, j, w);
@@ -1290,14 +1291,18 @@ D377_HD void dcb_invert_slot(IO& io, int slot, int cnt) {
     io.put(slot, j, w);
   }
 }
+template <class IO>
+D377_HD void dcb_invert_slot(IO& io, int slot, int cnt) {
+  if (cnt <= 0) return;
+  dcb_invert_slot_with(io, slot, cnt, [](const fe& c) { return fe_invert(c); });
+}
 
 // (Fetching the next element's records ahead of the current one's work, here and in the round driver, was measured
 // and bought nothing: the waits are already covered.)
 // `invert`: fe -> fe, the inversion of the one product (fe_invert in a lane; the one-wave kernels pass the whole wave's,
 // row_ops.hpp fe_invert_wave)
 template <class IO, class INV>
-D377_HD void dcb_finish_with(IO& io, int cnt, INV invert) {
-  if (cnt <= 0) return;
+D377_HD void dcb_finish_with(IO& io, int cnt, INV invert) {       // (cnt = 0: the lane only takes part in `invert`)
   uint32_t w[8];
   fe c = fe_const(FE_ONE);
 #pragma unroll 1
@@ -1326,6 +1331,7 @@ D377_HD void dcb_finish_with(IO& io, int cnt, INV invert) {
 template <class PT, class IO>
 D377_HD void dcb_finish(PT& pt, IO& io, int cnt) {
   (void)pt;
+  if (cnt <= 0) return;
   dcb_finish_with(io, cnt, [](const fe& c) { return fe_invert(c); });
 }
 // one element's encoding from its state and 1 / p (what the loop above does per element, on values instead of records)

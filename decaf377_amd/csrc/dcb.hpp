@@ -7,6 +7,7 @@
 
 #include "curve.hpp"
 #include "device_util.hpp"
+#include "row_ops.hpp"
 
 namespace d377 {
 
@@ -155,7 +156,13 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
     }
     if (assist) {
 #pragma unroll 1
-      for (int sl = 0; sl < NINV; ++sl) dcb_invert_slot(io, sl, cnt);
+      for (int sl = 0; sl < NINV; ++sl) {
+#if defined(D377_DCB_LANE_INVERSIONS)                  // A/B: every lane its own divsteps inversion (rounds 2-4)
+        dcb_invert_slot(io, sl, cnt);
+#else                                                  // one inversion per WAVE (row_ops.hpp fe_invert_lanes); all lanes are here
+        dcb_invert_slot_with(io, sl, cnt, [](const fe& c) { return row::fe_invert_lanes(c); });
+#endif
+      }
     }
 #pragma unroll 1
     for (int j = 0; j < cnt; ++j) {
@@ -166,7 +173,11 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
       }
       phase1(io.base + (size_t)j * BLOCK, j, cur, assist);
     }
+#if defined(D377_DCB_LANE_INVERSIONS)
     if (FINISH) dcb_finish(pt, io, cnt);
+#else
+    if (FINISH) dcb_finish_with(io, cnt, [](const fe& c) { return row::fe_invert_lanes(c); });
+#endif
     post(io, cnt);
   }
 }

@@ -425,6 +425,34 @@ __device__ __forceinline__ fe fe_invert_wave_impl(const fe& x_own, uint32_t* dbg
 }
 __device__ __forceinline__ fe fe_invert_wave(const fe& x_own) { return fe_invert_wave_impl<false>(x_own, nullptr); }
 
+// 1 / c for EVERY lane of a full wave out of ONE inversion: the lanes' values are multiplied up a butterfly (six exchange
+// steps: after step l a lane holds the product of its block of 2^(l+1) lanes, and keeps the sibling block's product), the
+// total -- the same residue in every lane -- is inverted by the wave together (fe_invert_wave: 17 us on a lone wave against
+// 31 us for the lane's own divsteps, and the 64 lanes used to run 64 of those side by side), and on the way back
+// 1 / (my block) = 1 / (parent block) x (sibling block).  12 products, 54 exchanged words and one wave inversion per lane
+// instead of ~26 000 instructions of divsteps: the chunked kernels pay one such inversion per lane per 8 (fixed base: 16)
+// elements and per batched-inversion pass, 4-10 % of their time.  Values must be non-zero (the callers store 1 for a
+// zero); every lane of the wave must be here.
+__device__ __forceinline__ fe fe_shfl_xor(const fe& x, int mask) {
+  fe r = x;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) r.l[k] = (uint32_t)__shfl_xor((int)x.l[k], mask, 64);
+  return r;
+}
+__device__ __forceinline__ fe fe_invert_lanes(const fe& c) {
+  fe sib[6];
+  fe p = c;
+#pragma unroll
+  for (int l = 0; l < 6; ++l) {
+    sib[l] = fe_shfl_xor(p, 1 << l);
+    p = fe_mul(p, sib[l]);
+  }
+  fe inv = fe_invert_wave(p);                          // (lane 0's product; every lane's is the same residue)
+#pragma unroll
+  for (int l = 5; l >= 0; --l) inv = fe_mul(inv, sib[l]);
+  return inv;
+}
+
 // ---- between the two forms (whole field elements in a lane, Montgomery 9 x 29 <-> plain 10 x 28 across a row) --------
 // one lane writes an element as a row record (16 words, canonical value, limbs 10..15 zero) / reads a tight record back as
 // a product: curve.hpp fe_to_limbs28 / fe_from_limbs28 (whole-element code, so the host build checks its bounds)
