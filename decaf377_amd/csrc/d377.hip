@@ -1047,7 +1047,7 @@ constexpr int AFFINE_PER_LANE = 32;
 // instead of 12, 0.62 -> see profiles/README.md.)
 __global__ void __launch_bounds__(BLOCK) k_to_affine(const uint64_t* xyzt, size_t n, uint64_t* xy) {
   const size_t T = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (t >= n) return;
+  const bool live = t < n;                                  // (a lane without elements still takes part in the wave's inversion)
   const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
   uint8_t* o = reinterpret_cast<uint8_t*>(xy);
   uint32_t* slots = reinterpret_cast<uint32_t*>(xy);       // 16 words per element
@@ -1055,8 +1055,8 @@ __global__ void __launch_bounds__(BLOCK) k_to_affine(const uint64_t* xyzt, size_
   // are requested before the current element's products start, so the chain does not wait for memory at every step.
   fe p = fe_const(FE_ONE);
   size_t last = t;
-  uint32_t zn[8];
-  load32(b, 4 * t + 2, zn);
+  uint32_t zn[8] = {};
+  if (live) load32(b, 4 * t + 2, zn);
   for (size_t i = t; i < n; i += T) {
     uint32_t zw[8];
 #pragma unroll
@@ -1068,7 +1068,8 @@ __global__ void __launch_bounds__(BLOCK) k_to_affine(const uint64_t* xyzt, size_
     p = fe_mul(p, z);
     last = i;
   }
-  fe inv = fe_mul(fe_invert(p), fe_const(FE_TO_MONT256));
+  fe inv = fe_mul(row::fe_invert_lanes(p), fe_const(FE_TO_MONT256));   // one inversion per wave (row_ops.hpp)
+  if (!live) return;
   uint32_t xn[8], yn[8];
   load32(b, 4 * last + 2, zn);
   load32(b, 4 * last + 0, xn);
@@ -1133,6 +1134,27 @@ __global__ void __launch_bounds__(BLOCK) k_fq_op(int op, const uint64_t* a, cons
     }
     store32(reinterpret_cast<uint8_t*>(out), i, o);
     if (status) status[i] = (uint8_t)st;
+  }
+}
+// Fq::inverse on a batch (src/fields/fq/u64/wrapper.rs:104-112): ONE inversion per wave and trip (row_ops.hpp fe_invert_lanes:
+// 12 products and a share of the wave's inversion per element instead of the lane's own ~26 000 instructions of divsteps).
+// A zero has no inverse: zero record, status 1; it enters the wave's product as 1.
+__global__ void __launch_bounds__(BLOCK) k_fq_inv(const uint64_t* a, size_t n, uint64_t* out, uint8_t* status) {
+  const uint8_t* ab = reinterpret_cast<const uint8_t*>(a);
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  for (size_t base = (size_t)blockIdx.x * BLOCK; base < n; base += stride) {     // (uniform per workgroup: every lane is in the wave's inversion)
+    const size_t i = base + threadIdx.x;
+    const bool live = i < n;
+    uint32_t w[8] = {}, o[8];
+    if (live) load32(ab, i, w);
+    const fe x = fe_from_mont256_words(w);
+    const bool zero = !live || fe_is_zero(x);
+    const fe r = row::fe_invert_lanes(fe_select(zero, fe_const(FE_ONE), x));
+    fe_to_mont256_words(fe_select(zero, fe_zero(), r), o);
+    if (live) {
+      store32(reinterpret_cast<uint8_t*>(out), i, o);
+      if (status) status[i] = zero ? 1 : 0;
+    }
   }
 }
 __global__ void __launch_bounds__(BLOCK) k_fq_from_bytes_checked(const uint8_t* in, size_t n, uint64_t* out, uint8_t* status) {
@@ -1650,8 +1672,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     }
     case OP_FQ_BIN:
     case OP_FQ_UN:
-      hipLaunchKernelGGL(k_fq_op, dim3(g), dim3(BLOCK), 0, s, aux, (const uint64_t*)in0, (const uint64_t*)in1, n,
-                         (uint64_t*)out0, (uint8_t*)out1);
+      if (op == OP_FQ_UN && aux == D377_FQ_INVERSE)
+        hipLaunchKernelGGL(k_fq_inv, dim3(g), dim3(BLOCK), 0, s, (const uint64_t*)in0, n, (uint64_t*)out0, (uint8_t*)out1);
+      else
+        hipLaunchKernelGGL(k_fq_op, dim3(g), dim3(BLOCK), 0, s, aux, (const uint64_t*)in0, (const uint64_t*)in1, n,
+                           (uint64_t*)out0, (uint8_t*)out1);
       break;
     case OP_FQ_CHECKED:
       hipLaunchKernelGGL(k_fq_from_bytes_checked, dim3(g), dim3(BLOCK), 0, s, (const uint8_t*)in0, n, (uint64_t*)out0, (uint8_t*)out1);

@@ -215,7 +215,7 @@ k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinSha
                  const uint32_t* flag) {
   if (*flag == 0) return;
   const size_t Tn = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (t >= n) return;
+  const bool live = t < n;                               // (a lane without points still takes part in the wave's inversion)
   const uint8_t* b = reinterpret_cast<const uint8_t*>(xyzt);
   // The coordinates are used as they lie in memory (curve.hpp, "normalize_batch on raw records"): the words of z * 2^256
   // taken as limbs are z * 2^-5 in the internal radix, the powers of two the prefix products collect cancel in
@@ -232,7 +232,8 @@ k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinSha
     p = fe_mul(p, z);
     last = i;
   }
-  fe inv = fe_invert(p);
+  fe inv = row::fe_invert_lanes(p);                      // one inversion per wave (row_ops.hpp)
+  if (!live) return;
   for (size_t i = last;; i -= Tn) {
     uint32_t w[8];
     bool zz;

@@ -1695,23 +1695,24 @@ def test_bench_self_launches_its_ranks():
                        cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
-    assert line["parity_sample_ok"] is True and line["parity_sample_per_rank"] == 256
-    assert line["config"]["elements_total"] == 2 << 16 and line["value"] > 0
+    ctx_msg = lines[0][:4000]                      # (a failed check below shows the line it was made on)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak", ctx_msg
+    assert line["parity_sample_ok"] is True and line["parity_sample_per_rank"] == 256, ctx_msg
+    assert line["config"]["elements_total"] == 2 << 16 and line["value"] > 0, ctx_msg
     # one invocation carries everything a multi-GPU node can give: the weak headline, BASELINE configs[3] as written
     # (2^log2n in total, and from rank 0 with the scatter / gather timed), configs[4] at its total size, the CPU leg
     ex = line["extra"]
     strong, root, ell = ex["strong_2^16_total"], ex["from_root"], ex["encode_to_curve_2^20_total"]
-    assert strong["elements_total"] == 1 << 16 and strong["elements_per_rank"] == [1 << 15, 1 << 15]
-    assert len(strong["kernel_ms_per_rank"]) == 2 and all(v > 0 for v in strong["kernel_ms_per_rank"]) and strong["value"] > 0
-    assert root["elements_total"] == 1 << 16 and root["collective_ms"] > 0 and root["parity_sample_ok"] and strong["parity_sample_ok"]
-    assert root["ms_per_step"] >= root["collective_ms"] and len(root["kernel_ms_per_rank"]) == 2
-    assert ell["elements_total"] == 1 << 16 and len(ell["kernel_ms_per_rank"]) == 2 and ell["parity_sample_ok"] and ell["value"] > 0
+    assert strong["elements_total"] == 1 << 16 and strong["elements_per_rank"] == [1 << 15, 1 << 15], ctx_msg
+    assert len(strong["kernel_ms_per_rank"]) == 2 and all(v > 0 for v in strong["kernel_ms_per_rank"]) and strong["value"] > 0, ctx_msg
+    assert root["elements_total"] == 1 << 16 and root["collective_ms"] > 0 and root["parity_sample_ok"] and strong["parity_sample_ok"], ctx_msg
+    assert root["ms_per_step"] >= root["collective_ms"] and len(root["kernel_ms_per_rank"]) == 2, ctx_msg
+    assert ell["elements_total"] == 1 << 16 and len(ell["kernel_ms_per_rank"]) == 2 and ell["parity_sample_ok"] and ell["value"] > 0, ctx_msg
     cb = line["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["matches_gpu_output"] is True and cb["value"] > 0 and cb["cores"] >= 1
-    assert line["roofline"]["kernel"] == "k_scalar_mul_var" and "encodes_per_sec" in ex
+    assert cb["kind"] == "port" and cb["matches_gpu_output"] is True and cb["value"] > 0 and cb["cores"] >= 1, ctx_msg
+    assert line["roofline"]["kernel"] == "k_scalar_mul_var" and "encodes_per_sec" in ex, ctx_msg
 
 
 def test_multigpu_selftest_tool():
