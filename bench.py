@@ -483,7 +483,7 @@ def main():
         # vartime_multiscalar_mul (Pippenger MSM), 2^20 Elements -> one Encoding
         pm, _ = ctx.decompress(enc1)
         ker, _ = time_op(torch, lambda: ctx.msm(pm, scalars[:ne]), 3, 1)
-        msm_w = 18 if ne >= (1 << 20) else None             # 14-bit windows from 2^20 points, 16-bit (16 windows) from 3 x 2^20 (msm.hip pick_window)
+        msm_w = 18 if ne >= (1 << 20) else None             # 14-bit windows from 2^19 points, 16-bit (16 windows) from 3 x 2^20 (msm.hip pick_window)
         extra["msm_2^20"] = {"n": ne, "ms": ker, "per_sec": ne / (ker * 1e-3)}
         if msm_w:
             extra["msm_2^20"]["roofline_valu"] = valu_view(msm_w * MSM_MACS_PER_ADDITION, ne, ker)

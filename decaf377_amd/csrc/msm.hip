@@ -1492,7 +1492,9 @@ int pick_window(const DeviceState& d, size_t n) {
   // Round 5 (span sums, the tree to 16 bits, windows of mixed widths: no ragged top), 14 / 15 / 16 bits, one box: 2^20 1575 /
   // 1744 / 1734 us, 2^21 2844 / 2861 / 2959, 2^22 5585 / 5414 / 5299, 2^23 10713 / 10296 / 10013, 2^24 20966 / 20046 / 19203
   // (profiles/r05_msm_window_sweep.txt): 16 bits from 3 x 2^20 points.
-  const int c = n >= ((size_t)3 << 20) ? 16 : (n >= ((size_t)1 << 20) ? 14 : 12);
+  // At HEAD of round 5 (12 / 13 / 14 / 15 / 16 bits): 2^18 698 / 703 / 703 / 815 / 897 us, 2^19 1037 / 1029 / 1007 / 1070 / 1139,
+  // 2^20 1685 / 1685 / 1522 / 1585 / 1638, 2^21 2981 / 2976 / 2720 / 2776 / 2784: 14 bits from 2^19 points.
+  const int c = n >= ((size_t)3 << 20) ? 16 : (n >= ((size_t)1 << 19) ? 14 : 12);
   return (int)d.tuned(D377_TUNE_MSM_WINDOW, c);              // developer override: 4 .. 16 (>= 4: at most 63 windows, k_msm_final's table of cached sums)
 }
 
