@@ -447,8 +447,8 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
   D377_DCB_END();
 }
 
-// Up to three workgroups per CU (168 VGPRs): this kernel's additions wait on table gathers from HBM (14 random 128-byte
-// records per element, L2 hit rate 0.25), which a third wave per SIMD hides a little better, and large batches share one
+// Up to three workgroups per CU (168 VGPRs): this kernel's additions wait on table gathers from HBM (11 random 128-byte
+// records per element of the 23-bit comb, L2 hit rate 0.25), which a third wave per SIMD hides a little better, and large batches share one
 // inversion among FB_K = 16 elements per lane instead of 8 (launch(): OP_MUL_BASE chooses per call).
 __global__ void __launch_bounds__(BLOCK, FB_SETS) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
                                                            const uint8_t* scalar32, size_t n, uint8_t* out32, DcbScratch dcb) {

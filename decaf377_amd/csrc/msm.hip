@@ -50,16 +50,12 @@ namespace {
 constexpr int PT_WORDS = 4 * SLOT;      // one cached or extended point record: 192 B
 constexpr int CHUNK = 8;                // buckets per lane in k_msm_chunks (short chains: this phase is latency-bound)
 constexpr int FOLD = 4;                 // points per lane in k_msm_fold (a serial chain per lane: short chains, more levels)
-// Partial sums per lane in the further reduction levels (k_msm_reduce), level 2, 3, 4.  With random scalars a bucket of a
-// 2^22-point MSM leaves 16 partials: eight per lane keeps 2 x the buckets busy instead of one lane per bucket walking
-// 15 dependent additions (883 workgroups of 4 waves on 768 places: 335 us for 2.2 M additions, against ~120 us of
-// issue time); the wide last level is for runs that hold most of the points (many equal scalars).
-// `skip`: a level runs only if some bucket still has more than this many partials; fewer are summed by the lane that
-// finishes the bucket (a level of its own for two or three leftovers -- the tail of the Poisson run lengths -- cost 27-56 us).
-// Segment length x skip threshold swept at 2^20 / 2^22 (16-64 x 4-16): everything within 2 %; round 4 (tools/msm_tune_sweep.py,
-// skip 4 / 8 / 16): 2^16 553 / 537 / 529 us, 2^18 804 / 799 / 799, 2^20 1786 / 1773 / 1768, 2^22 5840 / 5814 / 5832 -- with random
-// scalars a bucket leaves 4-16 partials at every size, and the lane that finishes the bucket sums those in less time than a
-// level of its own costs: 16 -- and 32 since four lanes share a bucket's partials (k_msm_buckets): up to eight additions per lane.
+// Partial sums per lane in the further reduction levels (k_msm_reduce), level 2, 3, 4, and `skip`: a level runs only if some
+// bucket still has more than this many partials; fewer are summed by the lane (or pair of lanes) that finishes the bucket.
+// With the span sums a bucket of random scalars is left with 1 + size / L partials -- one to three -- so no level runs; the
+// levels are for runs that hold most of the points (many equal scalars: one bucket with thousands of partials), which each
+// level cuts by its group size.  (Rounds 3-4, one lane per <= seg points of a bucket: 4-30 partials per bucket, skip and
+// the segment length swept at 2^16 ... 2^22, everything within 2 %.)
 struct RedSizes { int g[3]; uint32_t skip; };
 constexpr RedSizes RED_DEFAULT = {{8, 8, 32}, 32};
 
