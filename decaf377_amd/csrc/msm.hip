@@ -39,6 +39,7 @@
 #include "curve.hpp"
 #include "device_util.hpp"
 #include "dcb.hpp"
+#include "msm_plan.hpp"
 #include "quad_ops.hpp"
 #include "row_ops.hpp"
 #include "host_state.hpp"
@@ -77,32 +78,6 @@ using row::RQ_WORDS;
 using row::rq_store_point;
 using row::rq_store_cached;
 using row::rq_load_point;
-
-// The windows of the 252 scalar bits: W = ceil(252 / c) of them, the first `nwide` c bits wide and the rest c - 1, so that they
-// tile the 252 bits exactly whatever c is (c = 16: twelve 16-bit and four 15-bit windows; 14 and 12 tile by themselves).  A
-// uniform width with a ragged top window -- 12 significant bits at c = 16 -- would pile n / 2^10 points on each of a few
-// hundred buckets; here the top window is at most one bit narrower than the others, and because k / 2 mod r < r < 2^250.23 its
-// UNSIGNED digits (the top window is not wrapped) stay below 2^(width - 1.77) + 1: inside the 2^(width-1) buckets of its width.
-struct WinShape {
-  int c, W, nwide;
-  __host__ __device__ __forceinline__ int width(int w) const { return w < nwide ? c : c - 1; }
-  __host__ __device__ __forceinline__ int first_bit(int w) const { return w * c - (w > nwide ? w - nwide : 0); }
-};
-inline WinShape win_shape(int c) {
-  const int W = (252 + c - 1) / c;
-  return WinShape{c, W, W - (W * c - 252)};
-}
-// signed digit w of k: the top window is not wrapped
-__device__ __forceinline__ int msm_digit(const uint32_t k[8], int w, const WinShape& ws, uint32_t& carry) {
-  const int bit = ws.first_bit(w), cw = ws.width(w);
-  const int wi = bit >> 5, sh = bit & 31;
-  uint64_t v = k[wi];
-  if (wi + 1 < 8) v |= (uint64_t)k[wi + 1] << 32;
-  uint32_t d = (uint32_t)((v >> sh) & ((1u << cw) - 1u)) + carry;
-  carry = 0;
-  if (w + 1 < ws.W && d >= (1u << (cw - 1))) { carry = 1; return (int)d - (1 << cw); }
-  return (int)d;
-}
 
 __device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t i, size_t n, const WinShape& ws, bool skip, int16_t* digits) {
   uint32_t k[8];
@@ -389,7 +364,7 @@ __global__ void __launch_bounds__(1024) k_msm_scan2(uint32_t* offs, const uint32
   }
   uint32_t own[1 + REDUCE_LEVELS];                               // [0] non-empty, [1] partials after the spans, [2..] groups per level
   own[0] = size != 0 ? 1u : 0u;
-  own[1] = size != 0 ? (start + size - 1) / L - start / L + 1 : 0u;
+  own[1] = span_partials(start, size, L);
   for (int l = 2; l <= REDUCE_LEVELS; ++l) own[l] = (own[l - 1] + (uint32_t)red.g[l - 2] - 1) / (uint32_t)red.g[l - 2];
   part[0][t] = own[0];
   for (int l = 1; l < REDUCE_LEVELS; ++l) part[l][t] = own[l + 1];
@@ -694,9 +669,8 @@ __device__ __forceinline__ void span_partials_of(const SpanPlan& sp, int w, int 
   const uint32_t o = sp.offs[(size_t)w * len + b], e = sp.offs[(size_t)w * len + b + 1];
   if (e == o) { *first_slot = 0; *count = 0; return; }
   const WinInfo wi = sp.winfo[w];
-  const uint32_t f = o / sp.L, l = (e - 1) / sp.L;
-  *first_slot = (size_t)wi.lane0 + wi.ne0 + sp.ne[(size_t)w * len + b] + f;
-  *count = l - f + 1;
+  *first_slot = (size_t)wi.lane0 + wi.ne0 + sp.ne[(size_t)w * len + b] + span_first_lane(o, sp.L);
+  *count = span_partials(o, e - o, sp.L);
 }
 
 // One lane per span of L consecutive sorted entries of a window (see THE SPANS above): mixed additions (7 products each),

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include "curve.hpp"
+#include "msm_plan.hpp"
 using namespace d377;
 
 static std::vector<uint32_t> g_gtab(6 * 256 * GT_STRIDE);
@@ -490,6 +491,25 @@ void sim_scalar_mul_var_sqrt(const uint32_t* enc, const uint32_t* k, size_t n, u
     HostTab tab; ge r = ge_scalar_mul_w4(g, dg, tab);
     ge_compress(g_T, pt, r, out + 8 * i);
   }
+}
+// The MSM's integer plan (msm_plan.hpp): the windows for width c, and the signed digits of n scalars exactly as the prepare
+// kernels write them (scalar mod r, halved mod r, recoded).  shape = {W, nwide}; digits: n rows of 64 ints (W <= 63 used).
+void sim_msm_digits(const uint32_t* k, size_t n, int c, int* shape, int* digits) {
+  const WinShape ws = win_shape(c);
+  shape[0] = ws.W; shape[1] = ws.nwide;
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t w[8];
+    for (int j = 0; j < 8; ++j) w[j] = k[8 * i + j];
+    fr_reduce_words(w);
+    fr_half_words(w);
+    uint32_t carry = 0;
+    for (int q = 0; q < ws.W; ++q) digits[64 * i + q] = msm_digit(w, q, ws, carry);
+    digits[64 * i + 63] = (int)carry;                   // must end as 0
+  }
+}
+// lanes that touch a bucket holding the entries [o, o + size) of its window when every lane takes L consecutive entries
+void sim_span_plan(const uint32_t* o, const uint32_t* size, size_t nb, uint32_t L, uint32_t* first_lane, uint32_t* partials) {
+  for (size_t b = 0; b < nb; ++b) { first_lane[b] = span_first_lane(o[b], L); partials[b] = span_partials(o[b], size[b], L); }
 }
 void sim_scalar_mul_base(const uint32_t* k, size_t n, uint32_t* out) {
   HostFTab ft{g_fbase.data()};

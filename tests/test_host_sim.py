@@ -699,6 +699,63 @@ def test_to_affine_on_raw_records(sim, oracle):
     assert (got[keep] == want[keep]).all() and not got[3].any() and not got[7].any()
 
 
+def test_msm_windows_digits_and_span_plan(sim):
+    """msm_plan.hpp, the code the MSM kernels run, on the host: (1) for every window width c = 4 .. 16 the windows -- the first
+    `nwide` c bits wide, the rest c - 1 -- tile the 252 scalar bits, and the signed digits of a scalar recompose to
+    k / 2 mod r (the MSM sums with k / 2 and doubles at the end) with |digit| <= 2^(width - 1) and an unwrapped,
+    non-negative top digit inside the buckets of its width, for random, zero, tiny, near-r and all-ones scalars;
+    (2) the span plan: with every lane taking L consecutive sorted entries, a bucket is touched by exactly the lanes the
+    closed form names, and slot = lane + (non-empty buckets before) is strictly increasing along the entries -- no two
+    partial sums share a slot."""
+    L = sim
+    rng = np.random.default_rng(55)
+    n = 400
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    k[0] = 0
+    k[1, :] = 0; k[1, 0] = 1
+    k[2] = np.frombuffer((R_ORDER - 1).to_bytes(32, "little"), np.uint8)
+    k[3] = np.frombuffer(R_ORDER.to_bytes(32, "little"), np.uint8)
+    k[4] = 255
+    k[5, 8:] = 0                                                   # a 64-bit scalar
+    kw = np.ascontiguousarray(k).view(np.uint32).reshape(n, 8)
+    for c in range(4, 17):
+        shape = np.zeros(2, np.int32)
+        dig = np.zeros((n, 64), np.int32)
+        L.sim_msm_digits(kw.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), c, shape.ctypes.data_as(ctypes.c_void_p), dig.ctypes.data_as(ctypes.c_void_p))
+        W, nwide = int(shape[0]), int(shape[1])
+        widths = [c if w < nwide else c - 1 for w in range(W)]
+        assert W == -(-252 // c) and sum(widths) == 252 and W <= 63, (c, W, nwide)
+        first = [sum(widths[:w]) for w in range(W)]
+        for i in range(n):
+            kv = int.from_bytes(bytes(k[i]), "little") % R_ORDER
+            half = kv // 2 if kv % 2 == 0 else (kv + R_ORDER) // 2
+            d = [int(x) for x in dig[i, :W]]
+            assert dig[i, 63] == 0 and sum(dv << first[w] for w, dv in enumerate(d)) == half, (c, i)
+            assert all(abs(dv) <= 1 << (widths[w] - 1) for w, dv in enumerate(d)), (c, i)
+            assert 0 <= d[W - 1] <= 1 << (widths[W - 1] - 1), (c, i)
+    # (2) the span plan on random bucket sizes (many empty, some huge), several L
+    for trial in range(40):
+        nb = int(rng.integers(1, 300))
+        size = rng.integers(0, 40, nb).astype(np.uint32)
+        size[rng.random(nb) < 0.3] = 0
+        if trial % 5 == 0:
+            size[int(rng.integers(0, nb))] = 5000
+        o = np.concatenate(([0], np.cumsum(size)[:-1])).astype(np.uint32)
+        Ls = int(rng.integers(1, 70))
+        fl = np.zeros(nb, np.uint32); pc = np.zeros(nb, np.uint32)
+        L.sim_span_plan(o.ctypes.data_as(ctypes.c_void_p), size.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nb), Ls,
+                        fl.ctypes.data_as(ctypes.c_void_p), pc.ctypes.data_as(ctypes.c_void_p))
+        bucket_of = np.repeat(np.arange(nb), size)                 # entry -> bucket
+        lane_of = np.arange(bucket_of.size) // Ls                  # entry -> lane
+        ne = np.concatenate(([0], np.cumsum(size != 0)[:-1]))      # non-empty buckets before b
+        slots = []
+        for b in range(nb):
+            lanes = np.unique(lane_of[bucket_of == b])
+            assert pc[b] == lanes.size and (lanes.size == 0 or (fl[b] == lanes[0] and lanes[-1] == lanes[0] + lanes.size - 1)), (trial, b)
+            slots += [int(l) + int(ne[b]) for l in lanes]
+        assert all(a < b_ for a, b_ in zip(slots, slots[1:])), trial
+
+
 def test_bench_mac_counts():
     """bench.py's KERNEL_OPS (field products / squarings per element, the numerator of roofline_valu) are the
     counts the instrumented host build of the same headers reports for one element of each operation."""
