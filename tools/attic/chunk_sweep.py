@@ -18,6 +18,7 @@ ops = {
     "sqrt_ratio_zeta": lambda n: ctx.sqrt_ratio_zeta(r0[:n], k[:n], outs=[o32[:n], o1[:n]]),
     "encode_to_curve": lambda n: ctx.encode_to_curve(r0[:n], outs=[o32[:n]]),
     "hash_to_curve": lambda n: ctx.hash_to_curve(r0[:n], k[:n], outs=[o32[:n]]),
+    "scalar_mul_base": lambda n: ctx.scalar_mul_base(k[:n], outs=[o32[:n]]),
     "scalar_mul_var": lambda n: ctx.scalar_mul_var(enc[:n], k[:n], outs=[o32[:n], o1[:n]]),
 }
 for name, fn in ops.items():
