@@ -324,13 +324,15 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_encode_to_curve(SqrtT
 // sum, so the encoding needs no third square root (curve.hpp, ge_dcb_from_jacobi_sum): 1.8e8 -> 2.5e8 /s at 2^20.  A pair
 // that hits the addition law's exceptional case (s1 s2 = +-1) goes the reference's way, Edwards addition and generic
 // compression, and enters the batch as a finished encoding; the branch is taken by a wave only if one of its lanes needs it.
-// (Out of line, and handed nothing but the pair's input words BY VALUE: it maps both inputs again, in the reference's
-// inversion-free form.  References to the caller's (s, t) values would put those in scratch memory for EVERY element -- 144
-// bytes of stores per element on the hot path, which is what the first version did -- to save four square roots on a route
-// no known input takes.)
+// (Handed nothing but the pair's input words BY VALUE: it maps both inputs again, in the reference's inversion-free form.
+// References to the caller's (s, t) values would put those in scratch memory for EVERY element -- 144 bytes of stores per
+// element on the hot path, which is what the first version did -- to save four square roots on a route no known input
+// takes.  Inline since it left the per-element loops: as a call it cost its callers an argument block and six more
+// registers in scratch -- k_hash_to_curve 80 -> 24 bytes per lane, what is left are addresses kept per chunk; the tiny
+// kernels none at all -- for the same time, profiles/r05_ab_exceptional_inline.txt.)
 struct Words8 { uint32_t w[8]; };
 template <class PT>
-__device__ __noinline__ Words8 hash_exceptional_words(SqrtTables T, PT pt, Words8 a1, Words8 a2) {
+__device__ __forceinline__ Words8 hash_exceptional_words(SqrtTables T, PT pt, Words8 a1, Words8 a2) {
   fe s1, t1, s2, t2, unused = fe_zero();
   ge_elligator_st(T, pt, fe_from_words_mod_order(a1.w), &s1, &t1, &unused, false);
   ge_elligator_st(T, pt, fe_from_words_mod_order(a2.w), &s2, &t2, &unused, false);
