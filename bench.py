@@ -513,7 +513,7 @@ def main():
             o22 = torch.empty((n22, 32), dtype=torch.uint8, device=dev)
             ker, _ = time_op(torch, lambda: ctx.scalar_mul_base(scalars[:n22], outs=[o22]), 3, 1)
             extra["scalar_mul_base_2^22"] = {"n": n22, "kernel_ms": ker, "per_sec": n22 / (ker * 1e-3),
-                                             # wide launch from 2^21 elements: one inversion per 16 elements, not 8
+                                             # wide launch beyond 2^20 elements: one inversion per 16 elements, not 8
                                              "roofline_valu": valu_view(KERNEL_MACS["scalar_mul_base"] - DIVSTEP_MACS_PER_INVERSION / 16.0, n22, ker)}
             del pm22, o22
         # small batches: a call lasts as long as one element's dependency chain (one quad of lanes per element / point)

@@ -1384,7 +1384,7 @@ int check_residency(DeviceState& d) {
     if (nb < 1 || nb > sets)
       return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", names[k]);
   }
-  // the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU, below FB_WIDE_GENERATIONS generations of full chunks): its own padding
+  // the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU, up to FB_WIDE_GENERATIONS generation of full chunks): its own padding
   {
     const int pad = (160 * 1024) / (WAVES_PER_SIMD + 1) + 1024;
     int nb = 0;
@@ -1578,12 +1578,12 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
       break;
     case OP_MUL_BASE: {
-      // Wide launch (3 workgroups per CU, 16 elements per inversion) from FB_WIDE_GENERATIONS x DCB_K elements per resident lane (2^21 on 256 CUs), where the chunks come in
-      // several generations; below, the narrow one (2 per CU, 8 per inversion) tiles the chip exactly at the sizes that
-      // matter (2^20 elements = 512 chunks of 8 per lane on 512 places; on 768 places they are 683 of 6 per lane).
-      // Measured, one box, alternating (profiles/README.md), narrow / wide: 2^20 1.13 / 1.06, 2^21 1.14 / 1.17,
-      // 3 x 2^20 1.09-1.13 / 1.17-1.20, 2^22 1.08-1.13 / 1.19, 2^23 1.14 / 1.21 x 10^9 per s.
-      // (FB_WIDE_GENERATIONS x DCB_K elements per resident lane: 2^21 on 256 CUs)
+      // Wide launch (3 workgroups per CU, 16 elements per inversion) beyond ONE generation of full narrow chunks (DCB_K elements per
+      // resident lane: 2^20 on 256 CUs); up to there the narrow one (2 per CU, 8 per inversion), whose rounds are dealt out
+      // evenly, is as fast or faster (196 608 elements: 166 against 186 us).  Beyond, the narrow launch needs a second
+      // generation of workgroups and the wide one does not: wide / narrow 0.88 at 1.25 x 2^20, 0.95 at 1.5 x, 0.88 at
+      // 1.75 x, 0.96 at 2^21, 0.94-0.95 at 3 x 2^20 and 2^22, warm clocks, alternating (profiles/r05_fb_wide_sweep.txt; the
+      // threshold of rounds 3-4, two generations, was measured on the 18-bit comb before the rounds were dealt out evenly).
       if (n <= tiny_batch_max(d)) {                           // one scalar per wave, lane-spread arithmetic
         hipLaunchKernelGGL(k_scalar_mul_base_tiny<false>, dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
         break;
@@ -1593,7 +1593,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
                            (const uint8_t*)in0, n, (uint8_t*)out0);
         break;
       }
-      bool wide = n >= d.resident_lanes() * DCB_K * FB_WIDE_GENERATIONS;
+      bool wide = n > d.resident_lanes() * DCB_K * FB_WIDE_GENERATIONS;
       if (d.is_tuned(D377_TUNE_FB_WIDE)) wide = d.tuned(D377_TUNE_FB_WIDE, 0) != 0;               // developer overrides (A/B)
       const int fk = (int)d.tuned(D377_TUNE_FB_K, wide ? FB_K : DCB_K);
       int gb;

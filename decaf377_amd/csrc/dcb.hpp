@@ -15,8 +15,11 @@ namespace d377 {
 // DCB_K elements per lane, except the fixed-base multiplication (FB_SETS, FB_K: see k_scalar_mul_base).  The scratch
 // layout is sized for the largest of each and is the same for all of them.
 constexpr int DCB_KMAX = 16;
-constexpr int FB_SETS = 3, FB_K = 16;
-constexpr int FB_WIDE_GENERATIONS = 2;            // generations of full narrow chunks from which the fixed-base kernel takes FB_SETS / FB_K
+#ifndef D377_FB_SETS
+#define D377_FB_SETS 3                // (4: 128 VGPRs, 13 of them spilled, the same time at 2^20 ... 2^23: profiles/r05_ab_fb_sets.txt)
+#endif
+constexpr int FB_SETS = D377_FB_SETS, FB_K = 16;
+constexpr int FB_WIDE_GENERATIONS = 1;            // generations of full narrow chunks beyond which the fixed-base kernel takes FB_SETS / FB_K
 constexpr int DCB_SETS_MAX = FB_SETS > WAVES_PER_SIMD ? FB_SETS : WAVES_PER_SIMD;
 static_assert(DCB_K <= DCB_KMAX && FB_K <= DCB_KMAX, "the scratch layout has DCB_KMAX record rows per slot");
 
