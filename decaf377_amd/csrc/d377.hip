@@ -1506,8 +1506,8 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
   // workgroup takes rounds / places of them and the first rounds % places workgroups one more (DcbScratch::extra).
   // (Chunks of ceil(n / resident lanes) elements per lane for everybody left a batch just above k x the resident lanes
   // with fewer workgroups of k + 1 rounds each: pairs of them shared a CU while other CUs held one, and the call took
-  // as long as k + 1 full rounds -- profiles/r04_size_sweep.txt.)  Beyond that: chunks of kmax per lane, as many
-  // workgroups as chunks (oversubscribed on purpose, see DcbScratch).
+  // as long as k + 1 full rounds -- profiles/r04_size_sweep.txt.)  Beyond that: the same deal over the fewest generations
+  // that hold the rounds (host_state.hpp deal_chunks), as many workgroups as chunks (oversubscribed on purpose, see DcbScratch).
   auto chunks_of = [&](int sets, int kmax, int& grid, DcbScratch& sc) {
     const size_t places = (size_t)d.cus * (size_t)sets;
     const size_t rounds = (n + BLOCK - 1) / BLOCK;
@@ -1516,12 +1516,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       per_lane = (size_t)d.tuned(D377_TUNE_CHUNK_PER_LANE, 1);
       if (per_lane > (size_t)kmax) per_lane = (size_t)kmax;
       nchunks = (rounds + per_lane - 1) / per_lane;
-    } else if (rounds <= places) {
-      per_lane = 1; nchunks = rounds;
-    } else if (rounds <= places * (size_t)kmax) {
-      per_lane = rounds / places; extra = rounds % places; nchunks = places;
     } else {
-      per_lane = (size_t)kmax; nchunks = (rounds + per_lane - 1) / per_lane;
+      const ChunkDeal c = deal_chunks(rounds, places, (size_t)kmax, (size_t)d.cus * 64);      // host_state.hpp
+      per_lane = c.per_lane; extra = c.extra; nchunks = c.nchunks;
     }
     if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
     grid = (int)nchunks;

@@ -55,7 +55,7 @@ struct DcbScratch {
   int nslots;          // the sets THIS kernel may claim: the first nslots (its resident workgroups: 2 or 3 per CU)
   int per_lane;        // elements per lane in a chunk, 1 .. the kernel's K: smaller for small batches, so that the grid still fills the chip
   int lanes;           // the layout's lane count: the same for every kernel, so a set is the same memory whoever claims it
-  int extra;           // single-generation launches: the first `extra` workgroups take per_lane + 1 elements per lane (0: every chunk alike)
+  int extra;           // launches of one workgroup per chunk: the first `extra` workgroups take per_lane + 1 elements per lane (0: every chunk alike)
   uint32_t* health;    // [0] ticket counter, [1] workgroups that waited DCB_STUCK_TICKS for a set, [2] workgroups that gave up
 };
 constexpr uint64_t DCB_STUCK_TICKS = 25000000ull;        // wall_clock64() ticks (100 MHz): 0.25 s

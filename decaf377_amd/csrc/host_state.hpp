@@ -141,6 +141,28 @@ struct DeviceState {
   SqrtTables tables() const { return SqrtTables{gtab, s_lookup, inv_fail}; }
 };
 
+// How a chunked kernel's rounds (of BLOCK elements) are dealt out to its workgroups.  `places` workgroups are resident at a
+// time and a chunk holds at most kmax rounds (elements per lane).  Up to one round per place: a workgroup per round.
+// Otherwise G = the fewest generations of resident workgroups that can hold the rounds: exactly G x places chunks, the rounds
+// dealt out evenly, the first `extra` chunks one round longer (DcbScratch::extra) -- every generation is full and there is
+// no last generation of a few stragglers.  (Chunks of kmax left 5 x 2^18 elements with 128 of them: sqrt_ratio_zeta 2.54 ms
+// against 2.13 dealt evenly, variable base 24.1 against 19.4: profiles/r05_chunk_between_generations.txt.)  Whole multiples
+// of places x kmax rounds -- 2^20, 2^21, 2^22 elements on 256 CUs -- come out as chunks of kmax, as before.  Beyond `cap`
+// chunks the workgroups walk several chunks of kmax.
+struct ChunkDeal { size_t per_lane, extra, nchunks; };
+inline ChunkDeal deal_chunks(size_t rounds, size_t places, size_t kmax, size_t cap) {
+  ChunkDeal c{1, 0, rounds};
+  if (rounds <= places) return c;
+  const size_t gens = (rounds + places * kmax - 1) / (places * kmax);
+  if (gens * places <= cap) {
+    c.nchunks = gens * places; c.per_lane = rounds / c.nchunks; c.extra = rounds % c.nchunks;
+  } else {
+    c.per_lane = kmax; c.nchunks = (rounds + kmax - 1) / kmax;
+    if (c.nchunks > cap) c.nchunks = cap;
+  }
+  return c;
+}
+
 inline int grow(uint8_t*& p, size_t& cap, size_t bytes, size_t slack) {
   if (bytes <= cap) return D377_OK;
   if (p) HIP_TRY(hipFree(p));

@@ -1649,12 +1649,9 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
         d.msm_enc_chunked = (nb >= 1 && nb <= WAVES_PER_SIMD) ? 1 : 0;
       }
       if (n >= chunked_min && d.msm_enc_chunked == 1) {
-        const size_t resident = (size_t)d.cus * WAVES_PER_SIMD * BLOCK;
-        size_t per_lane = (n + resident - 1) / resident;
-        if (per_lane > (size_t)DCB_K) per_lane = DCB_K;
-        size_t nchunks = (n + per_lane * BLOCK - 1) / (per_lane * BLOCK);
-        if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
-        const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)per_lane, d.dcb_sets * BLOCK, 0, d.pool_health};
+        const ChunkDeal c = deal_chunks((n + BLOCK - 1) / BLOCK, (size_t)d.cus * WAVES_PER_SIMD, (size_t)DCB_K, (size_t)d.cus * 64);
+        const size_t nchunks = c.nchunks;
+        const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)c.per_lane, d.dcb_sets * BLOCK, (int)c.extra, d.pool_health};
         GuardScope vb{d.vb_guard, s};                       // the lane-set areas: queue behind their last user
         if ((rc = vb.acquire())) return rc;
         hipLaunchKernelGGL(k_msm_prepare_enc_chunked, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, wshape,

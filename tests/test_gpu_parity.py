@@ -485,7 +485,8 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
 
 def test_ragged_chunks_match_uniform_chunks(ctx, torch_mod, oracle):
     """Batches of up to DCB_K rounds per resident workgroup run in one generation with the rounds dealt out evenly: the
-    first `rounds % places` workgroups take one round more than the others (d377.hip `chunks_of`, DcbScratch::extra),
+    first `rounds % places` workgroups take one round more than the others (d377.hip `chunks_of`, DcbScratch::extra);
+    larger ones in the fewest generations that hold them, dealt out the same way,
     and a workgroup decides by its own count whether it shares an inversion between its square roots.  Every chunked
     operation gives the same bytes as with uniform chunks of 1, 2, 3 and 8 elements per lane forced through the tuning
     call, at sizes that leave 1 .. places - 1 workgroups with the extra round (and a partial last round), and a
@@ -494,8 +495,11 @@ def test_ragged_chunks_match_uniform_chunks(ctx, torch_mod, oracle):
     dev = torch.device("cuda:0")
     places = torch.cuda.get_device_properties(0).multi_processor_count * 2
     g = torch.Generator(device=dev).manual_seed(515)
+    # ... and beyond one generation the same deal over the fewest generations that hold the rounds (host_state.hpp deal_chunks):
+    # 10 rounds per place and a few (two generations of 5, three chunks of 6), 17 and a third (three generations of 5 and 6)
     sizes = [places * 256 + 1, places * 256 + 256 * 97 - 13, 2 * places * 256 + 255, 3 * places * 256 - 256 - 1,
-             (7 * places + 1) * 256 + 5, (3 * places + places // 2) * 256]
+             (7 * places + 1) * 256 + 5, (3 * places + places // 2) * 256,
+             (10 * places + 3) * 256 + 7, (17 * places + places // 3) * 256 - 1]
     for n in sizes:
         r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
         k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
