@@ -216,11 +216,11 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtT
 }
 
 // decompress, compress and the round trip run one element per lane on the wide grid, each square root in the
-// reference's inversion-free form: in chunks with batched inverses they execute 4-8 % fewer instructions, but at 2^20
-// elements the chunked grid has no more workgroups than fit at once, the wide grid keeps the issue port fuller, and
-// they finish no sooner (measured, profiles/README.md).  From 2^21 elements -- several generations of chunks -- the
-// decompression does gain (5-8 %: k_decompress_chunked below); the compression gains 1-4 % and stays as it is.
-constexpr int DECOMPRESS_CHUNKED_GENERATIONS = 2;   // batches of at least this many generations of full chunks (x DCB_K x the resident lanes)
+// reference's inversion-free form: in chunks with batched inverses they execute 4-8 % fewer instructions.  The
+// decompression takes the chunked form (k_decompress_chunked below) as soon as a lane has the DCB_ASSIST_MIN elements
+// that make an inversion worth sharing: 3 x the resident lanes, 393 216 elements on 256 CUs (-4 % there, -5 % at 2^19,
+// -7 % from 2^20 on: profiles/r05_decompress_route_sweep.txt; rounds 2-4 switched at 2^21, before a wave shared one
+// inversion and before the rounds were dealt out evenly over the generations); the compression gains 1-4 % and stays.
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
                                                       uint64_t* xyzt, uint8_t* status) {
   D377_POW_LDS();
@@ -1542,15 +1542,14 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
                          (uint8_t*)out0, (uint8_t*)out1, aux, dcb);
       break;
     case OP_DECOMPRESS: {
-      // several generations of chunks: the batched-inverse form (one box, alternating: 2^20 1.93-1.97 against 1.99 ms,
-      // 2^21 3.76-3.90 against 4.14-4.18, 2^22 7.71-7.78 against 8.19, 2^23 15.2-15.6 against 16.5); below, the wide grid
-      // (the threshold is DECOMPRESS_CHUNKED_GENERATIONS full chunks per resident lane set: 2^21 elements on 256 CUs)
+      // from DCB_ASSIST_MIN elements per resident lane: the batched-inverse form (2^19 0.97 against 1.02 ms, 2^20 1.89 / 2.04,
+      // 2^21 3.79 / 4.06, 2^22 7.66 / 8.10); below, the wide grid
       if (n <= tiny4_batch_max(d)) {
         hipLaunchKernelGGL(k_decompress_tiny<false>, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
         break;
       }
       const size_t chunked_min = (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN,
-                                                 (long long)(d.resident_lanes() * DCB_K * DECOMPRESS_CHUNKED_GENERATIONS));
+                                                 (long long)(d.resident_lanes() * DCB_ASSIST_MIN));
       if (n >= chunked_min) {
         if ((rc = vb.acquire())) return rc;
         hipLaunchKernelGGL(k_decompress_chunked, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_DECOMPRESS], s, T, (const uint8_t*)in0, n, (uint64_t*)out0,

@@ -111,9 +111,9 @@ k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, s
 }
 
 // The same in chunks with the square roots' denominators inverted together (dcb.hpp; as k_scalar_mul_var and
-// k_decompress_chunked decode their points): 5-8 % fewer cycles per decompression once the chunks come in several
-// generations, which is where msm_launch uses it.
-constexpr int MSM_ENC_CHUNKED_GENERATIONS = 2;      // from this many generations of full chunks (x DCB_K x the resident lanes: 2^21 points on 256 CUs)
+// k_decompress_chunked decode their points): 5-8 % fewer cycles per decompression; msm_launch uses it from DCB_ASSIST_MIN
+// points per resident lane, like d377_batch_decompress (393 216 points on 256 CUs: the call -0.7 % there, -2 % at 2^20, -4 % at
+// 2^22; profiles/r05_decompress_route_sweep.txt).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, WinShape ws,
                           uint32_t* pts, int16_t* digits, uint8_t* status, DcbScratch dcb) {
@@ -1640,7 +1640,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
 
   if (n) {
     if (encoded) {
-      const size_t chunked_min = (size_t)d.tuned(D377_TUNE_MSM_ENC_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_K * MSM_ENC_CHUNKED_GENERATIONS));
+      const size_t chunked_min = (size_t)d.tuned(D377_TUNE_MSM_ENC_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_ASSIST_MIN));
       if (n >= chunked_min && d.msm_enc_chunked < 0) {
         // the chunked kernel claims lane sets of the scratch areas: only if its residency matches them (as d377_ctx_create
         // checks for the kernels of d377.hip); otherwise the wide kernel stays

@@ -416,6 +416,17 @@ def test_batched_inverse_decoding_from_2_21(ctx, torch_mod, oracle):
     ident = torch.from_numpy(oracle.identity_xyzt().view(np.int64)).to(dev)
     Pz[st != 0] = ident
     assert bytes(ctx.msm(Pz, k2)[0]) == bytes(m[0])
+    # the chunked forms start at DCB_ASSIST_MIN = 3 elements per resident lane (2 workgroups x 256 lanes per CU): ragged sizes
+    # from there up, where the rounds are dealt out unevenly (DcbScratch::extra), against the wide grid
+    lanes = torch.cuda.get_device_properties(0).multi_processor_count * 2 * 256
+    for n2 in (3 * lanes, 3 * lanes + 77, 5 * lanes - 3, 8 * lanes + 256 * 5 + 1, 9 * lanes + 13):
+        P, st = ctx.decompress(enc[:n2])
+        m = ctx.msm(enc[:n2], k[:n2])
+        with ctx.tuning(decompress_chunked_min=1 << 40, msm_enc_chunked_min=1 << 40):
+            P0, st0 = ctx.decompress(enc[:n2])
+            m0 = ctx.msm(enc[:n2], k[:n2])
+        assert torch.equal(P, P0) and torch.equal(st, st0), n2
+        assert bytes(m[0]) == bytes(m0[0]) and torch.equal(torch.as_tensor(m[2]), st), n2
 
 
 def test_full_size_hash_to_curve_two_routes_2_20(ctx, torch_mod, oracle):
