@@ -57,10 +57,12 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
 # 8 elements per lane they have.
 KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (88.25, 3.0),
               "sqrt_ratio_zeta": (75.25, 241.0), "encode_to_curve": (102.5, 243.0), "hash_to_curve": (202.75, 491.0),
-              "decompress": (93.0, 291.0), "compress": (92.0, 289.0)}
+              "decompress": (93.0, 291.0), "compress": (92.0, 289.0),
+              # decompress from 3 elements per resident lane (393 216 on 256 CUs): chunks with batched inverses (d377.hip)
+              "decompress_chunked": (88.25, 246.0)}
 # divsteps inversions per element (one per lane per 8 elements and per batched-inversion pass of the kernel)
 KERNEL_INVERSIONS = {"scalar_mul_var": 2 / 8.0, "scalar_mul_base": 1 / 8.0, "sqrt_ratio_zeta": 1 / 8.0, "encode_to_curve": 2 / 8.0,
-                     "hash_to_curve": 3 / 8.0}
+                     "hash_to_curve": 3 / 8.0, "decompress_chunked": 1 / 8.0}
 MACS_PER_MUL, MACS_PER_SQR = 153, 117
 DIVSTEP_MACS_PER_INVERSION = 20 * 90                       # v_mad_i64_i32: update_fg_30 (36) + update_de_30 (54) per round
 KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR + KERNEL_INVERSIONS.get(k, 0.0) * DIVSTEP_MACS_PER_INVERSION
@@ -573,8 +575,11 @@ def main():
             ("hash_to_curve", lambda: ctx.hash_to_curve(r0[:ne], scalars[:ne], outs=[o1])),
         ]:
             ker, _ = time_op(torch, fn, 3, 1)
+            macs = KERNEL_MACS[name]
+            if name == "decompress" and ne >= 3 * 512 * torch.cuda.get_device_properties(dev).multi_processor_count:
+                macs = KERNEL_MACS["decompress_chunked"]            # the route d377_batch_decompress takes at this size
             extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3),
-                           "roofline_valu": valu_view(KERNEL_MACS[name], ne, ker)}
+                           "roofline_valu": valu_view(macs, ne, ker)}
         extra["encodes_per_sec"] = extra["roundtrip"]["per_sec_all_gpus"]          # whole job, all GPUs
         extra["elligator_encodes_per_sec"] = extra["encode_to_curve"]["per_sec_all_gpus"]
         line["extra"] = extra

@@ -783,12 +783,13 @@ def run(n, what):
     if what == "encode_to_curve": L.sim_encode_to_curve(p(r0), n_(n), p(enc), None)
     if what == "hash_to_curve": L.sim_hash_to_curve_quartic(p(r0), p(k), n_(n), p(out), 0, None, None)
     if what == "decompress": L.sim_decompress(p(enc), n_(n), p(np.zeros((n, 16), np.uint64)), p(st))
+    if what == "decompress_chunked": L.sim_decompress_assisted(p(enc), n_(n), p(np.zeros((n, 16), np.uint64)), p(st))
     if what == "compress":
         x = np.zeros((n, 16), np.uint64); L.sim_decompress(p(enc), n_(n), p(x), p(st)); L.sim_op_counts(ctypes.byref(m), ctypes.byref(s))
         L.sim_compress(p(x), n_(n), p(out))
     L.sim_op_counts(ctypes.byref(m), ctypes.byref(s)); print(what, m.value / n, s.value / n)
 run(32, "scalar_mul_var"); run(8, "roundtrip"); run(8, "scalar_mul_base_w8"); run(8, "sqrt_ratio_zeta")
-run(8, "encode_to_curve"); run(8, "hash_to_curve"); run(8, "decompress"); run(8, "compress")
+run(8, "encode_to_curve"); run(8, "hash_to_curve"); run(8, "decompress"); run(8, "compress"); run(8, "decompress_chunked")
 """
     r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -796,7 +797,7 @@ run(8, "encode_to_curve"); run(8, "hash_to_curve"); run(8, "decompress"); run(8,
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    for name in ("scalar_mul_var", "roundtrip", "sqrt_ratio_zeta", "encode_to_curve", "hash_to_curve", "decompress", "compress"):
+    for name in ("scalar_mul_var", "roundtrip", "sqrt_ratio_zeta", "encode_to_curve", "hash_to_curve", "decompress", "compress", "decompress_chunked"):
         assert got[name] == b.KERNEL_OPS[name], (name, got[name])
     # the bounds build uses the 8-bit comb (32 mixed additions of 7 products); the product build's 23-bit comb has 11
     m8, s8 = got["scalar_mul_base_w8"]

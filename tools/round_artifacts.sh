@@ -36,7 +36,7 @@ timeout 600 python3 tools/route_stress.py 200 5 > "$out/route_stress.txt" 2>&1
 echo "route stress: $(tail -1 "$out/route_stress.txt")"
 # round 4: quarter-octave sweep of the chunked kernels (ragged chunks), half-octave sweep of the MSM, the lane-spread
 # arithmetic's microbenchmarks, clock against table traffic, the release check of the PMC record
-timeout 600 python3 tools/size_sweep.py --sizes 65536,77936,92682,110218,131072,155872,185364,220436,262144,311744,370728,440872,524288,623487,741455,881744,1048576 \
+timeout 600 python3 tools/size_sweep.py --sizes 65536,77936,92682,110218,131072,155872,185364,220436,262144,311744,370728,440872,524288,623487,741455,881744,1048576,1310720,1572864,1835008,2097152 \
   --ops sqrt_ratio_zeta,encode_to_curve,hash_to_curve,scalar_mul_base,decompress,scalar_mul_var > "$out/size_sweep_quarter.txt" 2>&1
 timeout 600 python3 tools/size_sweep.py --sizes 16,256,1024,1025,4096,8192,11585,16384,23170,32768,46341,65536,92682,131072,185364,262144,370728,524288,1048576,2097152,3145727,3145728,4194304,8388608,16777216 \
   --ops "msm (Elements),msm (Encodings)" > "$out/size_sweep_msm.txt" 2>&1
