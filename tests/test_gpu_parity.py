@@ -548,6 +548,28 @@ def test_ragged_chunks_match_uniform_chunks(ctx, torch_mod, oracle):
         assert (want["base"][0][ti].cpu().numpy() == oracle.scalar_mul_base(k[ti].cpu().numpy())).all(), n
 
 
+def test_workgroups_walk_several_chunks_beyond_the_grid_cap(ctx, torch_mod, oracle):
+    """Beyond 64 chunks per CU (2^25 elements on 256 CUs) the grid stops growing and a workgroup walks several chunks of 8
+    elements per lane, drawing a new ticket for each (dcb.hpp dcb_rounds; host_state.hpp deal_chunks): the largest shape a
+    call can take.  Same bytes as the two halves as calls of their own (dealt out evenly, one chunk per workgroup), and a
+    sample is the oracle's."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n = cus * 64 * 8 * 256 + 256 * 3 + 5                  # one chunk more than the cap, the last one ragged
+    g = torch.Generator(device=dev).manual_seed(2525)
+    r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    out = ctx.encode_to_curve(r0)
+    h = n // 2 + 11
+    assert torch.equal(out[:h], ctx.encode_to_curve(r0[:h])) and torch.equal(out[h:], ctx.encode_to_curve(r0[h:]))
+    idx = np.unique(np.concatenate([np.arange(300), np.arange(n - 1500, n), np.arange(cus * 64 * 8 * 256 - 300, cus * 64 * 8 * 256 + 300),
+                                    np.arange(31, n, n // 97)]))
+    ti = torch.from_numpy(idx).to(dev)
+    assert (out[ti].cpu().numpy() == oracle.encode_to_curve(r0[ti].cpu().numpy())).all()
+    del r0, out
+    torch.cuda.empty_cache()
+
+
 def test_lane_set_pool_health_and_reset(torch_mod, oracle):
     """The lane-set pool has a way back (dcb.hpp, d377_ctx_health / d377_ctx_reset_scratch).  A context of its own: every
     set is marked as claimed by nobody (the debug hook: what a launch that died mid-kernel leaves behind), a chunked
