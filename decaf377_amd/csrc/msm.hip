@@ -1257,9 +1257,11 @@ k_msm_final(SqrtTables T, const uint32_t* sums, WinShape ws, uint8_t* enc_out, u
 }
 
 // ---- small batches: no buckets -------------------------------------------------------------------------------------
+// (Rounds 3-4; since round 5 the bucket method's floor is 0.35 ms and msm_launch takes it from 3 073 / 4 097 points, see
+// msm_small_max: this kernel is reached through the tuning override -- the route tests -- and stays as the cross-check.)
 // Up to one quad of lanes per point and one wave per SIMD (n <= 4 x 16 x the CUs: 16384 on an MI355X) the bucket
-// method has nothing to share: its kernels wait on their own dependency chains (the tree of bit-sums, the Horner chains
-// of the windows, the 252 doublings of the tail: 0.55 ms whatever n) while most of the chip idles.  Here every quad
+// method had nothing to share: its kernels waited on their own dependency chains (the tree of bit-sums, the Horner chains
+// of the windows, the 252 doublings of the tail: 0.55 ms whatever n) while most of the chip idled.  Here every quad
 // computes [k_i / 2]P_i by itself -- the same 252 doublings, all points at once -- the 16 quads of a wave add their
 // results up, and a second kernel sums the waves' partial results and encodes the double.  (Straus' interleaving would
 // share the doublings between the points of a quad, which saves work and no time while every point has a quad.)
@@ -1505,8 +1507,15 @@ int msm_reserve(DeviceState& d, hipStream_t s, size_t bytes, MsmHeld& held) {
   return D377_OK;
 }
 
-// Batches up to this many points skip the buckets (k_msm_small).  D377_TUNE_MSM_SMALL_MAX: developer override (0 = never).
-size_t msm_small_max(const DeviceState& d) { return (size_t)d.tuned(D377_TUNE_MSM_SMALL_MAX, (long long)d.cus * 4 * MS_QUADS); }
+// Batches up to this many points skip the buckets: a wave per 1 .. 3 points (Elements) or 1 .. 4 (Encodings), k_msm_tiny below.
+// The bucket method's floor came down to 0.35 ms this round (span sums, the tree's block kernels), under the quads of
+// k_msm_small, which took 4 097 .. 16 384 points in round 4 and are now reached by the tuning override only: Elements at
+// 4 096 / 8 192 / 16 384 points 387 / 410 / 428 us on the small route against 353 / 366 / 378 with buckets, Encodings at
+// 6 144 / 16 384 542 / 566 against 497 / 516; at 3 072 points the waves still win (346 / 358; Encodings at 4 096: 482 / 489)
+// (profiles/r05_msm_small_route_sweep.txt).  D377_TUNE_MSM_SMALL_MAX: developer override (0 = never).
+size_t msm_small_max(const DeviceState& d, bool encoded) {
+  return (size_t)d.tuned(D377_TUNE_MSM_SMALL_MAX, (long long)d.cus * 4 * (encoded ? 4 : 3));
+}
 
 // Batches up to this many points take a wave per 1 .. MT_MAX points (k_msm_tiny): one wave per SIMD, up to 4 points each --
 // measured against the quads (profiles/r04_size_sweep_msm.txt; Encodings at 3 072 / 4 096 points: 454 / 489 us against 534 / 537).
@@ -1543,7 +1552,7 @@ int msm_launch_small(DeviceState& d, hipStream_t s, bool encoded, const void* pt
 int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t n,
                uint8_t* enc_out, uint64_t* xyzt_out, uint8_t* status) {
   if (n >= ((size_t)1 << 31)) return fail(D377_ERR_ARG, "%s", "msm: n must be below 2^31");
-  if (n && n <= msm_small_max(d) && n < ((size_t)1 << 24)) return msm_launch_small(d, s, encoded, pts_in, scalars, n, enc_out, xyzt_out, status);
+  if (n && n <= msm_small_max(d, encoded) && n < ((size_t)1 << 24)) return msm_launch_small(d, s, encoded, pts_in, scalars, n, enc_out, xyzt_out, status);
   const int c = pick_window(d, n);
   const WinShape wshape = win_shape(c);                      // W windows of c or c - 1 bits that tile the 252 scalar bits
   const int W = wshape.W;
