@@ -528,7 +528,7 @@ def main():
             ("scalar_mul_var_element", lambda: ctx.scalar_mul_var_element(pm[:ns], scalars[:ns])),
             ("scalar_mul_base", lambda: ctx.scalar_mul_base(scalars[:ns], outs=[o1[:ns]])),
         ]:
-            ker, _ = time_op(torch, fn, 5, 2)
+            ker, _ = time_op(torch, fn, 10, 10)       # ten untimed calls first: a call this short is otherwise timed at the clock the previous route left behind
             small[name] = ker
         extra["small_batch_2^12_ms_per_call"] = small
         # the smallest batches (up to one element per SIMD: 4 x the CUs) take one WAVE per element / point, lane-spread arithmetic
@@ -547,14 +547,14 @@ def main():
             ("encode_to_curve", lambda: ctx.encode_to_curve(r0[:nt], outs=[o1[:nt]])),
             ("hash_to_curve", lambda: ctx.hash_to_curve(r0[:nt], scalars[:nt], outs=[o1[:nt]])),
         ]:
-            ker, _ = time_op(torch, fn, 5, 2)
+            ker, _ = time_op(torch, fn, 10, 10)
             tiny[name] = ker
         extra["tiny_batch_2^8_ms_per_call"] = tiny
         # mid-size MSMs (what a batch verifier holds): whole call
         mid = {}
         for lg in (16, 18):
             if ne >= (1 << lg):
-                ker, _ = time_op(torch, lambda: ctx.msm(pm[:1 << lg], scalars[:1 << lg]), 5, 2)
+                ker, _ = time_op(torch, lambda: ctx.msm(pm[:1 << lg], scalars[:1 << lg]), 10, 10)
                 mid["2^%d" % lg] = ker
         extra["msm_mid_ms_per_call"] = mid
         aff = torch.empty((ne, 8), dtype=torch.int64, device=dev)
