@@ -59,10 +59,10 @@ KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scal
               "sqrt_ratio_zeta": (75.25, 241.0), "encode_to_curve": (102.5, 243.0), "hash_to_curve": (202.75, 491.0),
               "decompress": (93.0, 291.0), "compress": (92.0, 289.0),
               # decompress from 3 elements per resident lane (393 216 on 256 CUs): chunks with batched inverses (d377.hip)
-              "decompress_chunked": (88.25, 246.0)}
+              "decompress_chunked": (88.25, 246.0), "compress_chunked": (91.25, 243.0), "roundtrip_chunked": (168.5, 489.0)}
 # divsteps inversions per element (one per lane per 8 elements and per batched-inversion pass of the kernel)
 KERNEL_INVERSIONS = {"scalar_mul_var": 2 / 8.0, "scalar_mul_base": 1 / 8.0, "sqrt_ratio_zeta": 1 / 8.0, "encode_to_curve": 2 / 8.0,
-                     "hash_to_curve": 3 / 8.0, "decompress_chunked": 1 / 8.0}
+                     "hash_to_curve": 3 / 8.0, "decompress_chunked": 1 / 8.0, "compress_chunked": 1 / 8.0, "roundtrip_chunked": 2 / 8.0}
 MACS_PER_MUL, MACS_PER_SQR = 153, 117
 DIVSTEP_MACS_PER_INVERSION = 20 * 90                       # v_mad_i64_i32: update_fg_30 (36) + update_de_30 (54) per round
 KERNEL_MACS = {k: m * MACS_PER_MUL + s * MACS_PER_SQR + KERNEL_INVERSIONS.get(k, 0.0) * DIVSTEP_MACS_PER_INVERSION
@@ -464,6 +464,9 @@ def main():
     if not args.no_extra:
         extra = dict(multi)
         ne = min(1 << 20, n)
+        # from 3 elements per resident lane (2 workgroups x 256 lanes per CU) decompress / compress / round trip run in chunks with
+        # batched inverses (d377.hip): fewer products per element, priced as such below
+        chunked_min = 3 * 512 * torch.cuda.get_device_properties(dev).multi_processor_count
         enc1 = points[:ne]
         o1 = torch.empty((ne, 32), dtype=torch.uint8, device=dev)
         s1 = torch.empty((ne,), dtype=torch.uint8, device=dev)
@@ -479,10 +482,11 @@ def main():
                 tt = torch.tensor([ker], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 ker_all = float(tt.item())
+            macs = KERNEL_MACS["roundtrip_chunked"] if name == "roundtrip" and ne >= chunked_min else KERNEL_MACS[name]
             extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3),
                            "per_sec_all_gpus": ne * world / (ker_all * 1e-3),
                            "algo_GBps": ALGO_BYTES[name] * ne / (ker * 1e-3) / 1e9,
-                           "roofline_valu": valu_view(KERNEL_MACS[name], ne, ker)}
+                           "roofline_valu": valu_view(macs, ne, ker)}
         # vartime_multiscalar_mul (Pippenger MSM), 2^20 Elements -> one Encoding
         pm, _ = ctx.decompress(enc1)
         ker, _ = time_op(torch, lambda: ctx.msm(pm, scalars[:ne]), 5, 5)
@@ -577,8 +581,8 @@ def main():
         ]:
             ker, _ = time_op(torch, fn, 5, 5)
             macs = KERNEL_MACS[name]
-            if name == "decompress" and ne >= 3 * 512 * torch.cuda.get_device_properties(dev).multi_processor_count:
-                macs = KERNEL_MACS["decompress_chunked"]            # the route d377_batch_decompress takes at this size
+            if name in ("decompress", "compress") and ne >= chunked_min:
+                macs = KERNEL_MACS[name + "_chunked"]               # the route the entry point takes at this size
             extra[name] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3),
                            "roofline_valu": valu_view(macs, ne, ker)}
         extra["encodes_per_sec"] = extra["roundtrip"]["per_sec_all_gpus"]          # whole job, all GPUs

@@ -24,6 +24,7 @@
 #include "quad_ops.hpp"
 #include "row_ops.hpp"
 #include "host_state.hpp"
+#include "codec_chunked.hpp"
 
 using namespace d377;
 
@@ -216,11 +217,12 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtT
 }
 
 // decompress, compress and the round trip run one element per lane on the wide grid, each square root in the
-// reference's inversion-free form: in chunks with batched inverses they execute 4-8 % fewer instructions.  The
-// decompression takes the chunked form (k_decompress_chunked below) as soon as a lane has the DCB_ASSIST_MIN elements
-// that make an inversion worth sharing: 3 x the resident lanes, 393 216 elements on 256 CUs (-4 % there, -5 % at 2^19,
-// -7 % from 2^20 on: profiles/r05_decompress_route_sweep.txt; rounds 2-4 switched at 2^21, before a wave shared one
-// inversion and before the rounds were dealt out evenly over the generations); the compression gains 1-4 % and stays.
+// reference's inversion-free form: in chunks with batched inverses they execute 4-8 % fewer instructions.  All three
+// take the chunked form (k_decompress_chunked below; k_compress_chunked, k_roundtrip_chunked in codec_chunked.hip) as soon as a lane has the
+// DCB_ASSIST_MIN elements that make an inversion worth sharing: 3 x the resident lanes, 393 216 elements on 256 CUs
+// (decompress -4 % there, -5 % at 2^19, -7 % from 2^20 on; compress -1 / -1 / -6 / -4 %; round trip -3 / -3 / -3 / -5 %,
+// -6 % at 2^22: profiles/r05_decompress_route_sweep.txt; rounds 2-4 switched the decompression at 2^21 and left the
+// others on the wide grid, before a wave shared one inversion and before the rounds were dealt out evenly).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
                                                       uint64_t* xyzt, uint8_t* status) {
   D377_POW_LDS();
@@ -1564,11 +1566,23 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
         hipLaunchKernelGGL(k_compress_tiny, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint64_t*)in0, n, (uint8_t*)out0);
         break;
       }
+      if (n >= (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_ASSIST_MIN)) &&   // as OP_DECOMPRESS
+          codec_chunked_ok(d)) {                                                  // codec_chunked.hip
+        if ((rc = vb.acquire())) return rc;
+        if ((rc = codec_chunked_launch(d, s, false, in0, n, out0, nullptr, gv, dcb))) return rc;
+        break;
+      }
       hipLaunchKernelGGL(k_compress, dim3(g), dim3(BLOCK), 0, s, T, (const uint64_t*)in0, n, (uint8_t*)out0);
       break;
     case OP_ROUNDTRIP:
       if (n <= tiny4_batch_max(d)) {
         hipLaunchKernelGGL(k_decompress_tiny<true>, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
+        break;
+      }
+      if (n >= (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_ASSIST_MIN)) &&   // as OP_DECOMPRESS
+          codec_chunked_ok(d)) {
+        if ((rc = vb.acquire())) return rc;
+        if ((rc = codec_chunked_launch(d, s, true, in0, n, out0, out1, gv, dcb))) return rc;
         break;
       }
       hipLaunchKernelGGL(k_roundtrip, dim3(g), dim3(BLOCK), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);

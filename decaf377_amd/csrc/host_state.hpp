@@ -102,6 +102,7 @@ struct DeviceState {
   int chunk_k[CK_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};          // elements per lane per shared inversion
   int fb_narrow_lds = 0;                 // LDS padding of the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU)
   int msm_enc_chunked = -1;              // msm.hip: may the chunked decoding pass run (its residency matches the lane sets)?  -1 = not asked yet
+  int codec_chunked = -1;                // codec_chunked.hip: may its kernels claim lane sets (their residency matches them)?  -1 = not asked yet
   int msm_span_blocks = -1;              // msm.hip: workgroups of k_msm_spans a CU holds (occupancy query), -1 = not asked yet
   int dcb_sets = 0;                      // lane sets of the round-record area and its pool (the largest chunk_sets x CUs)
   uint32_t* gtab = nullptr;

@@ -138,7 +138,7 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
  * path (D377_DEBUG_* diagnostics at context creation and in the multi-device test hook aside).
  *   SMALL_MAX              scalar_mul_var[_element], scalar_mul_base[_element]: batches up to this many elements take the quad-per-element
  *                          kernel (0 = never; it also caps TINY_MAX)
- *   DECOMPRESS_CHUNKED_MIN decompress: batches from this many elements decode with shared inversions
+ *   DECOMPRESS_CHUNKED_MIN decompress, compress, roundtrip: batches from this many elements run in chunks with shared inversions
  *   FB_WIDE                scalar_mul_base: 0 = narrow launch (2 workgroups per CU), 1 = wide (3 per CU) at every size the lane kernel takes
  *   FB_K                   scalar_mul_base: elements per lane per shared inversion, 1..16
  *   AFFINE_BLOCKS_PER_CU   to_affine: workgroups per CU that share the batch, >= 1

@@ -452,6 +452,33 @@ void sim_roundtrip_assisted(const uint32_t* enc, size_t n, uint32_t* out, uint8_
       if (bad) memset(out + 8 * i, 0, 32); else ge_compress(g_T, pt, g, out + 8 * i);
     });
 }
+// the chunked round trip of d377.hip (k_roundtrip_chunked): the decoding pass takes the inverses of its denominators, leaves
+// (X, Y) of each point and the compressor's denominator behind; those are inverted together and the compressor runs with them
+void sim_roundtrip_chunked(const uint32_t* enc, size_t n, uint32_t* out, uint8_t* st) {
+  for (size_t base = 0; base < n; base += DCB_K) {
+    HostDcbIO io; io.out = out; io.base = base;
+    const int cnt = (int)((n - base) < (size_t)DCB_K ? (n - base) : (size_t)DCB_K);
+    fe xs[DCB_K], ys[DCB_K];
+    for (int j = 0; j < cnt; ++j) dcb_put_den(io, 0, j, ge_decompress_den(enc + 8 * (base + j)));
+    dcb_invert_slot(io, 0, cnt);
+    for (int j = 0; j < cnt; ++j) {
+      const fe inv = dcb_get_inv(io, 0, j);
+      RegPowTab pt; ge g; const uint32_t bad = ge_decompress(g_T, pt, enc + 8 * (base + j), &g, &inv);
+      st[base + j] = (uint8_t)bad;
+      if (bad) g = ge_identity();
+      xs[j] = g.x; ys[j] = g.y;
+      dcb_put_den(io, 0, j, ge_compress_den(g));
+    }
+    dcb_invert_slot(io, 0, cnt);
+    for (int j = 0; j < cnt; ++j) {
+      const fe inv = dcb_get_inv(io, 0, j);
+      ge g; g.x = xs[j]; g.y = ys[j]; g.z = fe_const(FE_ONE); g.t = fe_mul(g.x, g.y);
+      RegPowTab pt; uint32_t w[8];
+      ge_compress(g_T, pt, g, w, st[base + j] == 0, &inv);
+      if (st[base + j]) memset(out + 8 * (base + j), 0, 32); else memcpy(out + 8 * (base + j), w, 32);
+    }
+  }
+}
 void sim_encode_to_curve(const uint32_t* r0, size_t n, uint32_t* enc, uint32_t* xyzt) {
   dcb_rounds<1>(n, enc, true,
     [&](HostDcbIO& io, size_t i, int j) { dcb_put_den(io, 0, j, ge_elligator_den(fe_from_words_mod_order(r0 + 8 * i))); },

@@ -400,15 +400,29 @@ def test_batched_inverse_decoding_from_2_21(ctx, torch_mod, oracle):
     k = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
     P, st = ctx.decompress(enc)
     m = ctx.msm(enc, k)
+    rt, rst = ctx.roundtrip(enc)
+    ce = ctx.compress(P)
     with ctx.tuning(decompress_chunked_min=1 << 40, msm_enc_chunked_min=1 << 40):
         P0, st0 = ctx.decompress(enc)
         m0 = ctx.msm(enc, k)
+        rt0, rst0 = ctx.roundtrip(enc)
+        ce0 = ctx.compress(P)
     assert torch.equal(P, P0) and torch.equal(st, st0) and 0 < int(st.sum().item()) < n // 100
+    # compress and the round trip (two batched inversions per chunk) in chunks against the wide grid; in place too
+    assert torch.equal(rt, rt0) and torch.equal(rst, rst0) and torch.equal(rst, st) and torch.equal(ce, ce0)
+    assert torch.equal(rt[st == 0], enc[st == 0]) and not rt[st != 0].any()
+    e2 = enc.clone()
+    ctx.roundtrip(e2, outs=[e2, rst0])
+    assert torch.equal(e2, rt)
     assert bytes(m[0]) == bytes(m0[0]) and torch.equal(torch.as_tensor(m[2]), torch.as_tensor(m0[2])) and torch.equal(torch.as_tensor(m[2]), st)
     idx = np.unique(np.concatenate([np.arange(40), np.arange(7, n, 1013)[:20], np.arange(13, n, 4001)[:20], np.arange(n - 40, n)]))
     ti = torch.from_numpy(idx).to(dev)
     o_P, o_st = oracle.decompress(enc[ti].cpu().numpy())
     assert (P[ti].cpu().numpy().view(np.uint64) == o_P).all() and (st[ti].cpu().numpy() == o_st).all()
+    o_rt, o_rst = oracle.roundtrip(enc[ti].cpu().numpy())
+    assert (rt[ti].cpu().numpy() == o_rt).all() and (rst[ti].cpu().numpy() == o_rst).all()
+    ok_i = ti[st[ti] == 0]
+    assert (ce[ok_i].cpu().numpy() == oracle.compress(P[ok_i].cpu().numpy().view(np.uint64))).all()
     # the sum itself: against the MSM of the decoded Elements with the invalid ones left out (zero scalars)
     k2 = k.clone()
     k2[st != 0] = 0
@@ -422,10 +436,15 @@ def test_batched_inverse_decoding_from_2_21(ctx, torch_mod, oracle):
     for n2 in (3 * lanes, 3 * lanes + 77, 5 * lanes - 3, 8 * lanes + 256 * 5 + 1, 9 * lanes + 13):
         P, st = ctx.decompress(enc[:n2])
         m = ctx.msm(enc[:n2], k[:n2])
+        rt, rst = ctx.roundtrip(enc[:n2])
+        ce = ctx.compress(P)
         with ctx.tuning(decompress_chunked_min=1 << 40, msm_enc_chunked_min=1 << 40):
             P0, st0 = ctx.decompress(enc[:n2])
             m0 = ctx.msm(enc[:n2], k[:n2])
+            rt0, rst0 = ctx.roundtrip(enc[:n2])
+            ce0 = ctx.compress(P)
         assert torch.equal(P, P0) and torch.equal(st, st0), n2
+        assert torch.equal(rt, rt0) and torch.equal(rst, rst0) and torch.equal(ce, ce0), n2
         assert bytes(m[0]) == bytes(m0[0]) and torch.equal(torch.as_tensor(m[2]), st), n2
 
 

@@ -283,6 +283,10 @@ def test_inverse_assisted_square_roots(sim, oracle):
         sim.sim_roundtrip_assisted(_p(enc), n_(2 * n), _p(o1), _p(s1))
         o2, s2 = oracle.roundtrip(enc)
         assert (o1 == o2).all() and (s1 == s2).all()
+        # ... and with the compressor's denominators inverted together as well (k_roundtrip_chunked)
+        o3, s3 = np.zeros((2 * n, 32), np.uint8), np.zeros(2 * n, np.uint8)
+        sim.sim_roundtrip_chunked(_p(enc), n_(2 * n), _p(o3), _p(s3))
+        assert (o3 == o2).all() and (s3 == s2).all()
 
 
 def test_divsteps_inversion(sim, oracle):
@@ -503,6 +507,7 @@ L.sim_raw_ge_sub(p(xyzt), p(x2), n_(n), p(a)); L.sim_raw_ge_sub(p(full), p(full)
 L.sim_hash_to_curve_quartic(p(r0), p(k), n_(n), p(out), 0, None, None); L.sim_hash_to_curve_quartic(p(r0), p(k), n_(n), p(out), 1, None, None)
 L.sim_hash_to_curve(p(r0), p(k), n_(n), p(out)); L.sim_compress_assisted(p(xyzt), n_(n), p(out)); L.sim_sqrt_ratio_zeta_plain(p(r0), p(k), n_(n), p(out), p(st))
 L.sim_decompress_assisted(p(enc), n_(n), p(x2), p(st)); L.sim_roundtrip_assisted(p(k), n_(n), p(out), p(st))
+L.sim_roundtrip_chunked(p(enc), n_(n), p(out), p(st)); L.sim_roundtrip_chunked(p(k), n_(n), p(out), p(st))
 L.sim_scalar_mul_var_sqrt(p(enc), p(k), n_(n), p(out), p(st)); L.sim_encode_to_curve_sqrt(p(r0), n_(n), p(out))
 w = np.zeros((n, 4), np.uint64)
 L.sim_fq_mul(p(xyzt), p(x2), n_(n), p(w)); L.sim_fq_sub(p(xyzt), p(x2), n_(n), p(w)); L.sim_fq_add(p(xyzt), p(x2), n_(n), p(w))
@@ -784,12 +789,17 @@ def run(n, what):
     if what == "hash_to_curve": L.sim_hash_to_curve_quartic(p(r0), p(k), n_(n), p(out), 0, None, None)
     if what == "decompress": L.sim_decompress(p(enc), n_(n), p(np.zeros((n, 16), np.uint64)), p(st))
     if what == "decompress_chunked": L.sim_decompress_assisted(p(enc), n_(n), p(np.zeros((n, 16), np.uint64)), p(st))
+    if what == "roundtrip_chunked": L.sim_roundtrip_chunked(p(enc), n_(n), p(out), p(st))
+    if what == "compress_chunked":
+        x = np.zeros((n, 16), np.uint64); L.sim_decompress(p(enc), n_(n), p(x), p(st)); L.sim_op_counts(ctypes.byref(m), ctypes.byref(s))
+        L.sim_compress_assisted(p(x), n_(n), p(out))
     if what == "compress":
         x = np.zeros((n, 16), np.uint64); L.sim_decompress(p(enc), n_(n), p(x), p(st)); L.sim_op_counts(ctypes.byref(m), ctypes.byref(s))
         L.sim_compress(p(x), n_(n), p(out))
     L.sim_op_counts(ctypes.byref(m), ctypes.byref(s)); print(what, m.value / n, s.value / n)
 run(32, "scalar_mul_var"); run(8, "roundtrip"); run(8, "scalar_mul_base_w8"); run(8, "sqrt_ratio_zeta")
 run(8, "encode_to_curve"); run(8, "hash_to_curve"); run(8, "decompress"); run(8, "compress"); run(8, "decompress_chunked")
+run(8, "compress_chunked"); run(8, "roundtrip_chunked")
 """
     r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -797,7 +807,8 @@ run(8, "encode_to_curve"); run(8, "hash_to_curve"); run(8, "decompress"); run(8,
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    for name in ("scalar_mul_var", "roundtrip", "sqrt_ratio_zeta", "encode_to_curve", "hash_to_curve", "decompress", "compress", "decompress_chunked"):
+    for name in ("scalar_mul_var", "roundtrip", "sqrt_ratio_zeta", "encode_to_curve", "hash_to_curve", "decompress", "compress", "decompress_chunked",
+                 "compress_chunked", "roundtrip_chunked"):
         assert got[name] == b.KERNEL_OPS[name], (name, got[name])
     # the bounds build uses the 8-bit comb (32 mixed additions of 7 products); the product build's 23-bit comb has 11
     m8, s8 = got["scalar_mul_base_w8"]

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-DD377_DCB_K=8", "-DD377_WAVES_PER_SIMD=2"] + sys.argv[1:]
-for unit in ("d377", "msm"):
+for unit in ("d377", "msm", "codec_chunked"):
     out = "/tmp/spill_sites_%s.s" % unit
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["--cuda-device-only", "-S", "decaf377_amd/csrc/%s.hip" % unit, "-o", out],
                           stderr=subprocess.DEVNULL)
