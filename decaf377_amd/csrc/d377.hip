@@ -939,6 +939,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var_el(con
     for (int j = 0; j < dcb.per_lane; ++j) {
       const size_t i = chunk * chunk_elems + (size_t)j * BLOCK + threadIdx.x;
       if (i >= n) break;
+      dcb_progress_priority(dcb.prio, j, dcb.per_lane);  // dcb.hpp: the wave that is behind outranks the one ahead
       uint32_t k[8], dg[8];
       load32(scalar32, i, k);
       const ge g = load_ge_mont256(xyzt, i);
@@ -1609,6 +1610,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       int gb;
       DcbScratch db;
       chunks_of(wide ? FB_SETS : WAVES_PER_SIMD, fk, gb, db);
+      if (wide) db.prio = 0;                                  // dcb.hpp dcb_progress_priority: waves in step gather in bursts
       if ((rc = vb.acquire())) return rc;
       hipLaunchKernelGGL(k_scalar_mul_base, dim3(gb), dim3(BLOCK), wide ? d.chunk_lds[CK_MUL_BASE] : d.fb_narrow_lds, s, T, d.fbase,
                          (const uint8_t*)in0, n, (uint8_t*)out0, db);
@@ -2250,6 +2252,15 @@ int d377_debug_poison_pool(d377_ctx* ctx, int dev, int sets) {
   if (sets) HIP_TRY(hipMemcpy(d.slot_pool, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
   return D377_OK;
 }
+#ifdef D377_WG_TIMES
+// developer variant only (dcb.hpp): the records of the last chunked kernel of THIS translation unit, 6 x u64 per workgroup
+extern "C" int d377_debug_wg_times(unsigned long long* out, int workgroups) {
+  if (!out || workgroups < 0 || workgroups > WG_TIMES_MAX) return D377_ERR_ARG;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_times), (size_t)workgroups * 6 * sizeof(unsigned long long)));
+  return D377_OK;
+}
+#endif
 int d377_ctx_chunk_residency(const d377_ctx* ctx, int dev, int* sets_per_cu, int* max_blocks_per_cu, int* lds_pad_bytes) {
   if (!ctx || dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "bad context or device index");
   const DeviceState& d = ctx->devs[(size_t)dev];

@@ -57,6 +57,7 @@ struct DcbScratch {
   int lanes;           // the layout's lane count: the same for every kernel, so a set is the same memory whoever claims it
   int extra;           // launches of one workgroup per chunk: the first `extra` workgroups take per_lane + 1 elements per lane (0: every chunk alike)
   uint32_t* health;    // [0] ticket counter, [1] workgroups that waited DCB_STUCK_TICKS for a set, [2] workgroups that gave up
+  int prio = 1;        // issue priority by progress (dcb_progress_priority below); 0: the launch leaves the arbiter alone
 };
 constexpr uint64_t DCB_STUCK_TICKS = 25000000ull;        // wall_clock64() ticks (100 MHz): 0.25 s
 constexpr uint64_t DCB_GIVE_UP_TICKS = 1000000000ull;    // 10 s
@@ -67,6 +68,7 @@ struct DcbIO {
   int slot, per_lane, extra;
   int* claim;                           // this workgroup's word of the pool (holds its ticket)
   uint32_t* tickets;                    // the ticket counter (health[0])
+  int prio;                             // DcbScratch::prio
   __device__ __forceinline__ size_t rec(int sl, int j) const { return (size_t)(sl * DCB_KMAX + j) * nlanes + lane; }
   __device__ __forceinline__ void put(int sl, int j, const uint32_t w[8]) { store32(scratch, rec(sl, j), w); }
   __device__ __forceinline__ void get(int sl, int j, uint32_t w[8]) const { load32(scratch, rec(sl, j), w); }
@@ -81,7 +83,11 @@ __device__ __forceinline__ int dcb_claim(const DcbScratch& sc) {
   __shared__ int s_slot;
   if (threadIdx.x == 0) {
     const int ticket = (int)(atomicAdd(&sc.health[0], 1u) & 0x7FFFFFFFu) + 1;
+#ifdef D377_SLOT_ROT                                     // experiment: a workgroup's first choice of lane set shifted by one (set parity against XCD parity)
+    int s = (int)((blockIdx.x + 1u) % (unsigned)sc.nslots);
+#else
     int s = (int)(blockIdx.x % (unsigned)sc.nslots);
+#endif
     int tries = 0;
     uint64_t t0 = 0;
     bool counted = false;
@@ -121,6 +127,32 @@ __device__ __forceinline__ void dcb_release(const DcbScratch& sc, int slot) {
 // and at those batch sizes (n <= 2 x the resident lanes) its latency is the whole call.  SMALL_OK = false keeps a
 // kernel on the always-assisted form (k_scalar_mul_var: its codegen is left exactly as it was measured).
 constexpr int DCB_ASSIST_MIN = 3;
+// Issue priority by progress.  The waves that share a SIMD (one of each resident workgroup) do the same work, and the
+// arbiter serves the OLDEST first: left alone, the older wave runs at a lone wave's rate (0.87 of the slots), the younger
+// one gets the rest (0.10), and once the older workgroup is done the younger runs alone for 0.89 of its chunk --
+// measured per workgroup at 2^20 (one generation: tools/wg_times.py, profiles/r05_wg_times.txt): durations from 980 to
+// 1 850 us for identical work, the kernel as long as the slowest.  A launch of several generations hides it (the CU is
+// refilled), a launch of one pays ~5 %.  So a wave lowers its priority as it gets through its chunk -- 3 for the first
+// half, 2 for the next quarter, then 1, and 0 for the last element -- and the wave that is behind always outranks the one
+// ahead: they take turns and end within the last stretch of each other.  2^20 elements (profiles/r05_ab_progress_priority.txt):
+// sqrt -8 %, encode_to_curve / hash_to_curve -6 / -7 %, round trip -4 %, variable and fixed base -5 %; 2^22: -0 ... -1 %.
+// The waves of a SIMD then run in step, which the fixed-base kernel's WIDE launch does not like (its additions wait on
+// table gathers, and waves in step gather in bursts: +4 % at 2^22), so a launch can leave the arbiter alone (`on`).
+#ifndef D377_DCB_PRIORITY
+#define D377_DCB_PRIORITY 1
+#endif
+__device__ __forceinline__ void dcb_progress_priority(int on, int j, int per_lane) {   // all uniform over the wave
+#if D377_DCB_PRIORITY
+  if (!on) return;
+  const int left = per_lane - j;                   // elements of the chunk still to do, this one included
+  if (left * 2 > per_lane) __builtin_amdgcn_s_setprio(3);
+  else if (left * 4 > per_lane) __builtin_amdgcn_s_setprio(2);
+  else if (left > 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#else
+  (void)on; (void)j; (void)per_lane;
+#endif
+}
 // post(io, cnt): runs after a chunk's outputs have been written (a kernel's rare fix-ups: k_hash_to_curve).
 struct DcbNoPost { __device__ __forceinline__ void operator()(DcbIO&, int) const {} };
 template <int NINV, bool FINISH, bool SMALL_OK = true, class PT, class P0, class P1, class PF = DcbNoPost>
@@ -150,6 +182,7 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
       atomicExch(io.claim, (int)(atomicAdd(io.tickets, 1u) & 0x7FFFFFFFu) + 1);
 #endif
     int cnt = 0;
+    dcb_progress_priority(io.prio, 0, per_lane);
 #pragma unroll 1
     for (int j = 0; j < per_lane; ++j) {
       const size_t i = io.base + (size_t)j * BLOCK;
@@ -169,6 +202,7 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
     }
 #pragma unroll 1
     for (int j = 0; j < cnt; ++j) {
+      dcb_progress_priority(io.prio, j, per_lane);
       uint32_t cur[NW][8] = {};
       if (assist) {
 #pragma unroll
@@ -184,12 +218,39 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
     post(io, cnt);
   }
 }
+// Developer variant (tools/build_variant.sh wgtimes -DD377_WG_TIMES; tools/wg_times.py): every workgroup of a chunked kernel of
+// d377.hip leaves its entry time, the time it held a lane set, its end time (wall_clock64: 100 MHz) and where it ran
+// (XCC_ID, HW_ID).  Not in the product build.
+#ifdef D377_WG_TIMES
+constexpr int WG_TIMES_MAX = 16384;
+static __device__ unsigned long long g_wg_times[WG_TIMES_MAX * 6];   // entry, set claimed, end (100 MHz); XCC_ID | HW_ID; clock64() at claim and end
+#define D377_WG_T0() const unsigned long long wg_t0_ = wall_clock64()
+#define D377_WG_T1()                                                                              \
+  if (threadIdx.x == 0 && blockIdx.x < (unsigned)WG_TIMES_MAX) {                                  \
+    g_wg_times[blockIdx.x * 6 + 0] = wg_t0_;                                                      \
+    g_wg_times[blockIdx.x * 6 + 1] = wall_clock64();                                              \
+    g_wg_times[blockIdx.x * 6 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32) | /* XCC_ID[3:0] */ \
+                                     (unsigned)__builtin_amdgcn_s_getreg(63492);                   /* HW_ID */       \
+    g_wg_times[blockIdx.x * 6 + 4] = clock64();                                                   \
+  }
+#define D377_WG_T2()                                                                              \
+  if (threadIdx.x == 0 && blockIdx.x < (unsigned)WG_TIMES_MAX) {                                  \
+    g_wg_times[blockIdx.x * 6 + 2] = wall_clock64();                                              \
+    g_wg_times[blockIdx.x * 6 + 5] = clock64();                                                   \
+  }
+#else
+#define D377_WG_T0()
+#define D377_WG_T1()
+#define D377_WG_T2()
+#endif
 #define D377_DCB_BEGIN(out_ptr)                                                                   \
+  D377_WG_T0();                                                                                   \
   const int dcb_slot_ = dcb_claim(dcb);                                                           \
+  D377_WG_T1();                                                                                   \
   if (dcb_slot_ < 0) return;                      /* no set for DCB_GIVE_UP_TICKS: counted in health[2] */ \
   DcbIO io{dcb.rec, reinterpret_cast<uint8_t*>(out_ptr), (size_t)dcb.lanes,                      \
            (size_t)dcb_slot_ * BLOCK + threadIdx.x, 0, dcb_slot_, dcb.per_lane, dcb.extra,       \
-           dcb.pool + dcb_slot_, dcb.health}
-#define D377_DCB_END() dcb_release(dcb, dcb_slot_)
+           dcb.pool + dcb_slot_, dcb.health, dcb.prio}
+#define D377_DCB_END() dcb_release(dcb, dcb_slot_); D377_WG_T2()
 
 }  // namespace d377

@@ -708,6 +708,14 @@ k_msm_spans(const uint32_t* pts, const uint32_t* idx, SpanPlan sp, const uint32_
     uint32_t e_nxt = iw[pos + 1 < end ? pos + 1 : end - 1];
     gea_raw r = pt_load_affine_raw(pts + (size_t)(e_cur & 0x7FFFFFFFu) * AP_WORDS);
     uint32_t j = pos;                                    // entries [pos, j) are in acc (or flushed); r holds entry j
+    // Issue priority by progress (dcb.hpp: dcb_progress_priority): the four waves of a SIMD have the same L additions to do and
+    // the arbiter serves the oldest first, so they would end one after the other and the last run alone; a wave that is
+    // behind outranks the ones ahead instead (3 for the first half of its span, 2 to 7/8, 1 to 31/32, then 0).
+#if D377_DCB_PRIORITY
+    uint32_t step = 0;                                   // additions done (the same in every lane of the wave)
+    const uint32_t step2 = L / 2, step1 = L - L / 8, step0 = L - L / 32;
+    __builtin_amdgcn_s_setprio(3);
+#endif
     ge acc;
     {                                                    // the lane's first entry is lifted from its record (4 products)
       const bool neg = (e_cur >> 31) != 0;
@@ -746,6 +754,12 @@ k_msm_spans(const uint32_t* pts, const uint32_t* idx, SpanPlan sp, const uint32_
       asm volatile("" ::: "memory");                     // ... and no load sinks below this line, to its first use after the addition
       acc = ge_add_affine(acc, cur, neg, true);
       ++j;
+#if D377_DCB_PRIORITY
+      ++step;
+      if (step == step2) __builtin_amdgcn_s_setprio(2);
+      else if (step == step1) __builtin_amdgcn_s_setprio(1);
+      else if (step == step0) __builtin_amdgcn_s_setprio(0);
+#endif
     }
   }
 }
