@@ -1526,6 +1526,11 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
     grid = (int)nchunks;
     sc = DcbScratch{d.dcb_scratch, d.slot_pool, d.cus * sets, (int)per_lane, d.dcb_sets * BLOCK, (int)extra, d.pool_health};
+    // Issue priority by progress (dcb.hpp dcb_progress_priority) for launches of one or two generations of workgroups: there the
+    // workgroups of a CU would end one after the other (-4 to -8 % at 2^20, -1 to -3 % at 1.5 and 2 x 2^20).  Longer launches
+    // refill their CUs and only their last generation has that tail: within +-1 % either way at 2^22, so they stay as they
+    // were measured (profiles/r05_ab_progress_priority.txt).
+    sc.prio = nchunks <= 2 * places ? 1 : 0;
   };
   chunks_of(WAVES_PER_SIMD, DCB_K, gv, dcb);  // every chunked kernel but the fixed-base one
   GuardScope vb{d.vb_guard, s};            // released (event recorded) when this function returns, if it was acquired

@@ -141,8 +141,11 @@ constexpr int DCB_ASSIST_MIN = 3;
 #ifndef D377_DCB_PRIORITY
 #define D377_DCB_PRIORITY 1
 #endif
+// (s_setprio is a scalar instruction: under a condition the compiler holds in vector registers it is predicated by EXEC
+// only -- it runs whatever the mask says -- so every condition around one is forced into scalar registers first.)
 __device__ __forceinline__ void dcb_progress_priority(int on, int j, int per_lane) {   // all uniform over the wave
 #if D377_DCB_PRIORITY
+  on = __builtin_amdgcn_readfirstlane(on); j = __builtin_amdgcn_readfirstlane(j); per_lane = __builtin_amdgcn_readfirstlane(per_lane);
   if (!on) return;
   const int left = per_lane - j;                   // elements of the chunk still to do, this one included
   if (left * 2 > per_lane) __builtin_amdgcn_s_setprio(3);
@@ -151,6 +154,21 @@ __device__ __forceinline__ void dcb_progress_priority(int on, int j, int per_lan
   else __builtin_amdgcn_s_setprio(0);
 #else
   (void)on; (void)j; (void)per_lane;
+#endif
+}
+// The same at a finer grain, for a kernel that counts steps of its own (k_msm_spans: additions): `done` of `total` steps are
+// behind the wave; 3 up to half of them, 2 up to three quarters, 1 up to the last `last`, then 0.  Called once per step.
+// (At the grain of the variable-base kernels' windows instead of their elements: -1 to -3 % between 2^17 and 2^19, but +2 %
+// at 2^16 and, for the Element form, from 2^20 on: not kept -- profiles/r05_ab_progress_priority.txt.)
+__device__ __forceinline__ void dcb_progress_priority_steps(int done, int total, int last) {
+#if D377_DCB_PRIORITY
+  done = __builtin_amdgcn_readfirstlane(done); total = __builtin_amdgcn_readfirstlane(total); last = __builtin_amdgcn_readfirstlane(last);
+  if (done == 0) __builtin_amdgcn_s_setprio(3);
+  else if (done == total / 2) __builtin_amdgcn_s_setprio(2);
+  else if (done == total - total / 4) __builtin_amdgcn_s_setprio(1);
+  else if (done == total - last) __builtin_amdgcn_s_setprio(0);
+#else
+  (void)done; (void)total; (void)last;
 #endif
 }
 // post(io, cnt): runs after a chunk's outputs have been written (a kernel's rare fix-ups: k_hash_to_curve).

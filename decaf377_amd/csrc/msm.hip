@@ -710,12 +710,10 @@ k_msm_spans(const uint32_t* pts, const uint32_t* idx, SpanPlan sp, const uint32_
     uint32_t j = pos;                                    // entries [pos, j) are in acc (or flushed); r holds entry j
     // Issue priority by progress (dcb.hpp: dcb_progress_priority): the four waves of a SIMD have the same L additions to do and
     // the arbiter serves the oldest first, so they would end one after the other and the last run alone; a wave that is
-    // behind outranks the ones ahead instead (3 for the first half of its span, 2 to 7/8, 1 to 31/32, then 0).
-#if D377_DCB_PRIORITY
-    uint32_t step = 0;                                   // additions done (the same in every lane of the wave)
-    const uint32_t step2 = L / 2, step1 = L - L / 8, step0 = L - L / 32;
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    // behind outranks the ones ahead instead (3 for the first half of its span, 2 to 3/4, 1 to 31/32, then 0).
+    int step = 0;                                        // additions done (the same in every lane of the wave)
+    const int last = (int)(L / 32) > 0 ? (int)(L / 32) : 1;
+    dcb_progress_priority_steps(0, (int)L, last);
     ge acc;
     {                                                    // the lane's first entry is lifted from its record (4 products)
       const bool neg = (e_cur >> 31) != 0;
@@ -754,12 +752,7 @@ k_msm_spans(const uint32_t* pts, const uint32_t* idx, SpanPlan sp, const uint32_
       asm volatile("" ::: "memory");                     // ... and no load sinks below this line, to its first use after the addition
       acc = ge_add_affine(acc, cur, neg, true);
       ++j;
-#if D377_DCB_PRIORITY
-      ++step;
-      if (step == step2) __builtin_amdgcn_s_setprio(2);
-      else if (step == step1) __builtin_amdgcn_s_setprio(1);
-      else if (step == step0) __builtin_amdgcn_s_setprio(0);
-#endif
+      dcb_progress_priority_steps(++step, (int)L, last);
     }
   }
 }
@@ -1674,7 +1667,8 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
       if (n >= chunked_min && d.msm_enc_chunked == 1) {
         const ChunkDeal c = deal_chunks((n + BLOCK - 1) / BLOCK, (size_t)d.cus * WAVES_PER_SIMD, (size_t)DCB_K, (size_t)d.cus * 64);
         const size_t nchunks = c.nchunks;
-        const DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)c.per_lane, d.dcb_sets * BLOCK, (int)c.extra, d.pool_health};
+        DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)c.per_lane, d.dcb_sets * BLOCK, (int)c.extra, d.pool_health};
+        dcb.prio = nchunks <= 2 * (size_t)d.cus * WAVES_PER_SIMD ? 1 : 0;      // as d377.hip's chunks_of: launches of one or two generations
         GuardScope vb{d.vb_guard, s};                       // the lane-set areas: queue behind their last user
         if ((rc = vb.acquire())) return rc;
         hipLaunchKernelGGL(k_msm_prepare_enc_chunked, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, wshape,
