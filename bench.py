@@ -392,7 +392,13 @@ def main():
         "kernel_ms": kernel_ms,
         "note": "integer-ALU-bound kernel: 3.7e5 32-bit MACs per 97 algorithmic bytes; see roofline_valu",
     }
-    macs = KERNEL_MACS["scalar_mul_var"] * n / (kernel_ms * 1e-3)
+    # beyond 8 elements per resident lane (2 workgroups x 256 lanes per CU) a chunk shares its two inversions among up to 16
+    # elements per lane (dcb.hpp DCB_K_LONG): the divsteps' share of an element is 2/16 instead of 2/8 there
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    macs_el = KERNEL_MACS["scalar_mul_var"]
+    if n > 8 * 512 * cus:
+        macs_el -= (2 / 8.0 - 2 / 16.0) * DIVSTEP_MACS_PER_INVERSION
+    macs = macs_el * n / (kernel_ms * 1e-3)
     line["roofline_valu"] = {
         "bound": "valu_int32_mac",
         "achieved": macs / 1e12,
@@ -401,13 +407,13 @@ def main():
         "frac": macs / VALU_MAC_PEAK,
         "peak_measured": VALU_MAC_PEAK_MEASURED / 1e12,
         "frac_of_measured": macs / VALU_MAC_PEAK_MEASURED,
-        "macs_per_element": KERNEL_MACS["scalar_mul_var"],
+        "macs_per_element": macs_el,
     }
     if pmc.get("valu_insts_per_element"):
         # every VALU instruction of this stream costs one issue slot: MACs / all VALU instructions is the ceiling
         # of `frac` for this instruction stream, and instructions/s against the issue rate says how full the pipe is
         vi = pmc["valu_insts_per_element"]
-        line["roofline_valu"]["valu_insts_per_mac"] = vi / KERNEL_MACS["scalar_mul_var"]
+        line["roofline_valu"]["valu_insts_per_mac"] = vi / macs_el
         # VALU instructions/s against one wave-instruction per 4 cycles per SIMD AT THE NOMINAL 2.4 GHz (DESIGN.md section 5's
         # "issue-slot utilisation" divides by the cycles the chip really ran, GRBM_GUI_ACTIVE, and reads ~0.04 higher)
         line["roofline_valu"]["valu_issue_frac_at_nominal_clock"] = vi * n / (kernel_ms * 1e-3) / VALU_MAC_PEAK

@@ -1157,8 +1157,9 @@ D377_HD void fr_half_words(uint32_t k[8]) {
 #ifndef D377_DCB_K
 #define D377_DCB_K 8
 #endif
-constexpr int DCB_K = D377_DCB_K;       // elements per lane per inversion (measured: 4 / 8 / 16 -> 60.9 / 61.0 / 62.0 ms per 2^22 var-base,
-                                        // 8 best for the 2^20 operations)
+constexpr int DCB_K = D377_DCB_K;       // elements per lane per inversion in one generation of workgroups (measured under the arbiter's own
+                                        // order: 4 / 8 / 16 -> 60.9 / 61.0 / 62.0 ms per 2^22 var-base, 8 best for the 2^20 operations);
+                                        // longer launches: dcb.hpp DCB_K_LONG
 #if defined(D377_CHECK_INVARIANTS)
 constexpr bool DCB_WANT_T = true;       // the debug assertions re-check T Z = X Y on the half point
 #else

@@ -1532,7 +1532,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     // were measured (profiles/r05_ab_progress_priority.txt).
     sc.prio = nchunks <= 2 * places ? 1 : 0;
   };
-  chunks_of(WAVES_PER_SIMD, DCB_K, gv, dcb);  // every chunked kernel but the fixed-base one
+  chunks_of(WAVES_PER_SIMD, DCB_K_LONG, gv, dcb);  // every chunked kernel but the fixed-base one (up to 2^20 on 256 CUs: <= DCB_K per lane either way)
   GuardScope vb{d.vb_guard, s};            // released (event recorded) when this function returns, if it was acquired
   int rc;
   switch (op) {

@@ -21,6 +21,12 @@ constexpr int DCB_KMAX = 16;
 constexpr int FB_SETS = D377_FB_SETS, FB_K = 16;
 constexpr int FB_WIDE_GENERATIONS = 1;            // generations of full narrow chunks beyond which the fixed-base kernel takes FB_SETS / FB_K
 constexpr int DCB_SETS_MAX = FB_SETS > WAVES_PER_SIMD ? FB_SETS : WAVES_PER_SIMD;
+// Beyond one generation of DCB_K elements per resident lane (2^20 on 256 CUs) a chunk grows to DCB_K_LONG per lane before
+// the launch takes a further generation of workgroups: with issue priority by progress (below) a launch of one or two
+// generations has next to no tail, so fewer, longer generations win -- 8 -> 16 per lane: variable base -1.4 % at 2^22
+// (61.2 -> 60.4 ms, same box), -2.2 % at 3 x 2^20, sqrt -3 to -7 %, encode_to_curve / hash_to_curve -2 % at 2^22, unchanged
+// at 2^23 (profiles/r05_ab_progress_priority.txt; under the arbiter's own order 16 per lane had LOST 1.6 %: curve.hpp).
+constexpr int DCB_K_LONG = DCB_KMAX;
 static_assert(DCB_K <= DCB_KMAX && FB_K <= DCB_KMAX, "the scratch layout has DCB_KMAX record rows per slot");
 
 // Round storage of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish): [5 slots][DCB_KMAX][lanes] 32-byte
@@ -135,9 +141,10 @@ constexpr int DCB_ASSIST_MIN = 3;
 // refilled), a launch of one pays ~5 %.  So a wave lowers its priority as it gets through its chunk -- 3 for the first
 // half, 2 for the next quarter, then 1, and 0 for the last element -- and the wave that is behind always outranks the one
 // ahead: they take turns and end within the last stretch of each other.  2^20 elements (profiles/r05_ab_progress_priority.txt):
-// sqrt -8 %, encode_to_curve / hash_to_curve -6 / -7 %, round trip -4 %, variable and fixed base -5 %; 2^22: -0 ... -1 %.
+// sqrt -8 %, encode_to_curve / hash_to_curve -6 / -7 %, round trip -4 %, variable and fixed base -5 %; 2^22: within +-1 %.
 // The waves of a SIMD then run in step, which the fixed-base kernel's WIDE launch does not like (its additions wait on
-// table gathers, and waves in step gather in bursts: +4 % at 2^22), so a launch can leave the arbiter alone (`on`).
+// table gathers, and waves in step gather in bursts: +4 % at 2^22), so a launch can leave the arbiter alone (`on`): the
+// host asks for priorities in launches of one or two generations of workgroups (d377.hip: chunks_of).
 #ifndef D377_DCB_PRIORITY
 #define D377_DCB_PRIORITY 1
 #endif

@@ -1665,7 +1665,7 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
         d.msm_enc_chunked = (nb >= 1 && nb <= WAVES_PER_SIMD) ? 1 : 0;
       }
       if (n >= chunked_min && d.msm_enc_chunked == 1) {
-        const ChunkDeal c = deal_chunks((n + BLOCK - 1) / BLOCK, (size_t)d.cus * WAVES_PER_SIMD, (size_t)DCB_K, (size_t)d.cus * 64);
+        const ChunkDeal c = deal_chunks((n + BLOCK - 1) / BLOCK, (size_t)d.cus * WAVES_PER_SIMD, (size_t)DCB_K_LONG, (size_t)d.cus * 64);
         const size_t nchunks = c.nchunks;
         DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)c.per_lane, d.dcb_sets * BLOCK, (int)c.extra, d.pool_health};
         dcb.prio = nchunks <= 2 * (size_t)d.cus * WAVES_PER_SIMD ? 1 : 0;      // as d377.hip's chunks_of: launches of one or two generations

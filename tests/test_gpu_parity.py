@@ -476,9 +476,9 @@ def test_full_size_hash_to_curve_two_routes_2_20(ctx, torch_mod, oracle):
 def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
     """The square-root-free compressor (curve.hpp `dcb_finish`; reference: src/ark_curve/encoding.rs:91-128) and the
     batched inversions work in chunks: one workgroup takes per_lane x 256 consecutive elements, per_lane = ceil(n /
-    resident lanes) capped at DCB_K = 8 (d377.hip `launch`; resident lanes = 2 workgroups x 256 lanes per CU = 131 072
-    on 256 CUs), and a lane inverts once for the per_lane elements it holds.  Sizes around every per_lane transition
-    (k x 131 072 +- 1 for k = 1..8: the last workgroup's lanes then hold per_lane, per_lane - 1 or 0 elements), sizes
+    resident lanes) capped at 16 (dcb.hpp DCB_K_LONG; d377.hip `launch`; resident lanes = 2 workgroups x 256 lanes per CU
+    = 131 072 on 256 CUs), and a lane inverts once for the per_lane elements it holds.  Sizes around every per_lane transition
+    (k x 131 072 +- 1 for k = 1..8, 12, 16, 17: the last workgroup's lanes then hold per_lane, per_lane - 1 or 0 elements), sizes
     that leave whole waves of the last chunk empty, and sizes several grid generations long must give the oracle's
     bytes on the first and last records and a spread in between -- for the variable-base, the fixed-base and the
     Elligator kernels, with invalid encodings and identity results sprinkled in, and in place."""
@@ -487,7 +487,7 @@ def test_batched_compressor_rounds_and_lane_tails(ctx, torch_mod, oracle):
     lanes = torch.cuda.get_device_properties(0).multi_processor_count * 2 * 256
     g = torch.Generator(device=dev).manual_seed(9077)
     sizes = [lanes - 5, lanes + 7, 31 * lanes + 3, 32 * lanes, 32 * lanes + 4099]
-    for kk in range(1, 9):
+    for kk in list(range(1, 9)) + [12, 16, 17]:
         sizes += [kk * lanes - 1, kk * lanes, kk * lanes + 1]
     sizes += [8 * lanes + 256 * 8 + 1, 255, 257, 64, 1]
     for n in sorted(set(sizes)):
@@ -525,8 +525,9 @@ def test_ragged_chunks_match_uniform_chunks(ctx, torch_mod, oracle):
     dev = torch.device("cuda:0")
     places = torch.cuda.get_device_properties(0).multi_processor_count * 2
     g = torch.Generator(device=dev).manual_seed(515)
-    # ... and beyond one generation the same deal over the fewest generations that hold the rounds (host_state.hpp deal_chunks):
-    # 10 rounds per place and a few (two generations of 5, three chunks of 6), 17 and a third (three generations of 5 and 6)
+    # ... and beyond 8 rounds per place chunks of up to 16 per lane (dcb.hpp DCB_K_LONG), dealt the same way over the fewest
+    # generations that hold them (host_state.hpp deal_chunks): 10 rounds per place and a few (one generation of 10, three
+    # chunks of 11), 17 and a third (two generations of 8 and 9)
     sizes = [places * 256 + 1, places * 256 + 256 * 97 - 13, 2 * places * 256 + 255, 3 * places * 256 - 256 - 1,
              (7 * places + 1) * 256 + 5, (3 * places + places // 2) * 256,
              (10 * places + 3) * 256 + 7, (17 * places + places // 3) * 256 - 1]
@@ -568,20 +569,20 @@ def test_ragged_chunks_match_uniform_chunks(ctx, torch_mod, oracle):
 
 
 def test_workgroups_walk_several_chunks_beyond_the_grid_cap(ctx, torch_mod, oracle):
-    """Beyond 64 chunks per CU (2^25 elements on 256 CUs) the grid stops growing and a workgroup walks several chunks of 8
+    """Beyond 64 chunks per CU (2^26 elements on 256 CUs) the grid stops growing and a workgroup walks several chunks of 16
     elements per lane, drawing a new ticket for each (dcb.hpp dcb_rounds; host_state.hpp deal_chunks): the largest shape a
     call can take.  Same bytes as the two halves as calls of their own (dealt out evenly, one chunk per workgroup), and a
     sample is the oracle's."""
     torch = torch_mod
     dev = torch.device("cuda:0")
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    n = cus * 64 * 8 * 256 + 256 * 3 + 5                  # one chunk more than the cap, the last one ragged
+    n = cus * 64 * 16 * 256 + 256 * 3 + 5                 # one chunk more than the cap, the last one ragged
     g = torch.Generator(device=dev).manual_seed(2525)
     r0 = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
     out = ctx.encode_to_curve(r0)
     h = n // 2 + 11
     assert torch.equal(out[:h], ctx.encode_to_curve(r0[:h])) and torch.equal(out[h:], ctx.encode_to_curve(r0[h:]))
-    idx = np.unique(np.concatenate([np.arange(300), np.arange(n - 1500, n), np.arange(cus * 64 * 8 * 256 - 300, cus * 64 * 8 * 256 + 300),
+    idx = np.unique(np.concatenate([np.arange(300), np.arange(n - 1500, n), np.arange(cus * 64 * 16 * 256 - 300, cus * 64 * 16 * 256 + 300),
                                     np.arange(31, n, n // 97)]))
     ti = torch.from_numpy(idx).to(dev)
     assert (out[ti].cpu().numpy() == oracle.encode_to_curve(r0[ti].cpu().numpy())).all()
