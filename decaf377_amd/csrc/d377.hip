@@ -1615,7 +1615,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       int gb;
       DcbScratch db;
       chunks_of(wide ? FB_SETS : WAVES_PER_SIMD, fk, gb, db);
-      if (wide) db.prio = 0;                                  // dcb.hpp dcb_progress_priority: waves in step gather in bursts
+      // dcb.hpp dcb_progress_priority in the wide launch: one generation only (-1 % at 1.25 x 2^20, -2 % at 2^21); two generations
+      // of waves in step gather their table entries in bursts (+6 to +10 % at 2^22: profiles/r05_ab_progress_priority.txt)
+      if (wide && gb > d.cus * FB_SETS) db.prio = 0;
       if ((rc = vb.acquire())) return rc;
       hipLaunchKernelGGL(k_scalar_mul_base, dim3(gb), dim3(BLOCK), wide ? d.chunk_lds[CK_MUL_BASE] : d.fb_narrow_lds, s, T, d.fbase,
                          (const uint8_t*)in0, n, (uint8_t*)out0, db);

@@ -142,9 +142,9 @@ constexpr int DCB_ASSIST_MIN = 3;
 // half, 2 for the next quarter, then 1, and 0 for the last element -- and the wave that is behind always outranks the one
 // ahead: they take turns and end within the last stretch of each other.  2^20 elements (profiles/r05_ab_progress_priority.txt):
 // sqrt -8 %, encode_to_curve / hash_to_curve -6 / -7 %, round trip -4 %, variable and fixed base -5 %; 2^22: within +-1 %.
-// The waves of a SIMD then run in step, which the fixed-base kernel's WIDE launch does not like (its additions wait on
-// table gathers, and waves in step gather in bursts: +4 % at 2^22), so a launch can leave the arbiter alone (`on`): the
-// host asks for priorities in launches of one or two generations of workgroups (d377.hip: chunks_of).
+// The waves of a SIMD then run in step, which the fixed-base kernel's WIDE launch does not like beyond one generation (its
+// additions wait on table gathers, and waves in step gather in bursts: +4 to +10 % at 2^22), so a launch can leave the arbiter
+// alone (`on`): the host asks for priorities in launches of one or two generations of workgroups (d377.hip: chunks_of).
 #ifndef D377_DCB_PRIORITY
 #define D377_DCB_PRIORITY 1
 #endif
