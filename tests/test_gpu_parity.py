@@ -830,7 +830,8 @@ def test_hash_to_curve_exceptional_pairs_in_the_product_build(ctx, oracle, torch
     want_e = np.array([list(bytes.fromhex(p["encoding"])) for p in pairs], np.uint8)
     rng = np.random.default_rng(4404)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    for n in (len(pairs), 8 * cus - 3, 16 * cus - 3, 70001):
+    # ... the last two in chunks of 5-6 and of 12-13 pairs per lane (the redo loop after a chunk's outputs: d377.hip k_hash_to_curve)
+    for n in (len(pairs), 8 * cus - 3, 16 * cus - 3, 70001, 5 * 512 * cus + 3, 12 * 512 * cus + 77):
         r1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
         r2 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
         pos = np.arange(len(pairs)) if n == len(pairs) else rng.choice(n, len(pairs), replace=False)
