@@ -55,7 +55,7 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
 # of a chunk (denominators, compressor: 3-4 M per element each, and one divsteps inversion per lane per 8 elements
 # each: inv30.hpp, 20 rounds x 90 signed 64-bit MACs on 30-bit limbs, + 2 M).  The 2^20 extras are counted at the
 # 8 elements per lane they have.
-KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (88.25, 3.0),
+KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (85.25, 3.0),
               "sqrt_ratio_zeta": (75.25, 241.0), "encode_to_curve": (102.5, 243.0), "hash_to_curve": (202.75, 491.0),
               "decompress": (93.0, 291.0), "compress": (92.0, 289.0),
               # decompress from 3 elements per resident lane (393 216 on 256 CUs): chunks with batched inverses (d377.hip)

@@ -1083,13 +1083,24 @@ D377_HD int fb_digit(const uint32_t k[8], int i, uint32_t& carry) {
 // in flight instead of one: 1.07-1.11e9/s against 1.09-1.12e9/s at 2^20 and 2^22, same box -- the gathers are covered.)
 template <class FTab>
 D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab, bool want_t = true) {
-  ge r = ge_identity();
   uint32_t carry = 0;
   int d = fb_digit(k, 0, carry);
   bool neg = d < 0;
   gea e = ftab.load(0, neg ? -d : d, neg);
+  // window 0: the sum starts from the record itself (ge_from_cached_affine: 4 products) instead of a 7-product addition to
+  // the identity -- 85 M + 3 S per scalar where the plain loop took 88 M + 3 S
+  ge r;
+  {
+    const gea cur = e;
+    const bool neg_cur = neg;
+    d = fb_digit(k, 1, carry);
+    neg = d < 0;
+    e = ftab.load(1, neg ? -d : d, neg);
+    r = ge_from_cached_affine(cur, neg_cur);
+  }
+  static_assert(FB_WINDOWS >= 2, "the first window is peeled off the loop");
 #pragma unroll 1
-  for (int i = 0; i < FB_WINDOWS; ++i) {
+  for (int i = 1; i < FB_WINDOWS; ++i) {
     const gea cur = e;
     const bool neg_cur = neg;
     if (i + 1 < FB_WINDOWS) {
