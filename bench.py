@@ -58,7 +58,7 @@ ALGO_BYTES = {"scalar_mul_var": 97, "roundtrip": 65, "encode_to_curve": 64, "sca
 KERNEL_OPS = {"scalar_mul_var": (1668.5, 1009.0), "roundtrip": (177, 580), "scalar_mul_base": (85.25, 3.0),
               "sqrt_ratio_zeta": (75.25, 241.0), "encode_to_curve": (102.5, 243.0), "hash_to_curve": (202.75, 491.0),
               "decompress": (93.0, 291.0), "compress": (92.0, 289.0),
-              # decompress from 3 elements per resident lane (393 216 on 256 CUs): chunks with batched inverses (d377.hip)
+              # decompress from 2 elements per resident lane (262 144 on 256 CUs): chunks with batched inverses (d377.hip)
               "decompress_chunked": (88.25, 246.0), "compress_chunked": (91.25, 243.0), "roundtrip_chunked": (168.5, 489.0)}
 # divsteps inversions per element (one per lane per 8 elements and per batched-inversion pass of the kernel)
 KERNEL_INVERSIONS = {"scalar_mul_var": 2 / 8.0, "scalar_mul_base": 1 / 8.0, "sqrt_ratio_zeta": 1 / 8.0, "encode_to_curve": 2 / 8.0,
@@ -470,9 +470,9 @@ def main():
     if not args.no_extra:
         extra = dict(multi)
         ne = min(1 << 20, n)
-        # from 3 elements per resident lane (2 workgroups x 256 lanes per CU) decompress / compress / round trip run in chunks with
+        # from 2 elements per resident lane (2 workgroups x 256 lanes per CU) decompress / compress / round trip run in chunks with
         # batched inverses (d377.hip): fewer products per element, priced as such below
-        chunked_min = 3 * 512 * torch.cuda.get_device_properties(dev).multi_processor_count
+        chunked_min = 2 * 512 * torch.cuda.get_device_properties(dev).multi_processor_count
         enc1 = points[:ne]
         o1 = torch.empty((ne, 32), dtype=torch.uint8, device=dev)
         s1 = torch.empty((ne,), dtype=torch.uint8, device=dev)

@@ -216,11 +216,15 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_sqrt_ratio_zeta(SqrtT
   D377_DCB_END();
 }
 
+// Elements per resident lane from which decompress, compress and the round trip take their chunked forms.  Their shared
+// inversion paid from 3 per lane (393 216 elements on 256 CUs); with issue priority by progress (dcb.hpp) the chunked forms lead
+// from 2 (262 144: chunked / wide 0.97-0.99, 393 216: 0.94-0.96, 2^20: 0.90-0.95; profiles/r05_decompress_route_sweep.txt).
+constexpr int CODEC_CHUNKED_MIN = 2;
 // decompress, compress and the round trip run one element per lane on the wide grid, each square root in the
 // reference's inversion-free form: in chunks with batched inverses they execute 4-8 % fewer instructions.  All three
-// take the chunked form (k_decompress_chunked below; k_compress_chunked, k_roundtrip_chunked in codec_chunked.hip) as soon as a lane has the
-// DCB_ASSIST_MIN elements that make an inversion worth sharing: 3 x the resident lanes, 393 216 elements on 256 CUs
-// (decompress -4 % there, -5 % at 2^19, -7 % from 2^20 on; compress -1 / -1 / -6 / -4 %; round trip -3 / -3 / -3 / -5 %,
+// take the chunked form (k_decompress_chunked below; k_compress_chunked, k_roundtrip_chunked in codec_chunked.hip) from
+// CODEC_CHUNKED_MIN elements per resident lane (measured before the priorities, when the rule switched at 3 x the resident lanes:
+// decompress -4 % there, -5 % at 2^19, -7 % from 2^20 on; compress -1 / -1 / -6 / -4 %; round trip -3 / -3 / -3 / -5 %,
 // -6 % at 2^22: profiles/r05_decompress_route_sweep.txt; rounds 2-4 switched the decompression at 2^21 and left the
 // others on the wide grid, before a wave shared one inversion and before the rounds were dealt out evenly).
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_decompress(SqrtTables T, const uint8_t* enc32, size_t n,
@@ -1557,7 +1561,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
         break;
       }
       const size_t chunked_min = (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN,
-                                                 (long long)(d.resident_lanes() * DCB_ASSIST_MIN));
+                                                 (long long)(d.resident_lanes() * CODEC_CHUNKED_MIN));
       if (n >= chunked_min) {
         if ((rc = vb.acquire())) return rc;
         hipLaunchKernelGGL(k_decompress_chunked, dim3(gv), dim3(BLOCK), d.chunk_lds[CK_DECOMPRESS], s, T, (const uint8_t*)in0, n, (uint64_t*)out0,
@@ -1572,7 +1576,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
         hipLaunchKernelGGL(k_compress_tiny, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint64_t*)in0, n, (uint8_t*)out0);
         break;
       }
-      if (n >= (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_ASSIST_MIN)) &&   // as OP_DECOMPRESS
+      if (n >= (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN, (long long)(d.resident_lanes() * CODEC_CHUNKED_MIN)) &&   // as OP_DECOMPRESS
           codec_chunked_ok(d)) {                                                  // codec_chunked.hip
         if ((rc = vb.acquire())) return rc;
         if ((rc = codec_chunked_launch(d, s, false, in0, n, out0, nullptr, gv, dcb))) return rc;
@@ -1585,7 +1589,7 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
         hipLaunchKernelGGL(k_decompress_tiny<true>, dim3(tiny4_grid(n)), dim3(64), 0, s, T, (const uint8_t*)in0, n, (uint8_t*)out0, (uint8_t*)out1);
         break;
       }
-      if (n >= (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_ASSIST_MIN)) &&   // as OP_DECOMPRESS
+      if (n >= (size_t)d.tuned(D377_TUNE_DECOMPRESS_CHUNKED_MIN, (long long)(d.resident_lanes() * CODEC_CHUNKED_MIN)) &&   // as OP_DECOMPRESS
           codec_chunked_ok(d)) {
         if ((rc = vb.acquire())) return rc;
         if ((rc = codec_chunked_launch(d, s, true, in0, n, out0, out1, gv, dcb))) return rc;

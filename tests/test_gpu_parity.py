@@ -430,10 +430,11 @@ def test_batched_inverse_decoding_from_2_21(ctx, torch_mod, oracle):
     ident = torch.from_numpy(oracle.identity_xyzt().view(np.int64)).to(dev)
     Pz[st != 0] = ident
     assert bytes(ctx.msm(Pz, k2)[0]) == bytes(m[0])
-    # the chunked forms start at DCB_ASSIST_MIN = 3 elements per resident lane (2 workgroups x 256 lanes per CU): ragged sizes
-    # from there up, where the rounds are dealt out unevenly (DcbScratch::extra), against the wide grid
+    # the chunked forms start at 2 (decompress, compress, round trip: d377.hip CODEC_CHUNKED_MIN) and 3 (the MSM's decoding pass:
+    # DCB_ASSIST_MIN) elements per resident lane (2 workgroups x 256 lanes per CU): ragged sizes from there up, where the
+    # rounds are dealt out unevenly (DcbScratch::extra), against the wide grid
     lanes = torch.cuda.get_device_properties(0).multi_processor_count * 2 * 256
-    for n2 in (3 * lanes, 3 * lanes + 77, 5 * lanes - 3, 8 * lanes + 256 * 5 + 1, 9 * lanes + 13):
+    for n2 in (2 * lanes, 2 * lanes + 256 * 3 + 5, 3 * lanes, 3 * lanes + 77, 5 * lanes - 3, 8 * lanes + 256 * 5 + 1, 9 * lanes + 13):
         P, st = ctx.decompress(enc[:n2])
         m = ctx.msm(enc[:n2], k[:n2])
         rt, rst = ctx.roundtrip(enc[:n2])
