@@ -113,6 +113,47 @@ def test_regression_seeds(ctx, kats):
     assert (out[:2] == seeds[:2]).all() and not out[2].any()
 
 
+def test_groth16_gadget_regression_inputs_gpu(ctx, oracle, kats):
+    """tests/groth16_gadgets.proptest-regressions:7-15: the reference's shrunk gadget inputs (4 Element encodings, 3 Fr,
+    2 Fq, one scalar byte array) through every hot-path operation they are values for, against the oracle (which
+    tests/test_oracle.py pins on the same inputs against the big-integer model): decompress -> compress, each point x each
+    scalar (Encoding and Element forms), GENERATOR x each scalar, the pair's sum, encode_to_curve / hash_to_curve and
+    sqrt_ratio_zeta of the field elements, and the 16 products as one multiscalar sum."""
+    from _kat_inputs import groth16_regression_inputs
+    g = groth16_regression_inputs(kats)
+    pts, ks, fq = g["points"], g["scalars"], g["fq"]
+    out, st = ctx.roundtrip(pts)
+    assert not st.any() and (out == pts).all()
+    xyzt, st = ctx.decompress(pts)
+    assert not st.any() and (xyzt == oracle.decompress(pts)[0]).all()
+    assert (ctx.compress(xyzt) == pts).all()
+    P_ = np.repeat(pts, 4, axis=0)
+    K_ = np.tile(ks, (4, 1))
+    o_out, o_st = oracle.scalar_mul_var(P_, K_)
+    out, st = ctx.scalar_mul_var(P_, K_)
+    assert (st == o_st).all() and (out == o_out).all()
+    X_ = np.repeat(xyzt, 4, axis=0)
+    assert (ctx.compress(ctx.scalar_mul_var_element(X_, K_)) == o_out).all()
+    assert (ctx.scalar_mul_base(ks) == oracle.scalar_mul_base(ks)).all()
+    assert (ctx.compress(ctx.add(xyzt[2:3], xyzt[3:4])) == oracle.compress(oracle.add_xyzt(xyzt[2:3], xyzt[3:4]))).all()
+    assert (ctx.encode_to_curve(fq) == oracle.encode_to_curve(fq)).all()
+    assert (ctx.hash_to_curve(fq[0:1], fq[1:2]) == oracle.hash_to_curve(fq[0:1], fq[1:2])).all()
+    one = ibytes(1)
+    num = np.stack([fq[0], fq[1], fq[0], fq[1], one, one])
+    den = np.stack([fq[1], fq[0], one, one, fq[0], fq[1]])
+    for conv, orc_fn in (("ark", oracle.sqrt_ratio_zeta), ("min_curve", oracle.sqrt_ratio_zeta_min_curve)):
+        root, ws = ctx.sqrt_ratio_zeta(num, den, root=conv)
+        o_root, o_ws = orc_fn(num, den)
+        assert (ws == o_ws).all() and (root == o_root).all(), conv
+    # sum_i k_i P_i over the 16 pairs, both input forms, against the oracle's fold of its own products
+    acc = oracle.decompress(o_out[0:1])[0]
+    for i in range(1, 16):
+        acc = oracle.add_xyzt(acc, oracle.decompress(o_out[i:i + 1])[0])
+    want = oracle.compress(acc)[0]
+    assert (np.asarray(ctx.msm(P_, K_)[0]).reshape(32) == want).all()
+    assert (np.asarray(ctx.msm(X_, K_)[0]).reshape(32) == want).all()
+
+
 # --- committed model vectors -------------------------------------------------------------------
 def test_vectors(ctx, vectors):
     v = vectors["sqrt_ratio_zeta"]

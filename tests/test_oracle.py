@@ -188,6 +188,55 @@ def test_regression_seeds(oracle, kats):
     assert list(st) == [0, 0, 1]
 
 
+def test_groth16_gadget_regression_inputs(oracle, kats):
+    """tests/groth16_gadgets.proptest-regressions:7-15: the shrunk inputs of the circuit-vs-native properties are values of
+    hot-path types (4 Element encodings, 3 Fr, 2 Fq, one 32-byte scalar array).  They pin no outputs -- the properties
+    compare a gadget with the native operation -- so the two independent statements of the reference's algorithms, the C
+    oracle and the big-integer model, are run on them against each other: decompress -> compress, every point x every
+    scalar, GENERATOR x every scalar, encode_to_curve and sqrt_ratio_zeta of the field elements."""
+    from _kat_inputs import groth16_regression_inputs
+    g = groth16_regression_inputs(kats)
+    pts, ks, fq = g["points"], g["scalars"], g["fq"]
+    assert pts.shape == (4, 32) and ks.shape == (4, 32) and fq.shape == (2, 32)
+    # the Elements are the reference's own encodings of points it generated: valid and canonical
+    out, st = oracle.roundtrip(pts)
+    assert not st.any() and (out == pts).all()
+    model_pts = [m.decompress(bytes(p)) for p in pts]
+    assert all(p is not None for p in model_pts)
+    assert [m.compress(p).hex() for p in model_pts] == hx(pts)
+    # the three Fr are canonical (Debug prints the reduced value); the byte array is not (>= r): mod-order reduction applies
+    kv = [int.from_bytes(bytes(k), "little") for k in ks]
+    assert [v < m.R_ORDER for v in kv] == [True, True, True, False]
+    assert list(oracle.fr_from_bytes_checked(ks)) == [0, 0, 0, 1]
+    P_ = np.repeat(pts, 4, axis=0)
+    K_ = np.tile(ks, (4, 1))
+    out, st = oracle.scalar_mul_var(P_, K_)
+    assert not st.any()
+    for i in range(16):
+        assert bytes(out[i]) == m.compress(m.scalar_mul(model_pts[i // 4], kv[i % 4] % m.R_ORDER)), i
+    # line 15's pair is the input of an addition property: a + b through both statements
+    a, _ = oracle.decompress(pts[2:3])
+    b, _ = oracle.decompress(pts[3:4])
+    assert bytes(oracle.compress(oracle.add_xyzt(a, b))[0]) == m.compress(m.pt_add(model_pts[2], model_pts[3]))
+    outb = oracle.scalar_mul_base(ks)
+    for i in range(4):
+        assert bytes(outb[i]) == m.compress(m.scalar_mul(m.GENERATOR, kv[i] % m.R_ORDER)), i
+    fv = [int.from_bytes(bytes(f), "little") for f in fq]
+    assert all(v < m.Q for v in fv)
+    enc = oracle.encode_to_curve(fq)
+    for i in range(2):
+        assert bytes(enc[i]) == m.compress(m.encode_to_curve(fv[i])), i
+    h = oracle.hash_to_curve(fq[0:1], fq[1:2])
+    assert bytes(h[0]) == m.compress(m.hash_to_curve(fv[0], fv[1]))
+    one = np.frombuffer((1).to_bytes(32, "little"), np.uint8)
+    num = np.stack([fq[0], fq[1], fq[0], fq[1], one, one])
+    den = np.stack([fq[1], fq[0], one, one, fq[0], fq[1]])
+    root, ws = oracle.sqrt_ratio_zeta(num, den)
+    for i in range(6):
+        mw, mr = m.sqrt_ratio_zeta(int.from_bytes(bytes(num[i]), "little"), int.from_bytes(bytes(den[i]), "little"))
+        assert int(ws[i]) == int(mw) and int.from_bytes(bytes(root[i]), "little") == mr, i
+
+
 # --- committed model vectors ----------------------------------------------
 def test_vectors_sqrt(oracle, vectors):
     v = vectors["sqrt_ratio_zeta"]

@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 import decaf377_amd as d  # noqa: E402
 from _oracle import Oracle  # noqa: E402
+from _kat_inputs import groth16_regression_inputs  # noqa: E402
 
 R_ORDER = 2111115437357092606062206234695386632838870926408408195193685246394721360383
 
@@ -45,11 +46,14 @@ def main():
         bad += 0 if ok else 1
 
     n = 1 << lg
+    # the reference's shrunk gadget inputs (tests/groth16_gadgets.proptest-regressions:7-15) ride along in every batch
+    kat = {k_: torch.from_numpy(v.copy()).to(dev) for k_, v in groth16_regression_inputs().items()}
     # Elligator on random field elements and on small ones
     r0 = rnd(2 * n)
     r0[:4096] = 0
     r0[:4096, 0] = torch.arange(4096, device=dev).to(torch.uint8)
     r0[:4096, 1] = (torch.arange(4096, device=dev) >> 8).to(torch.uint8)
+    r0[4096:4098] = kat["fq"]
     enc = ctx.encode_to_curve(r0)
     check("encode_to_curve", (enc,), "encode_to_curve", r0, None)
     # variable base: valid points, with invalid encodings and special scalars sprinkled in
@@ -60,6 +64,8 @@ def main():
     specials = [0, 1, 2, 3, R_ORDER - 1, R_ORDER, R_ORDER + 1, (R_ORDER - 1) // 2, (R_ORDER + 1) // 2, 2**251 - 1, 2**256 - 1]
     for j, v in enumerate(specials):
         k[11 + j::8191] = torch.from_numpy(le(v % 2**256).copy()).to(dev)
+    pts[6000:6016] = kat["points"].repeat_interleave(4, dim=0)     # each reference point x each reference scalar
+    k[6000:6016] = kat["scalars"].repeat(4, 1)
     out, st = ctx.scalar_mul_var(pts, k)
     check("scalar_mul_var", (out, st), "scalar_mul_var", pts, k)
     kb = k[: n // 2]
@@ -70,6 +76,8 @@ def main():
     num, den = rnd(n), rnd(n)
     den[3::997] = 0
     num[4::997] = 0
+    num[5:7] = kat["fq"]
+    den[5:7] = kat["fq"].flip(0)
     root, ws = ctx.sqrt_ratio_zeta(num, den)
     check("sqrt_ratio_zeta", (root, ws), "sqrt_ratio_zeta", num, den)
     # small batches take other kernels (one element per quad of lanes up to 16 384 elements; inversion-free roots below 3
