@@ -38,7 +38,14 @@ EXPORTS = [
     "d377_batch_fr_op", "d377_batch_fr_op_dev", "d377_batch_fr_from_wide_bytes", "d377_batch_fr_from_wide_bytes_dev",
     "d377_batch_fq_from_bytes_checked_dev", "d377_batch_fq_to_bytes_dev", "d377_batch_fr_from_le_bytes_mod_order_dev",
     "d377_batch_fr_from_bytes_checked_dev", "d377_ctx_starved_counter_dev",
+    "d377_ctx_create_ex", "d377_ctx_comb_info",
 ]
+
+
+class CtxOpts(ctypes.Structure):
+    """d377_ctx_opts (include/decaf377_amd.h)."""
+    _fields_ = [("size", ctypes.c_size_t), ("comb_bits", ctypes.c_int), ("comb_lazy", ctypes.c_int)]
+
 
 _lib = None
 
@@ -78,6 +85,10 @@ def load():
     lib.d377_last_error.restype = ctypes.c_char_p
     lib.d377_device_count.restype = i32
     lib.d377_ctx_create.argtypes = [ctypes.POINTER(i32), i32, ctypes.POINTER(vp)]
+    lib.d377_ctx_create_ex.argtypes = [ctypes.POINTER(i32), i32, ctypes.POINTER(CtxOpts), ctypes.POINTER(vp)]
+    lib.d377_ctx_create_ex.restype = i32
+    lib.d377_ctx_comb_info.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_uint64)]
+    lib.d377_ctx_comb_info.restype = i32
     lib.d377_ctx_destroy.argtypes = [vp]
     lib.d377_ctx_destroy.restype = None
     lib.d377_ctx_num_devices.argtypes = [vp]

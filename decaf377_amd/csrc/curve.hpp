@@ -1059,32 +1059,44 @@ D377_HD void fr_recode_signed256(const uint32_t k[8], int digits[32]) {
 #ifndef D377_FB_BITS
 #define D377_FB_BITS 23
 #endif
-constexpr int FB_BITS = D377_FB_BITS;
-constexpr int FB_WINDOWS = (252 + FB_BITS - 1) / FB_BITS;
-constexpr int FB_ENTRIES = (1 << (FB_BITS - 1)) + 1;
+// The comb's shape for a width of BITS.  The library instantiates its fixed-base kernels for FB_BITS (the build's default,
+// what d377_ctx_create takes) and for 18 / 21 / 23, and a context picks one of them at run time (d377_ctx_create_ex:
+// include/decaf377_amd.h); the host simulation builds its tables with 12 or 8.
 // The top digit must take the recoding's carry without one of its own.  Scalars are < r and r >> 228 = 0x4aad95, so the
-// top window's value is at most R_TOP >> (its first bit - 228); that + 1 has to stay below 2^(FB_BITS - 1).  True for
+// top window's value is at most R_TOP >> (its first bit - 228); that + 1 has to stay below 2^(BITS - 1).  True for
 // the widths that tile the 252 bits (18, 14, 12) and for ragged tops (8: 32 windows; 16: 16 windows, 11 bits in the last).
 constexpr unsigned long long FB_R_TOP = 0x4aad95ull;                        // r >> 228
-constexpr int FB_TOP_BIT = FB_BITS * (FB_WINDOWS - 1);
-static_assert(FB_BITS >= 4 && FB_BITS <= 23 && FB_TOP_BIT >= 228 && FB_BITS * FB_WINDOWS >= 252, "comb width");
-static_assert((FB_R_TOP >> (FB_TOP_BIT - 228)) + 1 < (1ull << (FB_BITS - 1)), "the top digit of a scalar below r must not carry out");
-// signed digit i of k (FB_BITS wide), with the running carry of the recoding
+template <int BITS>
+struct FbShape {
+  static constexpr int bits = BITS;
+  static constexpr int windows = (252 + BITS - 1) / BITS;
+  static constexpr int entries = (1 << (BITS - 1)) + 1;
+  static constexpr int top_bit = BITS * (windows - 1);
+  static_assert(BITS >= 4 && BITS <= 23 && top_bit >= 228 && BITS * windows >= 252, "comb width");
+  static_assert((FB_R_TOP >> (top_bit - 228)) + 1 < (1ull << (BITS - 1)), "the top digit of a scalar below r must not carry out");
+  static_assert(windows >= 2, "the first window is peeled off the loop");
+};
+constexpr int FB_BITS = D377_FB_BITS;
+constexpr int FB_WINDOWS = FbShape<FB_BITS>::windows;
+constexpr int FB_ENTRIES = FbShape<FB_BITS>::entries;
+// signed digit i of k (BITS wide), with the running carry of the recoding
+template <int BITS = FB_BITS>
 D377_HD int fb_digit(const uint32_t k[8], int i, uint32_t& carry) {
-  const int bit = FB_BITS * i, wi = bit >> 5, sh = bit & 31;
+  const int bit = BITS * i, wi = bit >> 5, sh = bit & 31;
   uint32_t v = k[wi] >> sh;
-  if (sh + FB_BITS > 32 && wi + 1 < 8) v |= k[wi + 1] << (32 - sh);
-  const uint32_t dd = (v & ((1u << FB_BITS) - 1u)) + carry;
-  carry = (dd >= (1u << (FB_BITS - 1))) ? 1u : 0u;        // k < r < 2^251: the top digit never carries out
-  return (int)dd - (int)(carry << FB_BITS);
+  if (sh + BITS > 32 && wi + 1 < 8) v |= k[wi + 1] << (32 - sh);
+  const uint32_t dd = (v & ((1u << BITS) - 1u)) + carry;
+  carry = (dd >= (1u << (BITS - 1))) ? 1u : 0u;        // k < r < 2^251: the top digit never carries out
+  return (int)dd - (int)(carry << BITS);
 }
 // want_t: whether the caller reads T of the result.  The entry of window i + 1 is fetched before the addition of
 // window i: the table lives in L2 / Infinity Cache, and one mixed addition is only ~1 500 instructions.  (Two entries
 // in flight instead of one: 1.07-1.11e9/s against 1.09-1.12e9/s at 2^20 and 2^22, same box -- the gathers are covered.)
-template <class FTab>
+template <int BITS = FB_BITS, class FTab>
 D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab, bool want_t = true) {
+  constexpr int W = FbShape<BITS>::windows;
   uint32_t carry = 0;
-  int d = fb_digit(k, 0, carry);
+  int d = fb_digit<BITS>(k, 0, carry);
   bool neg = d < 0;
   gea e = ftab.load(0, neg ? -d : d, neg);
   // window 0: the sum starts from the record itself (ge_from_cached_affine: 4 products) instead of a 7-product addition to
@@ -1093,22 +1105,21 @@ D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab, bool wan
   {
     const gea cur = e;
     const bool neg_cur = neg;
-    d = fb_digit(k, 1, carry);
+    d = fb_digit<BITS>(k, 1, carry);
     neg = d < 0;
     e = ftab.load(1, neg ? -d : d, neg);
     r = ge_from_cached_affine(cur, neg_cur);
   }
-  static_assert(FB_WINDOWS >= 2, "the first window is peeled off the loop");
 #pragma unroll 1
-  for (int i = 1; i < FB_WINDOWS; ++i) {
+  for (int i = 1; i < W; ++i) {
     const gea cur = e;
     const bool neg_cur = neg;
-    if (i + 1 < FB_WINDOWS) {
-      d = fb_digit(k, i + 1, carry);
+    if (i + 1 < W) {
+      d = fb_digit<BITS>(k, i + 1, carry);
       neg = d < 0;
       e = ftab.load(i + 1, neg ? -d : d, neg);
     }
-    r = ge_add_affine(r, cur, neg_cur, want_t || i + 1 < FB_WINDOWS);
+    r = ge_add_affine(r, cur, neg_cur, want_t || i + 1 < W);
   }
   return r;
 }

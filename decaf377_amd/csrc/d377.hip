@@ -15,6 +15,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/decaf377_amd.h"
@@ -55,10 +56,11 @@ struct GlobalTab {
 };
 // shared fixed-base comb FB[i][j] = affine cached j * 2^(FB_BITS i) * B, [FB_WINDOWS][FB_ENTRIES] 128-byte records
 // (device_util.hpp: pt_load_affine -- two sectors per gather; round 2's three 48-byte slots cost 3.25)
+template <int BITS>
 struct FixedTab {
   const uint32_t* base;
   __device__ __forceinline__ gea load(int i, int j, bool swap) const {
-    return pt_load_affine(base + ((size_t)i * FB_ENTRIES + j) * FBW_ENTRY_WORDS, swap);
+    return pt_load_affine(base + ((size_t)i * FbShape<BITS>::entries + j) * FBW_ENTRY_WORDS, swap);
   }
 };
 
@@ -134,7 +136,9 @@ __global__ void __launch_bounds__(BLOCK) k_init_slookup(uint8_t* s_lookup, uint3
 // inverted together (Montgomery's trick: one divsteps inversion per FB_RUN entries).  ~9 000 instructions per entry;
 // one thread per entry with its own ladder from B and its own inversion was ~420 000 at 21-bit windows (12.6 M entries).
 constexpr int FB_RUN = 16;
+template <int FB_BITS>
 __global__ void k_init_fbase_bases(uint32_t* bases) {          // bases[i] = 2^(FB_BITS i) * B as X, Y, Z, T: one thread
+  constexpr int FB_WINDOWS = FbShape<FB_BITS>::windows;
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   ge p = ge_generator();
 #pragma unroll 1
@@ -145,7 +149,9 @@ __global__ void k_init_fbase_bases(uint32_t* bases) {          // bases[i] = 2^(
     for (int k = 0; k < FB_BITS; ++k) p = ge_double(p);
   }
 }
+template <int FB_BITS>
 __global__ void __launch_bounds__(BLOCK) k_init_fbase(const uint32_t* bases, uint32_t* fb) {
+  constexpr int FB_WINDOWS = FbShape<FB_BITS>::windows, FB_ENTRIES = FbShape<FB_BITS>::entries;
   constexpr int RUNS = (FB_ENTRIES + FB_RUN - 1) / FB_RUN;
   const size_t idx = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (idx >= (size_t)FB_WINDOWS * RUNS) return;
@@ -458,11 +464,12 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var(SqrtTa
 // Up to three workgroups per CU (168 VGPRs): this kernel's additions wait on table gathers from HBM (11 random 128-byte
 // records per element of the 23-bit comb, L2 hit rate 0.25), which a third wave per SIMD hides a little better, and large batches share one
 // inversion among FB_K = 16 elements per lane instead of 8 (launch(): OP_MUL_BASE chooses per call).
+template <int BITS>
 __global__ void __launch_bounds__(BLOCK, FB_SETS) k_scalar_mul_base(SqrtTables T, const uint32_t* fbase,
                                                            const uint8_t* scalar32, size_t n, uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();                        // unused here (no square root): residency is capped by the launch's LDS padding
   D377_DCB_BEGIN(out32);
-  FixedTab ft{fbase};
+  FixedTab<BITS> ft{fbase};
   dcb_rounds<0, true>(n, io, pt,
     [&](size_t, int) {},
     [&](size_t i, int j, const uint32_t (*)[8], bool) {
@@ -470,7 +477,7 @@ __global__ void __launch_bounds__(BLOCK, FB_SETS) k_scalar_mul_base(SqrtTables T
       load32(scalar32, i, k);
       fr_reduce_words(k);
       fr_half_words(k);
-      const ge r = ge_scalar_mul_base_w8(k, ft, DCB_WANT_T);
+      const ge r = ge_scalar_mul_base_w8<BITS>(k, ft, DCB_WANT_T);
       D377_INVARIANT(T, r, true);
       dcb_put(io, j, ge_dcb_from_half(r, false));
     });
@@ -572,9 +579,10 @@ k_scalar_mul_var_small(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar
 // lane `role`'s slot of window i's comb entry for the digit d (the records hold Y + X, Y - X, 2dXY; Z = 1).
 // (A free function, not a lambda inside the kernel: with the lambda hipcc compiled EVERY kernel of this file differently --
 // k_scalar_mul_var 249 VGPRs and 84 SGPR spills instead of 256 and 47 -- which tools/resource_usage.sh is there to catch.)
+template <int FB_BITS>
 __device__ __forceinline__ fe fb_fetch_slot(const uint32_t* fbase, int role, int i, int d) {
   const int slot = gq_add_slot(role, d < 0);
-  const uint32_t* src = fbase + ((size_t)i * FB_ENTRIES + (size_t)(d < 0 ? -d : d)) * FBW_ENTRY_WORDS + NL * (slot == 0 ? 1 : (slot == 1 ? 0 : 2));
+  const uint32_t* src = fbase + ((size_t)i * FbShape<FB_BITS>::entries + (size_t)(d < 0 ? -d : d)) * FBW_ENTRY_WORDS + NL * (slot == 0 ? 1 : (slot == 1 ? 0 : 2));
   fe x = fe_const(FE_ONE);
   if (slot < 3) {
 #pragma unroll
@@ -582,9 +590,10 @@ __device__ __forceinline__ fe fb_fetch_slot(const uint32_t* fbase, int role, int
   }
   return x;
 }
-template <bool ELEMENT>
+template <bool ELEMENT, int FB_BITS>
 __global__ void __launch_bounds__(SMALL_THREADS)
 k_scalar_mul_base_small(const uint32_t* fbase, const uint8_t* scalar32, size_t n, uint8_t* out) {
+  constexpr int FB_WINDOWS = FbShape<FB_BITS>::windows;
   const int role = threadIdx.x & 3, quad = threadIdx.x >> 2;
   const size_t e_raw = (size_t)blockIdx.x * SMALL_QUADS + quad;   // grid = ceil(n / 16)
   const bool active = e_raw < n;
@@ -594,16 +603,16 @@ k_scalar_mul_base_small(const uint32_t* fbase, const uint8_t* scalar32, size_t n
   fr_reduce_words(k);
   if (!ELEMENT) fr_half_words(k);                                // [k]B = [2]([k/2 mod r]B): the encoding of a double needs no square root
   uint32_t carry = 0;
-  int d = fb_digit(k, 0, carry);
-  fe nxt = fb_fetch_slot(fbase, role, 0, d);
+  int d = fb_digit<FB_BITS>(k, 0, carry);
+  fe nxt = fb_fetch_slot<FB_BITS>(fbase, role, 0, d);
   fe v = gq_from_ge(ge_identity(), role);
 #pragma unroll 1
   for (int i = 0; i < FB_WINDOWS; ++i) {
     const fe cur = nxt;
     const bool neg = d < 0;
     if (i + 1 < FB_WINDOWS) {                                    // the next entry is in flight during this addition
-      d = fb_digit(k, i + 1, carry);
-      nxt = fb_fetch_slot(fbase, role, i + 1, d);
+      d = fb_digit<FB_BITS>(k, i + 1, carry);
+      nxt = fb_fetch_slot<FB_BITS>(fbase, role, i + 1, d);
     }
     v = gq_add_with(v, cur, role, neg);
   }
@@ -679,9 +688,10 @@ k_scalar_mul_var_tiny(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar3
 // lane-per-element wave does alone (~2.7 us each, then a 31 us inversion: 91 us per call whatever the batch).  One wave per
 // scalar instead: the comb entries of its digits, fetched and turned into row records by 3 x FB_WINDOWS lanes side by side,
 // then the additions in the lane-spread form (0.55 us each) and the wave's inversion (18 us).
-template <bool ELEMENT>
+template <bool ELEMENT, int FB_BITS>
 __global__ void __launch_bounds__(64)
 k_scalar_mul_base_tiny(const uint32_t* fbase, const uint8_t* scalar32, size_t n, uint8_t* out) {
+  constexpr int FB_WINDOWS = FbShape<FB_BITS>::windows, FB_ENTRIES = FbShape<FB_BITS>::entries;
   __shared__ uint32_t crec[FB_WINDOWS * row::RQ_WORDS];
   __shared__ uint32_t xrec[row::RQ_WORDS];
   __shared__ int sdig[FB_WINDOWS];
@@ -696,7 +706,7 @@ k_scalar_mul_base_tiny(const uint32_t* fbase, const uint8_t* scalar32, size_t n,
   if (t == 0) {
     uint32_t carry = 0;
 #pragma unroll 1
-    for (int i = 0; i < FB_WINDOWS; ++i) sdig[i] = fb_digit(k, i, carry);
+    for (int i = 0; i < FB_WINDOWS; ++i) sdig[i] = fb_digit<FB_BITS>(k, i, carry);
   }
   __syncthreads();
   // lane l: coordinate l % 4 of window l / 4's entry (Y + X, Y - X, 2dXY as stored; the fourth is Z = 1) -> the slot a row
@@ -954,14 +964,15 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var_el(con
   }
   dcb_release(dcb, slot);
 }
+template <int BITS>
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base_el(const uint32_t* fbase, const uint8_t* scalar32, size_t n,
                                                                               uint64_t* out) {
-  FixedTab ft{fbase};
+  FixedTab<BITS> ft{fbase};
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t k[8];
     load32(scalar32, i, k);
     fr_reduce_words(k);
-    store_ge_mont256(out, i, ge_scalar_mul_base_w8(k, ft));
+    store_ge_mont256(out, i, ge_scalar_mul_base_w8<BITS>(k, ft));
   }
 }
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_compress_to_field(SqrtTables T, const uint64_t* xyzt, size_t n, uint64_t* out) {
@@ -1338,13 +1349,6 @@ int grid_for(const DeviceState& d, size_t n) {
 int init_tables(DeviceState& d, uint32_t* keys, int* coll) {
   hipLaunchKernelGGL(k_init_gtab, dim3(6), dim3(BLOCK), 0, d.stream, d.gtab);
   hipLaunchKernelGGL(k_init_slookup, dim3(1), dim3(BLOCK), 0, d.stream, d.s_lookup, keys, coll);
-  {
-    // the window bases go through the first words of the lane-set scratch (free until the first batch call)
-    uint32_t* bases = reinterpret_cast<uint32_t*>(d.dcb_scratch);
-    hipLaunchKernelGGL(k_init_fbase_bases, dim3(1), dim3(64), 0, d.stream, bases);
-    const size_t runs = (size_t)FB_WINDOWS * ((FB_ENTRIES + FB_RUN - 1) / FB_RUN);
-    hipLaunchKernelGGL(k_init_fbase, dim3((unsigned)((runs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, bases, d.fbase);
-  }
   HIP_TRY(hipGetLastError());
   int h_coll = -1;
   HIP_TRY(hipMemcpyAsync(&h_coll, coll, sizeof(int), hipMemcpyDeviceToHost, d.stream));
@@ -1357,13 +1361,98 @@ int init_tables(DeviceState& d, uint32_t* keys, int* coll) {
 // on a CU (registers, the kernel's own LDS); where that is more than the sets, pad the launch with dynamic LDS until it
 // is not (160 KiB per CU: a pad of a little over 160 / (sets + 1) KiB admits `sets` workgroups and no more).  A kernel
 // that still exceeds the sets would only spin for a free set (dcb_claim), silently slower: refuse to start instead.
+// The comb widths a context can ask for at run time (d377_ctx_create_ex), plus whatever width the library was built with:
+// f(std::integral_constant<int, BITS>) runs with the kernels of that width.
+template <class F>
+int with_fb_bits(int bits, F&& f) {
+  switch (bits) {
+    case 18: return f(std::integral_constant<int, 18>{});
+    case 21: return f(std::integral_constant<int, 21>{});
+    case 23: return f(std::integral_constant<int, 23>{});
+  }
+  if (bits == FB_BITS) return f(std::integral_constant<int, FB_BITS>{});
+  return fail(D377_ERR_ARG, "%s", "comb width: 18, 21 or 23 bits (or 0 for the library's default)");
+}
+
+// residency of the fixed-base kernel of the context's comb width: its wide launch (FB_SETS lane sets per CU) and its narrow one
+int check_residency_fb(DeviceState& d, const void* fn) {
+  const bool verbose = getenv("D377_DEBUG_RESIDENCY") != nullptr;
+  {
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, 0));
+    d.chunk_lds[CK_MUL_BASE] = 0;
+    const int sets = d.chunk_sets[CK_MUL_BASE];
+    const int pad = (160 * 1024) / (sets + 1) + 1024;
+    if (nb > sets) {
+      if (pad > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+      d.chunk_lds[CK_MUL_BASE] = pad;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, (size_t)pad));
+    }
+    if (verbose) fprintf(stderr, "d377: k_scalar_mul_base<%d>: %d workgroups per CU with %d bytes of LDS padding\n", d.fb_bits, nb, d.chunk_lds[CK_MUL_BASE]);
+    d.chunk_blocks[CK_MUL_BASE] = nb;
+    if (nb < 1 || nb > sets)
+      return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", "k_scalar_mul_base");
+  }
+  // the narrow launch (WAVES_PER_SIMD workgroups per CU, up to FB_WIDE_GENERATIONS generation of full chunks): its own padding
+  {
+    const int pad = (160 * 1024) / (WAVES_PER_SIMD + 1) + 1024;
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, (size_t)pad));
+    if (verbose) fprintf(stderr, "d377: k_scalar_mul_base<%d>, narrow launch: %d workgroups per CU with %d bytes of LDS padding\n", d.fb_bits, nb, pad);
+    if (nb < 1 || nb > WAVES_PER_SIMD)
+      return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", "k_scalar_mul_base (narrow launch)");
+    d.fb_narrow_lds = pad;
+    if (pad > d.chunk_lds[CK_MUL_BASE] && pad > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+  }
+  return D377_OK;
+}
+
+// The fixed-base comb of the context's width: allocated and built on the context's stream the first time it is asked for --
+// by d377_ctx_create[_ex] for an eager context, by the first fixed-base call of a lazy one (d377_ctx_opts::comb_lazy: a
+// caller that never multiplies by the generator never pays the table, 5.9 GB at 23 bits) -- and complete when this returns.
+// `s`: the stream of the call that needs it; a capturing stream cannot allocate or synchronise, so a lazy context's FIRST
+// fixed-base call must not be inside a capture (as for an MSM that would have to grow its workspace).  Caller holds ctx->mu.
+int ensure_comb(DeviceState& d, hipStream_t s) {
+  if (d.fbase) return D377_OK;
+  if (s && ScratchGuard::capturing(s))
+    return fail(D377_ERR_ARG, "%s", "the fixed-base comb of a lazy context is built by its first fixed-base call, which cannot be captured into a graph: make one eager call first");
+  return with_fb_bits(d.fb_bits, [&](auto bits_c) -> int {
+    constexpr int BITS = decltype(bits_c)::value;
+    using Sh = FbShape<BITS>;
+    int rc = check_residency_fb(d, reinterpret_cast<const void*>(k_scalar_mul_base<BITS>));
+    if (rc) return rc;
+    const size_t bytes = (size_t)Sh::windows * Sh::entries * FBW_ENTRY_WORDS * sizeof(uint32_t);
+    uint32_t* fb = nullptr;
+    if (hipMalloc(&fb, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(d377_g_err, sizeof d377_g_err,
+               "the %d-bit fixed-base comb needs %.2f GB of device memory and the allocation failed (device %d): "
+               "d377_ctx_create_ex with comb_bits = 18 (0.24 GB) or 21 (1.6 GB), or free memory", BITS, (double)bytes / 1e9, d.id);
+      return D377_ERR_HIP;
+    }
+    if (!d.fb_bases && hipMalloc(&d.fb_bases, (size_t)FbShape<8>::windows * 4 * SLOT * sizeof(uint32_t)) != hipSuccess) {
+      (void)hipFree(fb);
+      return fail(D377_ERR_HIP, "%s", "hipMalloc failed (comb window bases)");
+    }
+    hipLaunchKernelGGL(k_init_fbase_bases<BITS>, dim3(1), dim3(64), 0, d.stream, d.fb_bases);
+    const size_t runs = (size_t)Sh::windows * ((Sh::entries + FB_RUN - 1) / FB_RUN);
+    hipLaunchKernelGGL(k_init_fbase<BITS>, dim3((unsigned)((runs + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, d.fb_bases, fb);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+    if (e != hipSuccess) { (void)hipFree(fb); return fail(D377_ERR_HIP, "building the fixed-base comb: %s", hipGetErrorString(e)); }
+    d.fbase = fb;
+    return D377_OK;
+  });
+}
+
 int check_residency(DeviceState& d) {
   const void* fns[CK_COUNT];
   fns[CK_SQRT] = reinterpret_cast<const void*>(k_sqrt_ratio_zeta);
   fns[CK_ENCODE] = reinterpret_cast<const void*>(k_encode_to_curve);
   fns[CK_HASH] = reinterpret_cast<const void*>(k_hash_to_curve);
   fns[CK_MUL_VAR] = reinterpret_cast<const void*>(k_scalar_mul_var);
-  fns[CK_MUL_BASE] = reinterpret_cast<const void*>(k_scalar_mul_base);
+  fns[CK_MUL_BASE] = nullptr;                                  // per comb width: check_residency_fb, when the comb is built
   fns[CK_MUL_VAR_EL] = reinterpret_cast<const void*>(k_scalar_mul_var_el);
   fns[CK_MAP_EL] = reinterpret_cast<const void*>(k_map_to_element);
   fns[CK_ENCODE_WIDE] = reinterpret_cast<const void*>(k_encode_to_curve_wide);
@@ -1373,6 +1462,7 @@ int check_residency(DeviceState& d) {
                                         "k_decompress_chunked"};
   const bool verbose = getenv("D377_DEBUG_RESIDENCY") != nullptr;
   for (int k = 0; k < CK_COUNT; ++k) {
+    if (!fns[k]) continue;
     int nb = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[k], BLOCK, 0));
     d.chunk_lds[k] = 0;
@@ -1390,18 +1480,6 @@ int check_residency(DeviceState& d) {
     d.chunk_blocks[k] = nb;
     if (nb < 1 || nb > sets)
       return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", names[k]);
-  }
-  // the fixed-base kernel's narrow launch (WAVES_PER_SIMD workgroups per CU, up to FB_WIDE_GENERATIONS generation of full chunks): its own padding
-  {
-    const int pad = (160 * 1024) / (WAVES_PER_SIMD + 1) + 1024;
-    int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[CK_MUL_BASE], BLOCK, (size_t)pad));
-    if (verbose) fprintf(stderr, "d377: k_scalar_mul_base, narrow launch: %d workgroups per CU with %d bytes of LDS padding\n", nb, pad);
-    if (nb < 1 || nb > WAVES_PER_SIMD)
-      return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", "k_scalar_mul_base (narrow launch)");
-    d.fb_narrow_lds = pad;
-    if (pad > d.chunk_lds[CK_MUL_BASE] && pad > 64 * 1024)
-      HIP_TRY(hipFuncSetAttribute(fns[CK_MUL_BASE], hipFuncAttributeMaxDynamicSharedMemorySize, pad));
   }
   return D377_OK;
 }
@@ -1434,7 +1512,6 @@ int init_device(DeviceState& d) {
   if ((rc = d.vb_guard.init()) || (rc = d.msm.guard.init())) return rc;
   HIP_TRY(hipMalloc(&d.gtab, (size_t)6 * 256 * GT_STRIDE * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&d.s_lookup, (size_t)1 << S_HASH_BITS));
-  HIP_TRY(hipMalloc(&d.fbase, (size_t)FB_WINDOWS * FB_ENTRIES * FBW_ENTRY_WORDS * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&d.inv_fail, sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(d.inv_fail, 0, sizeof(uint32_t), d.stream));
   // variable-base window tables: one per resident lane, fixed grid, grid-stride over the batch
@@ -1465,6 +1542,7 @@ int init_device(DeviceState& d) {
   rc = init_tables(d, keys, coll);
   (void)hipFree(keys);
   (void)hipFree(coll);
+  if (rc == D377_OK && !d.fb_lazy) rc = ensure_comb(d, nullptr);
   return rc;
 }
 
@@ -1475,7 +1553,7 @@ void free_device(DeviceState& d) {
   if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
   (void)d.vb_guard.drain();
   (void)d.msm.guard.drain();
-  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.pool_health); (void)hipFree(d.inv_fail);
+  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.fb_bases); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.pool_health); (void)hipFree(d.inv_fail);
   if (d.starve_host) (void)hipHostFree(d.starve_host);
   d.starve_host = nullptr;
   if (d.pool_host) (void)hipHostFree(d.pool_host);
@@ -1604,13 +1682,18 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       // generation of workgroups and the wide one does not: wide / narrow 0.88 at 1.25 x 2^20, 0.95 at 1.5 x, 0.88 at
       // 1.75 x, 0.96 at 2^21, 0.94-0.95 at 3 x 2^20 and 2^22, warm clocks, alternating (profiles/r05_fb_wide_sweep.txt; the
       // threshold of rounds 3-4, two generations, was measured on the 18-bit comb before the rounds were dealt out evenly).
+      if ((rc = ensure_comb(d, s))) return rc;                 // (a lazy context's first fixed-base call builds the table)
       if (n <= tiny_batch_max(d)) {                           // one scalar per wave, lane-spread arithmetic
-        hipLaunchKernelGGL(k_scalar_mul_base_tiny<false>, dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
+        if ((rc = with_fb_bits(d.fb_bits, [&](auto b) -> int {
+               hipLaunchKernelGGL((k_scalar_mul_base_tiny<false, decltype(b)::value>), dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
+               return D377_OK; }))) return rc;
         break;
       }
       if (n <= small_batch_max(d, false)) {                   // one scalar per quad of lanes
-        hipLaunchKernelGGL(k_scalar_mul_base_small<false>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, d.fbase,
-                           (const uint8_t*)in0, n, (uint8_t*)out0);
+        if ((rc = with_fb_bits(d.fb_bits, [&](auto b) -> int {
+               hipLaunchKernelGGL((k_scalar_mul_base_small<false, decltype(b)::value>), dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s,
+                                  d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
+               return D377_OK; }))) return rc;
         break;
       }
       bool wide = n > d.resident_lanes() * DCB_K * FB_WIDE_GENERATIONS;
@@ -1623,8 +1706,10 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       // of waves in step gather their table entries in bursts (+6 to +10 % at 2^22: profiles/r05_ab_progress_priority.txt)
       if (wide && gb > d.cus * FB_SETS) db.prio = 0;
       if ((rc = vb.acquire())) return rc;
-      hipLaunchKernelGGL(k_scalar_mul_base, dim3(gb), dim3(BLOCK), wide ? d.chunk_lds[CK_MUL_BASE] : d.fb_narrow_lds, s, T, d.fbase,
-                         (const uint8_t*)in0, n, (uint8_t*)out0, db);
+      if ((rc = with_fb_bits(d.fb_bits, [&](auto b) -> int {
+             hipLaunchKernelGGL((k_scalar_mul_base<decltype(b)::value>), dim3(gb), dim3(BLOCK), wide ? d.chunk_lds[CK_MUL_BASE] : d.fb_narrow_lds, s, T, d.fbase,
+                                (const uint8_t*)in0, n, (uint8_t*)out0, db);
+             return D377_OK; }))) return rc;
       break;
     }
     case OP_MUL_VAR:
@@ -1743,16 +1828,17 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       break;
     }
     case OP_MUL_BASE_EL:
-      if (n <= tiny_batch_max(d)) {
-        hipLaunchKernelGGL(k_scalar_mul_base_tiny<true>, dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
-        break;
-      }
-      if (n <= small_batch_max(d, true)) {
-        hipLaunchKernelGGL(k_scalar_mul_base_small<true>, dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, d.fbase,
-                           (const uint8_t*)in0, n, (uint8_t*)out0);
-        break;
-      }
-      hipLaunchKernelGGL(k_scalar_mul_base_el, dim3(g), dim3(BLOCK), 0, s, d.fbase, (const uint8_t*)in0, n, (uint64_t*)out0);
+      if ((rc = ensure_comb(d, s))) return rc;
+      if ((rc = with_fb_bits(d.fb_bits, [&](auto b) -> int {
+             constexpr int BITS = decltype(b)::value;
+             if (n <= tiny_batch_max(d))
+               hipLaunchKernelGGL((k_scalar_mul_base_tiny<true, BITS>), dim3((unsigned)n), dim3(64), 0, s, d.fbase, (const uint8_t*)in0, n, (uint8_t*)out0);
+             else if (n <= small_batch_max(d, true))
+               hipLaunchKernelGGL((k_scalar_mul_base_small<true, BITS>), dim3((unsigned)((n + SMALL_QUADS - 1) / SMALL_QUADS)), dim3(SMALL_THREADS), 0, s, d.fbase,
+                                  (const uint8_t*)in0, n, (uint8_t*)out0);
+             else
+               hipLaunchKernelGGL((k_scalar_mul_base_el<BITS>), dim3(g), dim3(BLOCK), 0, s, d.fbase, (const uint8_t*)in0, n, (uint64_t*)out0);
+             return D377_OK; }))) return rc;
       break;
     case OP_COMPRESS_FIELD:
       hipLaunchKernelGGL(k_compress_to_field, dim3(g), dim3(BLOCK), 0, s, T, (const uint64_t*)in0, n, (uint64_t*)out0);
@@ -2052,9 +2138,19 @@ int d377_device_count(void) {
   return n;
 }
 
-int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out) {
+int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out) { return d377_ctx_create_ex(device_ids, n_dev, nullptr, out); }
+int d377_ctx_create_ex(const int* device_ids, int n_dev, const d377_ctx_opts* opts, d377_ctx** out) {
   if (!out) return fail(D377_ERR_ARG, "%s", "null out pointer");
   *out = nullptr;
+  int comb_bits = FB_BITS, comb_lazy = 0;
+  if (opts) {
+    if (opts->size < sizeof(d377_ctx_opts)) return fail(D377_ERR_ARG, "%s", "d377_ctx_opts::size: set it to sizeof(d377_ctx_opts)");
+    if (opts->comb_bits != 0) comb_bits = opts->comb_bits;
+    comb_lazy = opts->comb_lazy;
+    if (comb_lazy != 0 && comb_lazy != 1) return fail(D377_ERR_ARG, "%s", "d377_ctx_opts::comb_lazy: 0 or 1");
+    int rcw = with_fb_bits(comb_bits, [](auto) -> int { return D377_OK; });
+    if (rcw) return rcw;
+  }
   int avail = d377_device_count();
   if (avail <= 0) return fail(D377_ERR_NO_DEVICE, "%s", "no HIP device visible");
   std::vector<int> ids;
@@ -2068,6 +2164,8 @@ int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out) {
   for (size_t k = 0; k < ids.size(); ++k) {
     ctx->devs[k].id = ids[k];
     ctx->devs[k].tune = &ctx->tune;
+    ctx->devs[k].fb_bits = comb_bits;
+    ctx->devs[k].fb_lazy = comb_lazy != 0;
     int rc = init_device(ctx->devs[k]);
     if (rc != D377_OK) {
       char saved[sizeof d377_g_err];
@@ -2101,6 +2199,19 @@ void d377_ctx_destroy(d377_ctx* ctx) {
   delete ctx;
 }
 int d377_ctx_num_devices(const d377_ctx* ctx) { return ctx ? (int)ctx->devs.size() : 0; }
+int d377_ctx_comb_info(d377_ctx* ctx, int dev, int* comb_bits, int* built, uint64_t* table_bytes) {
+  if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
+  if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const DeviceState& d = ctx->devs[(size_t)dev];
+  if (comb_bits) *comb_bits = d.fb_bits;
+  if (built) *built = d.fbase != nullptr;
+  if (table_bytes) {
+    const uint64_t windows = (uint64_t)((252 + d.fb_bits - 1) / d.fb_bits), entries = ((uint64_t)1 << (d.fb_bits - 1)) + 1;
+    *table_bytes = windows * entries * FBW_ENTRY_WORDS * sizeof(uint32_t);
+  }
+  return D377_OK;
+}
 int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count) {
   if (!ctx || !count) return fail(D377_ERR_ARG, "%s", "null argument");
   if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");

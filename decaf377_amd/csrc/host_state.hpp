@@ -107,7 +107,10 @@ struct DeviceState {
   int dcb_sets = 0;                      // lane sets of the round-record area and its pool (the largest chunk_sets x CUs)
   uint32_t* gtab = nullptr;
   uint8_t* s_lookup = nullptr;
-  uint32_t* fbase = nullptr;
+  uint32_t* fbase = nullptr;             // the fixed-base comb: null until built (d377.hip ensure_comb: at context creation, or by the first fixed-base call of a lazy context)
+  uint32_t* fb_bases = nullptr;          // 2^(fb_bits i) B, the comb builder's window bases
+  int fb_bits = FB_BITS;                 // the comb's width: the build's default, or d377_ctx_opts::comb_bits (18 / 21 / 23)
+  bool fb_lazy = false;                  // d377_ctx_opts::comb_lazy
   uint32_t* vb_scratch = nullptr;
   uint8_t* dcb_scratch = nullptr;        // round records of the batched inversions (curve.hpp: dcb_invert_slot, dcb_finish)
   int* slot_pool = nullptr;              // which of the lane sets of the scratch areas are claimed, and by which ticket (dcb.hpp, DcbScratch)

@@ -73,14 +73,21 @@ def _check(a, spec, n, what, device=None):
 class Context:
     """Owns the device tables and scratch for one or more GPUs (d377_ctx)."""
 
-    def __init__(self, device_ids=None):
+    def __init__(self, device_ids=None, comb_bits=0, comb_lazy=False):
+        """comb_bits: width of the fixed-base comb, 0 = the library's default (23) or 18 / 21 / 23 (0.24 / 1.6 / 5.9 GB per
+        device); comb_lazy: build it on the first fixed-base call instead of now (d377_ctx_create_ex) -- a context that
+        never multiplies by the generator then holds 0.73 GB per device instead of 6.7."""
         self._lib = _native.load()
         self._h = ctypes.c_void_p()
         if device_ids is None:
             ids, n = None, 0
         else:
             ids, n = (ctypes.c_int * len(device_ids))(*device_ids), len(device_ids)
-        _native.check(self._lib.d377_ctx_create(ids, n, ctypes.byref(self._h)))
+        if comb_bits == 0 and not comb_lazy:
+            _native.check(self._lib.d377_ctx_create(ids, n, ctypes.byref(self._h)))
+        else:
+            opts = _native.CtxOpts(ctypes.sizeof(_native.CtxOpts), int(comb_bits), 1 if comb_lazy else 0)
+            _native.check(self._lib.d377_ctx_create_ex(ids, n, ctypes.byref(opts), ctypes.byref(self._h)))
         self.device_ids = [self._lib.d377_ctx_device_id(self._h, i)
                            for i in range(self._lib.d377_ctx_num_devices(self._h))]
 
@@ -92,6 +99,12 @@ class Context:
         if rc < 0:
             _native.check(rc)
         return rc == 1, int(c.value)
+
+    def comb_info(self, dev=0):
+        """(width in bits, built yet?, table bytes) of the device's fixed-base comb: d377_ctx_comb_info."""
+        a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_uint64(0)
+        _native.check(self._lib.d377_ctx_comb_info(self._h, dev, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return int(a.value), bool(b.value), int(c.value)
 
     def chunk_residency(self, dev=0):
         """(lane sets per CU, largest residency of a set-claiming kernel per CU, LDS padding in bytes):

@@ -80,10 +80,31 @@ const char* d377_last_error(void);
 
 /* Builds the read-only device tables (Sarkar square-root tables of
  * src/ark_curve/invsqrt.rs:14-66, fixed-base table of Element::GENERATOR) once per device
- * and allocates the per-device scratch (about 6.7 GB of HBM per device: window tables, the records of the
- * batched inversions, the 5.9 GB fixed-base comb of 23-bit windows; `make lib FB_BITS=18` builds a 235 MB comb that
- * is 9-12 % slower on the fixed-base multiplication).  device_ids == NULL, n_dev == 0 -> device 0. */
+ * and allocates the per-device scratch (about 6.7 GB of HBM per device: 0.73 GB of window tables and records of the
+ * batched inversions, and the 5.9 GB fixed-base comb of 23-bit windows, built in 16 ms).  device_ids == NULL,
+ * n_dev == 0 -> device 0.  The comb is the one cost a caller may not want: in the reference Element::GENERATOR is a
+ * constant (src/min_curve/element.rs:61-81) and `GENERATOR * Fr` costs nothing until it is used -- d377_ctx_create_ex
+ * makes it so here too. */
 int d377_ctx_create(const int* device_ids, int n_dev, d377_ctx** out);
+/* The same with options (NULL = d377_ctx_create's defaults).
+ *   size        sizeof(d377_ctx_opts) as the caller was compiled (fields added later default to 0)
+ *   comb_bits   width of the fixed-base comb: 0 = the library's default (23), or 18 / 21 / 23 --
+ *               0.24 / 1.6 / 5.9 GB per device, 14 / 12 / 11 additions per scalar (18 is 9-12 % slower than 23 on
+ *               d377_batch_scalar_mul_base*, profiles/r05_ab_fixed_base_wide.txt); results are the same bytes
+ *   comb_lazy   0: the comb is built at context creation.  1: by the first fixed-base call on each device
+ *               (d377_batch_scalar_mul_base[_element][_dev], d377_batch_sharded_dev with those operations), which then
+ *               allocates, builds (16 ms at 23 bits) and synchronises once -- so that first call must not be inside a
+ *               stream capture (D377_ERR_ARG); a context that never multiplies by the generator holds 0.73 GB per device.
+ * A failed comb allocation is D377_ERR_HIP with a text that names the width and the smaller ones.
+ * d377_ctx_comb_info: the width of device `dev`'s comb, whether it has been built, and its size in bytes (any pointer
+ * may be NULL). */
+typedef struct d377_ctx_opts {
+  size_t size;
+  int comb_bits;
+  int comb_lazy;
+} d377_ctx_opts;
+int d377_ctx_create_ex(const int* device_ids, int n_dev, const d377_ctx_opts* opts, d377_ctx** out);
+int d377_ctx_comb_info(d377_ctx* ctx, int dev, int* comb_bits, int* built, uint64_t* table_bytes);
 void d377_ctx_destroy(d377_ctx* ctx);
 int d377_ctx_num_devices(const d377_ctx* ctx);
 int d377_ctx_device_id(const d377_ctx* ctx, int dev);

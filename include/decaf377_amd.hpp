@@ -116,6 +116,13 @@ class Engine {
     int rc = d377_ctx_create(device_ids.data(), (int)device_ids.size(), &ctx_);
     if (rc != D377_OK) throw DeviceError(rc);
   }
+  /// With the fixed-base comb's options (d377_ctx_create_ex): comb_bits 0 (default: 23), 18, 21 or 23; comb_lazy: the table
+  /// is built by the first GENERATOR * Fr batch -- Element::GENERATOR is a constant in the crate (src/min_curve/element.rs:61-81).
+  Engine(const std::vector<int>& device_ids, int comb_bits, bool comb_lazy) {
+    d377_ctx_opts o{sizeof(d377_ctx_opts), comb_bits, comb_lazy ? 1 : 0};
+    int rc = d377_ctx_create_ex(device_ids.data(), (int)device_ids.size(), &o, &ctx_);
+    if (rc != D377_OK) throw DeviceError(rc);
+  }
   ~Engine() { d377_ctx_destroy(ctx_); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;

@@ -75,6 +75,22 @@ impl GpuContext {
         check(unsafe { ffi::d377_ctx_create(device_ids.as_ptr(), device_ids.len() as i32, &mut p) })?;
         Ok(Self(p))
     }
+    /// The same with the fixed-base comb's options (d377_ctx_create_ex): `comb_bits` 0 (the library's default, 23), 18, 21
+    /// or 23 -- 0.24 / 1.6 / 5.9 GB per device; `comb_lazy`: build the table on the first `GENERATOR * Fr` batch instead of
+    /// now, so that a context that never multiplies by the generator does not pay for it (in the crate
+    /// `Element::GENERATOR` is a constant, src/min_curve/element.rs:61-81).
+    pub fn with_comb(device_ids: &[i32], comb_bits: i32, comb_lazy: bool) -> Result<Self, GpuError> {
+        let mut p = core::ptr::null_mut();
+        let opts = ffi::D377CtxOpts { size: core::mem::size_of::<ffi::D377CtxOpts>(), comb_bits, comb_lazy: comb_lazy as i32 };
+        check(unsafe { ffi::d377_ctx_create_ex(device_ids.as_ptr(), device_ids.len() as i32, &opts, &mut p) })?;
+        Ok(Self(p))
+    }
+    /// (comb width in bits, built yet?, table bytes) of device `dev`.
+    pub fn comb_info(&self, dev: i32) -> Result<(i32, bool, u64), GpuError> {
+        let (mut bits, mut built, mut bytes) = (0i32, 0i32, 0u64);
+        check(unsafe { ffi::d377_ctx_comb_info(self.0, dev, &mut bits, &mut built, &mut bytes) })?;
+        Ok((bits, built != 0, bytes))
+    }
     pub fn num_devices(&self) -> usize {
         unsafe { ffi::d377_ctx_num_devices(self.0) as usize }
     }

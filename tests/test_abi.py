@@ -51,6 +51,25 @@ def test_no_cpu_fallback_without_gpu(libpath):
         Context()
 
 
+def test_ctx_options_are_validated_before_any_device_is_touched(libpath):
+    """d377_ctx_create_ex: a bad option is D377_ERR_ARG whether or not a GPU is there (comb widths: 0, 18, 21, 23; comb_lazy
+    0 or 1; size = sizeof(d377_ctx_opts)); a good one gets as far as the device check."""
+    from decaf377_amd import _native
+    lib = _native.load()
+    h = ctypes.c_void_p()
+    mk = lambda size, bits, lazy: _native.CtxOpts(size, bits, lazy)
+    full = ctypes.sizeof(_native.CtxOpts)
+    for opts in (mk(full, 7, 0), mk(full, 24, 0), mk(full, 23, 2), mk(4, 23, 0)):
+        assert lib.d377_ctx_create_ex(None, 0, ctypes.byref(opts), ctypes.byref(h)) == -2, lib.d377_last_error()
+        assert not h.value
+    if lib.d377_device_count() == 0:
+        good = mk(full, 18, 1)
+        assert lib.d377_ctx_create_ex(None, 0, ctypes.byref(good), ctypes.byref(h)) == -3      # D377_ERR_NO_DEVICE
+        with pytest.raises(_native.NativeError):
+            from decaf377_amd import Context
+            Context(comb_lazy=True)
+
+
 def test_product_never_touches_oracle():
     """Nothing under decaf377_amd/ may import, link or name anything under oracle/."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "decaf377_amd")):

@@ -154,6 +154,67 @@ def test_groth16_gadget_regression_inputs_gpu(ctx, oracle, kats):
     assert (np.asarray(ctx.msm(X_, K_)[0]).reshape(32) == want).all()
 
 
+def test_lazy_comb_context_and_comb_widths(oracle, torch_mod):
+    """d377_ctx_create_ex (include/decaf377_amd.h): in the reference Element::GENERATOR is a constant
+    (src/min_curve/element.rs:61-81) and costs nothing until it is used.  A context created with comb_lazy holds under
+    1 GB of HBM (hipMemGetInfo before and after); operations that need no comb run on it; its first fixed-base call builds
+    the 5.9 GB table and is bit-exact; the 18- and 21-bit combs give the same bytes through every fixed-base route
+    (wave, quad, lane: narrow and wide launch; Encoding and Element forms)."""
+    import decaf377_amd as d
+    torch = torch_mod
+    rng = np.random.default_rng(606)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    c = d.Context([0], comb_lazy=True)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 1_000_000_000, free0 - free1
+    bits, built, nbytes = c.comb_info()
+    assert bits == 23 and not built and nbytes == 11 * (2**22 + 1) * 128
+    r0 = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    k = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    enc = c.encode_to_curve(r0)
+    out, st = c.scalar_mul_var(enc, k)
+    o_out, o_st = oracle.scalar_mul_var(oracle.encode_to_curve(r0), k)
+    assert (out == o_out).all() and (st == o_st).all()
+    assert not c.comb_info()[1]                                  # still no table
+    want = oracle.scalar_mul_base(k)
+    assert (c.scalar_mul_base(k) == want).all()                  # builds it
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert c.comb_info()[1] and free1 - free2 >= nbytes * 9 // 10
+    kd = torch.from_numpy(k).cuda()
+    assert (c.scalar_mul_base(kd).cpu().numpy() == want).all()    # the `_dev` route on the built table
+    c.close()
+    torch.cuda.synchronize()
+    # the narrower combs, eager and lazy, every route: 100 (a wave per scalar), 5 000 (a quad), 70 000 (lanes, narrow launch),
+    # 1.25 x 2^20 (lanes, wide launch: sample against the oracle, the rest against the default context)
+    sizes = (100, 5000, 70000)
+    ks = rng.integers(0, 256, (70000, 32), dtype=np.uint8)
+    ks[0] = 0
+    ks[1] = ibytes(R_ORDER - 1)
+    ks[2] = ibytes(R_ORDER)
+    ks[3] = 255
+    want = oracle.run_threads("scalar_mul_base", ks, None, len(os.sched_getaffinity(0)))[0]
+    big = torch.randint(0, 256, (5 * 2**18, 32), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    ref = None
+    for bits, lazy in ((23, False), (18, False), (21, True)):
+        c = d.Context([0], comb_bits=bits, comb_lazy=lazy)
+        assert c.comb_info()[:2] == (bits, not lazy)
+        for n in sizes:
+            assert (c.scalar_mul_base(ks[:n]) == want[:n]).all(), (bits, n)
+            assert (c.compress(c.scalar_mul_base_element(ks[:n])) == want[:n]).all(), (bits, n)
+        assert c.comb_info()[1]
+        got = c.scalar_mul_base(big)
+        if ref is None:
+            ref = got
+            assert (got[:4096].cpu().numpy() == oracle.scalar_mul_base(big[:4096].cpu().numpy())).all()
+        else:
+            assert bool((got == ref).all()), bits
+        c.close()
+        torch.cuda.synchronize()
+
+
 # --- committed model vectors -------------------------------------------------------------------
 def test_vectors(ctx, vectors):
     v = vectors["sqrt_ratio_zeta"]

@@ -12,8 +12,20 @@ C_TO_RUST = {
     "const uint8_t*": "*const u8", "uint8_t*": "*mut u8", "const uint64_t*": "*const u64", "uint64_t*": "*mut u64",
     "const int*": "*const c_int", "int*": "*mut c_int", "int": "c_int", "size_t": "usize", "void*": "*mut c_void", "const void*": "*const c_void",
     "const char*": "*const c_char", "void": None, "int64_t": "i64", "int64_t*": "*mut i64",
-    "const uint32_t**": "*mut *const u32",
+    "const uint32_t**": "*mut *const u32", "const d377_ctx_opts*": "*const D377CtxOpts",
 }
+
+
+def test_ctx_opts_struct_matches_header():
+    """d377_ctx_opts and its #[repr(C)] mirror: the same fields in the same order with the same C types."""
+    htext = open(os.path.join(ROOT, "include", "decaf377_amd.h")).read()
+    rtext = open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read()
+    body = re.search(r"typedef struct d377_ctx_opts \{(.*?)\} d377_ctx_opts;", htext, re.S).group(1)
+    cfields = [(t.strip(), n) for t, n in re.findall(r"\s*([a-z_0-9 ]+?)\s+([a-z_]+);", body)]
+    rbody = re.search(r"#\[repr\(C\)\]\s*pub struct D377CtxOpts \{(.*?)\}", rtext, re.S).group(1)
+    rfields = re.findall(r"pub ([a-z_]+): ([a-z_0-9]+),", rbody)
+    assert [(C_TO_RUST[t], n) for t, n in cfields] == [(t, n) for n, t in rfields] and len(cfields) == 3
+
 
 
 def header_prototypes():
