@@ -27,7 +27,7 @@ VARIANT ?=
 CSRC := decaf377_amd/csrc
 LIBDIR := decaf377_amd/lib
 HDRS := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/decaf377_amd.h
-UNITS := d377 msm codec_chunked
+UNITS := d377 msm codec_chunked batch_msm
 DEFS := -DD377_FB_BITS=$(FB_BITS) -DD377_DCB_K=$(DCB_K) -DD377_WAVES_PER_SIMD=$(WAVES_PER_SIMD) $(EXTRA)
 ifeq ($(CHECK_INVARIANTS),1)
 DEFS += -DD377_CHECK_INVARIANTS

@@ -1553,7 +1553,7 @@ void free_device(DeviceState& d) {
   if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
   (void)d.vb_guard.drain();
   (void)d.msm.guard.drain();
-  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.fb_bases); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.pool_health); (void)hipFree(d.inv_fail);
+  (void)hipFree(d.gtab); (void)hipFree(d.s_lookup); (void)hipFree(d.fbase); (void)hipFree(d.fb_bases); (void)hipFree(d.bm_scratch); (void)hipFree(d.vb_scratch); (void)hipFree(d.dcb_scratch); (void)hipFree(d.slot_pool); (void)hipFree(d.pool_health); (void)hipFree(d.inv_fail);
   if (d.starve_host) (void)hipHostFree(d.starve_host);
   d.starve_host = nullptr;
   if (d.pool_host) (void)hipHostFree(d.pool_host);

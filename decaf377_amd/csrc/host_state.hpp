@@ -105,6 +105,9 @@ struct DeviceState {
   int codec_chunked = -1;                // codec_chunked.hip: may its kernels claim lane sets (their residency matches them)?  -1 = not asked yet
   int msm_span_blocks = -1;              // msm.hip: workgroups of k_msm_spans a CU holds (occupancy query), -1 = not asked yet
   int dcb_sets = 0;                      // lane sets of the round-record area and its pool (the largest chunk_sets x CUs)
+  uint32_t* bm_scratch = nullptr;        // batch_msm.hip: tables and digit words of the batched small sums, per resident lane; grown on first use
+  size_t bm_cap = 0;
+  int bm_lds[2] = {-1, -1};              // batch_msm.hip: LDS padding of its lane kernel (Element / Encoding form), -1 = not asked yet
   uint32_t* gtab = nullptr;
   uint8_t* s_lookup = nullptr;
   uint32_t* fbase = nullptr;             // the fixed-base comb: null until built (d377.hip ensure_comb: at context creation, or by the first fixed-base call of a lazy context)

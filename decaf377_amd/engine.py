@@ -454,6 +454,45 @@ class Context:
         return self._run("d377_batch_to_affine", [xyzt], [ELEM], [AFF], outs)[0]
 
     # -- multi-scalar multiplication -------------------------------------------------------------
+    def msm_small(self, points, scalar32, m, outs=None):
+        """n independent multiscalar sums of m terms each (d377_batch_msm_small[_encoded]): Element::vartime_multiscalar_mul
+        (src/ark_curve/element/projective.rs:99-117) in the shape of the reference's own test, a 3-term sum per case
+        (tests/operations.rs:44-60), many at once.  points: [n * m, 16] u64 Elements or [n * m, 32] u8 Encodings, scalar32:
+        [n * m, 32], term-major within a sum; 1 <= m <= 8.  Returns enc [n, 32] for Elements, (enc, status [n * m]) for
+        Encodings (an invalid Encoding is reported and left out of its sum)."""
+        m = int(m)
+        if points.ndim != 2 or int(points.shape[1]) not in (16, 32):
+            raise ValueError("msm_small: points must be [n * m, 16] Elements or [n * m, 32] Encodings")
+        encoded = int(points.shape[1]) == 32
+        terms = _rows(points)
+        if m < 1 or terms % m:
+            raise ValueError("msm_small: the number of points must be a multiple of m")
+        n = terms // m
+        _check(points, ENC if encoded else ELEM, terms, "msm_small points")
+        _check(scalar32, ENC, terms, "msm_small scalars", points.device if _is_torch(points) else None)
+        name = "d377_batch_msm_small_encoded" if encoded else "d377_batch_msm_small"
+        if _is_torch(points):
+            import torch
+            dev = points.device
+            di = self._dev_index(dev)
+            pts, sc = points.contiguous(), scalar32.contiguous()
+            if outs is None:
+                outs = [torch.empty((n, 32), dtype=torch.uint8, device=dev)] + ([torch.empty((terms,), dtype=torch.uint8, device=dev)] if encoded else [])
+            for a, spec, rows in zip(outs, [ENC, FLAG], [n, terms]):
+                _check(a, spec, rows, "msm_small output", dev)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            p = lambda t: ctypes.c_void_p(t.data_ptr())
+            args = [self._h, di, stream, p(pts), p(sc), ctypes.c_size_t(m), ctypes.c_size_t(n)] + [p(o) for o in outs]
+            _native.check(getattr(self._lib, name + "_dev")(*args))
+            return tuple(outs) if encoded else outs[0]
+        pts, sc = np.ascontiguousarray(points), np.ascontiguousarray(scalar32)
+        if outs is None:
+            outs = [np.zeros((n, 32), np.uint8)] + ([np.zeros((terms,), np.uint8)] if encoded else [])
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        args = [self._h, p(pts), p(sc), ctypes.c_size_t(m), ctypes.c_size_t(n)] + [p(o) for o in outs]
+        _native.check(getattr(self._lib, name)(*args))
+        return tuple(outs) if encoded else outs[0]
+
     def msm(self, points, scalar32, encoded=None):
         """Element::vartime_multiscalar_mul (src/ark_curve/element/projective.rs:99-117).
         points: [n, 16] u64 Elements or [n, 32] u8 Encodings (detected by the row width).

@@ -142,6 +142,26 @@ static void vartime_multiscalar_mul_matches_scalar_mul(Engine& e) {
     Element msm = e.vartime_multiscalar_mul(k, pts);
     CHECK(e.eq(sum, {msm})[0]);
   }
+  // the same property for MANY cases in one call (d377_batch_msm_small): 40 three-term sums, Elements and Encodings
+  {
+    const size_t cases = 40, m = 3;
+    std::vector<Fq> r(cases * m); std::vector<Fr> k(cases * m);
+    for (auto& x : r) for (auto& b : x.b) b = (uint8_t)rng();
+    for (auto& x : k) for (auto& b : x.b) b = (uint8_t)rng();
+    auto enc = e.encode_to_curve(r);
+    std::vector<Element> pts;
+    for (auto& d : e.vartime_decompress(enc)) pts.push_back(d.unwrap());
+    auto sums = e.vartime_multiscalar_mul_batch(m, k, pts);
+    auto sums_e = e.vartime_multiscalar_mul_batch_encoded(m, k, enc);
+    CHECK(sums.size() == cases && sums_e.first.size() == cases);
+    for (size_t c = 0; c < cases; ++c) {
+      std::vector<Fr> kc(k.begin() + c * m, k.begin() + (c + 1) * m);
+      std::vector<Element> pc(pts.begin() + c * m, pts.begin() + (c + 1) * m);
+      CHECK(e.vartime_compress({e.vartime_multiscalar_mul(kc, pc)})[0] == sums[c]);
+      CHECK(sums_e.first[c] == sums[c]);
+    }
+    for (auto& st : sums_e.second) CHECK(st.ok);
+  }
   // P + (-P) is the identity; GENERATOR is the decoding of [8, 0, ...]
   auto g = Engine::generator();
   CHECK(e.is_identity(e.add({g}, e.neg({g})))[0]);

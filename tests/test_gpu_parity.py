@@ -1504,6 +1504,8 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_fr_from_bytes_checked_dev": lambda f: f.fr_from_bytes_checked,
         "d377_msm_dev": lambda f: f.msm,
         "d377_msm_encoded_dev": lambda f: f.msm,
+        "d377_batch_msm_small_dev": lambda f: f.msm_small,
+        "d377_batch_msm_small_encoded_dev": lambda f: f.msm_small,
         "d377_sum_elements_dev": None,
         "d377_ctx_starved_counter_dev": None,          # test_starved_call_is_an_error_not_a_silent_partial_output
         "d377_batch_sharded_dev": None,
@@ -1519,6 +1521,8 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_encode_to_curve_wide_dev": [(w48,), (w64,)],
         "d377_batch_fq_op_dev": [("add", a, b), ("sub", a, b), ("mul", a, b), ("square", a), ("neg", a), ("inverse", a)],
         "d377_msm_dev": [(Qp, k)], "d377_msm_encoded_dev": [(raw, k)],
+        "d377_batch_msm_small_dev": [(Qp, k, 5), (Qp, k, 2)],                      # 500 sums: a wave per sum; 1 250: a lane per sum
+        "d377_batch_msm_small_encoded_dev": [(raw, k, 5), (raw, k, 2)],
         "d377_batch_scalar_mul_var_element_dev": [(Qp, k)], "d377_batch_scalar_mul_base_element_dev": [(k,)],
         "d377_batch_compress_to_field_dev": [(Qp,)], "d377_batch_encode_to_curve_element_dev": [(r0,)],
         "d377_batch_hash_to_curve_element_dev": [(r0, r1)],

@@ -260,3 +260,123 @@ def test_msm_full_size_properties(ctx, oracle, log_n):
     q = 1 << 14
     e3, _, _ = ctx.msm(P[:q], k[:q])
     assert bytes(e3.cpu().numpy()) == bytes(oracle.msm(P[:q].cpu().numpy().view(np.uint64), k[:q].cpu().numpy(), threads=16)[0])
+
+
+# ---- many small sums at once: d377_batch_msm_small (batch_msm.hip) -----------------------------------------------------------
+def _fold_sums(oracle, P, k, m, threads=8):
+    """The reference's fold (src/ark_curve/element/projective.rs:99-117) per sum, on the oracle: Elements P [n m, 16], scalars
+    k [n m, 32] -> encodings [n, 32].  The products through the threaded scalar multiplication (on Encodings), the sums on
+    Element records."""
+    enc = oracle.compress(P)
+    prod_enc, st, _ = oracle.run_threads("scalar_mul_var", enc, k, threads)
+    assert not st.any()
+    prod = oracle.decompress(prod_enc)[0]
+    acc = prod[0::m].copy()
+    for j in range(1, m):
+        acc = oracle.add_xyzt(acc, prod[j::m])
+    return oracle.compress(acc)
+
+
+@pytest.fixture(params=["default", "lanes", "waves"])
+def small_route(request, ctx):
+    """d377_batch_msm_small's two kernels on the same inputs: a wave per sum (batches up to one sum per SIMD by default) and a
+    lane per sum (beyond) -- each also forced over all the test sizes."""
+    if request.param == "default":
+        yield request.param
+    else:
+        with ctx.tuning(tiny_max=0 if request.param == "lanes" else 1 << 20):
+            yield request.param
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 8])
+def test_batch_msm_small_matches_oracle_fold(ctx, oracle, m, small_route):
+    """tests/operations.rs:44-60 at scale: n independent m-term sums, Element and Encoding inputs, bit-exact against the
+    oracle's fold of its own products.  Mixed in: scalars 0, 1, r - 1, r, 2^256 - 1; the identity; projective Elements (Z != 1:
+    outputs of a scalar multiplication); a record with Z = 0 (the identity by contract); invalid Encodings (reported, left out)."""
+    rng = np.random.default_rng(7100 + m)
+    for n in (1, 3, 256, 1025, 3000):
+        terms = n * m
+        P = oracle.elligator_map_xyzt(rng.integers(0, 256, (terms, 32), dtype=np.uint8))
+        k = rng.integers(0, 256, (terms, 32), dtype=np.uint8)
+        for i, v in enumerate([0, 1, R_ORDER - 1, R_ORDER, (1 << 256) - 1]):
+            if i < terms:
+                k[(i * 7) % terms] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+        if terms >= 8:
+            P[5] = oracle.decompress(np.zeros((1, 32), np.uint8))[0][0]            # the identity as a term
+            P[6:8] = oracle.scalar_mul_xyzt(P[6:8], k[0:2])                         # projective representatives
+        want = _fold_sums(oracle, P, k, m)
+        got = ctx.msm_small(P, k, m)
+        assert got.shape == (n, 32) and (got == want).all(), (m, n, small_route, np.nonzero((got != want).any(axis=1))[0][:8])
+        # Encoding input: the same sums; then with invalid encodings, which drop out of their sums
+        encs = oracle.compress(P)
+        got_e, st = ctx.msm_small(encs, k, m)
+        assert not st.any() and (got_e == want).all(), (m, n, small_route)
+        if terms >= 8:
+            bad = encs.copy()
+            bad[3] = 0xFF
+            bad[terms - 1, 31] |= 0x80
+            ident = oracle.decompress(np.zeros((1, 32), np.uint8))[0][0]
+            Pref = P.copy()
+            Pref[3] = ident
+            Pref[terms - 1] = ident
+            want_b = _fold_sums(oracle, Pref, k, m)
+            Pz = Pref.copy()
+            Pz[3] = 0                                                               # Z = 0: no group element, counts as the identity
+            got_b, st = ctx.msm_small(bad, k, m)
+            assert list(np.nonzero(st)[0]) == [3, terms - 1] and (got_b == want_b).all(), (m, n, small_route)
+            assert (ctx.msm_small(Pz, k, m) == want_b).all(), (m, n, small_route)
+
+
+@pytest.mark.gpu
+def test_batch_msm_small_device_path_and_errors(ctx, oracle):
+    """Device tensors (the `_dev` entry points), in order on a stream; argument errors are errors."""
+    import torch
+    import decaf377_amd._native as nat
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7200)
+    m, n = 3, 2000
+    P = oracle.elligator_map_xyzt(rng.integers(0, 256, (n * m, 32), dtype=np.uint8))
+    k = rng.integers(0, 256, (n * m, 32), dtype=np.uint8)
+    want = _fold_sums(oracle, P, k, m)
+    Pd = torch.from_numpy(P.view(np.int64)).to(dev)
+    kd = torch.from_numpy(k).to(dev)
+    out = ctx.msm_small(Pd, kd, m)
+    assert (out.cpu().numpy() == want).all()
+    enc_d = ctx.compress(Pd)
+    out_e, st = ctx.msm_small(enc_d, kd, m)
+    assert (out_e.cpu().numpy() == want).all() and not st.cpu().numpy().any()
+    with pytest.raises(nat.NativeError):
+        ctx.msm_small(P[: 9 * 4], k[: 9 * 4], 9)                                    # more than D377_BATCH_MSM_MAX_TERMS terms
+    with pytest.raises(ValueError):
+        ctx.msm_small(P[:10], k[:10], 3)                                            # not a whole number of sums
+    assert ctx.msm_small(P[:0], k[:0], 3).shape == (0, 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,log_n", [(3, 20), (2, 18), (8, 17)])
+def test_batch_msm_small_full_size(ctx, oracle, m, log_n):
+    """2^20 three-term sums (and 2^18 pairs, 2^17 eight-term sums) on the device path: equal to the composition the call
+    replaces -- m scalar-multiplication batches on Elements, m - 1 addition batches, a compression -- on every sum, and to the
+    oracle's fold on a 2 048-sum sample; the Encoding form gives the same bytes."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << log_n
+    g = torch.Generator(device=dev).manual_seed(7300 + m)
+    r0 = torch.randint(0, 256, (n * m, 32), dtype=torch.uint8, device=dev, generator=g)
+    k = torch.randint(0, 256, (n * m, 32), dtype=torch.uint8, device=dev, generator=g)
+    encs = ctx.encode_to_curve(r0)
+    P, _ = ctx.decompress(encs)
+    out = ctx.msm_small(P, k, m)
+    prod = ctx.scalar_mul_var_element(P, k)
+    acc = prod[0::m].contiguous()
+    for j in range(1, m):
+        acc = ctx.add(acc, prod[j::m].contiguous())
+    ref = ctx.compress(acc)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    out_e, st = ctx.msm_small(encs, k, m)
+    assert torch.equal(out_e, ref) and int(st.sum().item()) == 0
+    q = 2048
+    want = _fold_sums(oracle, P[: q * m].cpu().numpy().view(np.uint64), k[: q * m].cpu().numpy(), m, threads=16)
+    assert (out[:q].cpu().numpy() == want).all()

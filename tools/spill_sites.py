@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""Where the scratch (spill / stack) instructions of each kernel sit: per kernel, scratch_load / scratch_store counts by the
-loop depth of their basic block, read from hipcc's assembly (-S).  Depth 0 is straight-line code around the loops (kernel
-prologue, epilogue), the per-element loops of the chunked kernels are depth 2 and deeper.
-usage: tools/spill_sites.py [extra -D flags]   (compiles both translation units to /tmp; a few minutes)"""
+"""Where the spill instructions of each kernel sit: per kernel, scratch_load / scratch_store (VGPR spills, stack) and
+v_writelane_b32 / v_readlane_b32 (SGPR spills parked in VGPR lanes, and the few lane moves a kernel writes itself) counted by
+the loop depth of their basic block, read from hipcc's assembly (-S).  Depth 0 is straight-line code around the loops
+(kernel prologue, epilogue); in the chunked kernels depth 1 is the walk over chunks, depth 2 the per-element loops, depth 3
+and deeper the loops inside an element (the window loop of a scalar multiplication, its four doublings).
+usage: tools/spill_sites.py [--units a,b] [extra -D flags]   (compiles the translation units to /tmp; a few minutes)"""
 import collections
 import re
 import subprocess
 import sys
 
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-DD377_DCB_K=8", "-DD377_WAVES_PER_SIMD=2"] + sys.argv[1:]
-for unit in ("d377", "msm", "codec_chunked"):
+ARGS = sys.argv[1:]
+UNITS = ("d377", "msm", "codec_chunked", "batch_msm")
+if ARGS and ARGS[0] == "--units":
+    UNITS = tuple(ARGS[1].split(","))
+    ARGS = ARGS[2:]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-DD377_DCB_K=8", "-DD377_WAVES_PER_SIMD=2"] + ARGS
+for unit in UNITS:
     out = "/tmp/spill_sites_%s.s" % unit
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["--cuda-device-only", "-S", "decaf377_amd/csrc/%s.hip" % unit, "-o", out],
                           stderr=subprocess.DEVNULL)
@@ -40,6 +47,8 @@ for unit in ("d377", "msm", "codec_chunked"):
             continue
         if ins[0].startswith("scratch_"):
             counts[kernel][(ins[0].split("_")[1], depth)] += 1
+        elif ins[0] in ("v_writelane_b32", "v_readlane_b32"):
+            counts[kernel][("writelane" if ins[0] == "v_writelane_b32" else "readlane", depth)] += 1
         elif ins[0] == "s_swappc_b64":
             counts[kernel][("call", depth)] += 1
         elif ins[0] == "s_endpgm":
