@@ -1089,35 +1089,36 @@ D377_HD int fb_digit(const uint32_t k[8], int i, uint32_t& carry) {
   carry = (dd >= (1u << (BITS - 1))) ? 1u : 0u;        // k < r < 2^251: the top digit never carries out
   return (int)dd - (int)(carry << BITS);
 }
-// want_t: whether the caller reads T of the result.  The entry of window i + 1 is fetched before the addition of
-// window i: the table lives in L2 / Infinity Cache, and one mixed addition is only ~1 500 instructions.  (Two entries
-// in flight instead of one: 1.07-1.11e9/s against 1.09-1.12e9/s at 2^20 and 2^22, same box -- the gathers are covered.)
+// want_t: whether the caller reads T of the result.  FTab: request(i, j) asks for entry j of window i, take(swap) -> gea hands
+// over the entry requested last (swap: the record of -P, Y + X and Y - X exchanged).  The entry of window i + 1 is requested
+// before the addition of window i, right after window i's has been taken, so a table may keep ONE entry in flight in storage
+// of its own (d377.hip: FixedTabCoop's LDS tile, FixedTab's raw registers).
 template <int BITS = FB_BITS, class FTab>
-D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab, bool want_t = true) {
+D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], FTab& ftab, bool want_t = true) {
   constexpr int W = FbShape<BITS>::windows;
   uint32_t carry = 0;
   int d = fb_digit<BITS>(k, 0, carry);
   bool neg = d < 0;
-  gea e = ftab.load(0, neg ? -d : d, neg);
+  ftab.request(0, neg ? -d : d);
   // window 0: the sum starts from the record itself (ge_from_cached_affine: 4 products) instead of a 7-product addition to
   // the identity -- 85 M + 3 S per scalar where the plain loop took 88 M + 3 S
   ge r;
   {
-    const gea cur = e;
+    const gea cur = ftab.take(neg);
     const bool neg_cur = neg;
     d = fb_digit<BITS>(k, 1, carry);
     neg = d < 0;
-    e = ftab.load(1, neg ? -d : d, neg);
+    ftab.request(1, neg ? -d : d);
     r = ge_from_cached_affine(cur, neg_cur);
   }
 #pragma unroll 1
   for (int i = 1; i < W; ++i) {
-    const gea cur = e;
+    const gea cur = ftab.take(neg);
     const bool neg_cur = neg;
     if (i + 1 < W) {
       d = fb_digit<BITS>(k, i + 1, carry);
       neg = d < 0;
-      e = ftab.load(i + 1, neg ? -d : d, neg);
+      ftab.request(i + 1, neg ? -d : d);
     }
     r = ge_add_affine(r, cur, neg_cur, want_t || i + 1 < W);
   }

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Same-box A/B of two builds of the library (build/variants/*.so or the product), the same size sweep in the order A B B A.
 # usage (GPU box): tools/ab_variants.sh build/variants/noprio.so decaf377_amd/lib/libdecaf377_amd.so out.txt [sizes] [ops]
-A=$1; B=$2; out=$3
+set -u
+A=$(realpath "$1"); B=$(realpath "$2"); out=$3
+[ -f "$A" ] && [ -f "$B" ] || { echo "ab_variants: a library is missing ($A, $B)" >&2; exit 1; }
 SIZES=${4:-524288,1048576,1572864,2097152,4194304}
 OPS=${5:-"scalar_mul_var,scalar_mul_var_element,scalar_mul_base,sqrt_ratio_zeta,decompress,compress,roundtrip,encode_to_curve,hash_to_curve"}
 : > "$out"
@@ -9,7 +11,11 @@ for rep in 1 2; do
   if [ $rep = 1 ]; then order=("$A" "$B"); else order=("$B" "$A"); fi
   for t in "${order[@]}"; do
     echo "=== lib $t, pass $rep" >> "$out"
-    D377_LIB=$PWD/$t timeout -k 10 400 python3 tools/size_sweep.py --sizes $SIZES --ops "$OPS" 2>&1 | grep -v "amdgpu.ids\|^one MI355X" | sed 's/   graph:.*//' >> "$out"
+    D377_LIB=$t timeout -k 10 400 python3 -u tools/size_sweep.py --sizes $SIZES --ops "$OPS" > "$out.pass" 2>&1
+    rc=$?
+    grep -v "amdgpu.ids\|^one MI355X" "$out.pass" | sed 's/   graph:.*//' >> "$out"
+    [ $rc -eq 0 ] && grep -q " us " "$out.pass" || { echo "ab_variants: the sweep of $t failed (rc=$rc) or printed no timings" >&2; rm -f "$out.pass"; exit 1; }
+    rm -f "$out.pass"
   done
 done
 python3 - "$out" "$A" "$B" <<'P'
