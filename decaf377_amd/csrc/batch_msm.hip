@@ -205,7 +205,7 @@ using row::RQ_WORDS;
 template <bool ENCODED>
 __global__ void __launch_bounds__(64)
 k_batch_msm_wave(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int m, size_t n, uint8_t* out32, uint8_t* status) {
-  __shared__ uint32_t tab[BM_MAX * row::RQ_TAB_ENTRIES * RQ_WORDS];
+  extern __shared__ uint32_t tab[];                                // m tables of RQ_TAB_ENTRIES x RQ_WORDS words (dynamic: 2 304 bytes per term)
   __shared__ uint32_t xrec[2 * RQ_WORDS];
   __shared__ uint32_t sdg[BM_MAX][8];                              // the points' signed digits (wave-uniform reads in the loop)
   const int t = threadIdx.x;
@@ -290,11 +290,14 @@ int batch_msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pt
                      uint8_t* out32, uint8_t* status) {
   if (n == 0) return D377_OK;
   const SqrtTables T = d.tables();
-  // up to one sum per SIMD: a wave per sum (D377_TUNE_TINY_MAX: the developer override of every wave-per-element route)
-  const size_t wave_max = (size_t)d.tuned(D377_TUNE_TINY_MAX, (long long)d.cus * 4);
+  // up to four sums per SIMD: a wave per sum (the lane kernel needs two sums per lane of the chip before it is the better use of
+  // it: 2^12 three-term sums 1.41 ms on lanes).  D377_TUNE_TINY_MAX, the developer override of every wave-per-element route,
+  // scales this one too.
+  const size_t wave_max = 4 * (size_t)d.tuned(D377_TUNE_TINY_MAX, (long long)d.cus * 4);
   if (n <= wave_max) {
-    if (encoded) hipLaunchKernelGGL(k_batch_msm_wave<true>, dim3((unsigned)n), dim3(64), 0, s, T, pts_in, scalars, (int)m, n, out32, status);
-    else hipLaunchKernelGGL(k_batch_msm_wave<false>, dim3((unsigned)n), dim3(64), 0, s, T, pts_in, scalars, (int)m, n, out32, status);
+    const size_t lds = m * row::RQ_TAB_ENTRIES * RQ_WORDS * sizeof(uint32_t);
+    if (encoded) hipLaunchKernelGGL(k_batch_msm_wave<true>, dim3((unsigned)n), dim3(64), lds, s, T, pts_in, scalars, (int)m, n, out32, status);
+    else hipLaunchKernelGGL(k_batch_msm_wave<false>, dim3((unsigned)n), dim3(64), lds, s, T, pts_in, scalars, (int)m, n, out32, status);
     HIP_TRY(hipGetLastError());
     return D377_OK;
   }

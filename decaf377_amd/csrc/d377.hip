@@ -103,6 +103,9 @@ struct FixedTabCoop {
 #ifndef D377_FB_COOP
 #define D377_FB_COOP 1                  // 0: A/B -- every lane gathers its own records (rounds 2-5)
 #endif
+#ifndef D377_FB_AHEAD
+#define D377_FB_AHEAD 1                 // 0: A/B -- a scalar requests its own first entry, the compressor loads where it uses (rounds 2-5)
+#endif
 
 // ------------------------------------------------------------------------- init kernels ---
 __device__ fe fe_pow_u32(const fe& x, uint32_t e) {   // e >= 1
@@ -509,35 +512,47 @@ __global__ void __launch_bounds__(BLOCK, FB_SETS) k_scalar_mul_base(SqrtTables T
                                                            const uint8_t* scalar32, size_t n, uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();                        // unused here (no square root): residency is capped by the launch's LDS padding
   D377_DCB_BEGIN(out32);
+  // A scalar's first comb entry is requested by the scalar BEFORE it (fb_request_first), ahead of that one's compressor state,
+  // and its bytes are loaded a whole multiplication ahead: as written in rounds 2-5 every scalar began with two trips to HBM one
+  // after the other -- its bytes, then, once the first digit was known, its first entry -- ~4 000 cycles a wave waited, next to
+  // the compressor's ~4 000 (dcb_finish_ahead_with): SQ_WAIT_ANY / SQ_WAVE_CYCLES 0.22, 18 % of the issue slots empty.  Index i
+  // of the walk's element j + 1 is i + BLOCK; past the batch (a chunk's last element, a ragged wave's idle lanes) the last
+  // scalar stands in and what was requested for it is simply never taken.
 #if D377_FB_COOP
   __shared__ uint4 fb_tile[BLOCK / 64][512];
   FixedTabCoop<BITS> ft{fbase, fb_tile[threadIdx.x >> 6], (int)(threadIdx.x & 63)};
-  dcb_rounds<0, true, true, true>(n, io, pt,
+#else
+  FixedTab<BITS> ft{fbase, {}};
+#endif
+  uint32_t kc[8] = {};                     // the current scalar, reduced and halved; its first entry is on its way
+  dcb_rounds<0, true, true, true, D377_FB_AHEAD != 0>(n, io, pt,
     [&](size_t, int) {},
     [&](size_t i, int j, const uint32_t (*)[8], bool) {
       const bool live = i < n;           // a ragged last wave: its idle lanes redo the last scalar and store nothing
-      uint32_t k[8];
-      load32(scalar32, live ? i : n - 1, k);
-      fr_reduce_words(k);
-      fr_half_words(k);
-      const ge r = ge_scalar_mul_base_w8<BITS>(k, ft, DCB_WANT_T);
+#if D377_FB_AHEAD
+      if (j == 0) {                      // a chunk's first scalar has nobody before it
+        load32(scalar32, live ? i : n - 1, kc);
+        fr_reduce_words(kc);
+        fr_half_words(kc);
+        fb_request_first<BITS>(kc, ft);
+      }
+      uint32_t kn[8];
+      load32(scalar32, i + BLOCK < n ? i + BLOCK : n - 1, kn);
+      const ge r = ge_scalar_mul_base_w8<BITS, true>(kc, ft, DCB_WANT_T);
+      fr_reduce_words(kn);
+      fr_half_words(kn);
+      fb_request_first<BITS>(kn, ft);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kc[q] = kn[q];
+#else
+      load32(scalar32, live ? i : n - 1, kc);
+      fr_reduce_words(kc);
+      fr_half_words(kc);
+      const ge r = ge_scalar_mul_base_w8<BITS>(kc, ft, DCB_WANT_T);
+#endif
       D377_INVARIANT(T, r, live);
       if (live) dcb_put(io, j, ge_dcb_from_half(r, false));
     });
-#else
-  FixedTab<BITS> ft{fbase, {}};
-  dcb_rounds<0, true>(n, io, pt,
-    [&](size_t, int) {},
-    [&](size_t i, int j, const uint32_t (*)[8], bool) {
-      uint32_t k[8];
-      load32(scalar32, i, k);
-      fr_reduce_words(k);
-      fr_half_words(k);
-      const ge r = ge_scalar_mul_base_w8<BITS>(k, ft, DCB_WANT_T);
-      D377_INVARIANT(T, r, true);
-      dcb_put(io, j, ge_dcb_from_half(r, false));
-    });
-#endif
   D377_DCB_END();
 }
 
@@ -1006,6 +1021,10 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var_el(con
   tab.tid = (size_t)slot * BLOCK + threadIdx.x;
   const size_t chunk_elems = (size_t)dcb.per_lane * BLOCK;
   for (size_t chunk = blockIdx.x; chunk * chunk_elems < n; chunk += gridDim.x) {
+    // a workgroup that walks several chunks (beyond the grid cap) draws a new ticket for each, as dcb_rounds does: the word of
+    // a set in use keeps changing however long the launch (d377_ctx_reset_scratch frees only sets whose ticket stood still)
+    if (chunk != blockIdx.x && threadIdx.x == 0)
+      atomicExch(dcb.pool + slot, (int)(atomicAdd(dcb.health, 1u) & 0x7FFFFFFFu) + 1);
 #pragma unroll 1
     for (int j = 0; j < dcb.per_lane; ++j) {
       const size_t i = chunk * chunk_elems + (size_t)j * BLOCK + threadIdx.x;
@@ -1879,6 +1898,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
       dv.per_lane = n > d.resident_lanes() ? 2 : 1;
       size_t nch = (n + (size_t)dv.per_lane * BLOCK - 1) / ((size_t)dv.per_lane * BLOCK);
       if (nch > (size_t)d.cus * 64) nch = (size_t)d.cus * 64;
+      // `dcb` carries the priority rule of ITS deal (chunks of up to 16 per lane); this launch has its own shape -- 8 192 chunks
+      // in 16 generations at 2^22 -- and the rule is about generations: priorities in launches of one or two of them
+      dv.prio = nch <= 2 * (size_t)d.cus * WAVES_PER_SIMD ? 1 : 0;
       if ((rc = vb.acquire())) return rc;
       hipLaunchKernelGGL(k_scalar_mul_var_el, dim3((int)nch), dim3(BLOCK), d.chunk_lds[CK_MUL_VAR_EL], s, (const uint64_t*)in0, (const uint8_t*)in1, n,
                          (uint64_t*)out0, d.vb_scratch, dv);

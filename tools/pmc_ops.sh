@@ -4,18 +4,24 @@
 # per element, cycles, issue-slot utilisation (VALU instructions x 4 cycles / SIMD against GRBM_GUI_ACTIVE / 8 XCDs), wait
 # share, LDS / VMEM instructions, L2 hit rate, fetched / written bytes (FETCH_SIZE doubled: gfx950 correction of the guide).
 # usage: tools/pmc_ops.sh <outdir> "<op,op,...>" "<size,size,...>"      (D377_LIB selects a variant build)
-out=$1; ops=$2; sizes=$3
-ROOT=$(pwd)
+set -u
+out=$(realpath -m "$1"); ops=$2; sizes=$3
+ROOT=$(realpath "$(dirname "$0")/..")
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 i=0
+failed=0
 for grp in "SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU" "SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS" \
            "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$ROOT/$out/pmc$i" -- python3 "$ROOT/tools/size_sweep.py" --ops "$ops" --sizes "$sizes" > "$ROOT/$out/pmc$i.log" 2>&1
-  echo "pass $i ($grp): rc=$?"
+  timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/pmc$i" -- python3 "$ROOT/tools/size_sweep.py" --ops "$ops" --sizes "$sizes" > "$out/pmc$i.log" 2>&1
+  rc=$?
+  nf=$(find "$out/pmc$i" -name '*counter_collection.csv' 2>/dev/null | wc -l)
+  echo "pass $i ($grp): rc=$rc counter files=$nf"
+  [ "$rc" -eq 0 ] && [ "$nf" -gt 0 ] || failed=$((failed+1))
 done
 cd "$ROOT"
+[ "$failed" -eq 0 ] || { echo "$failed pass(es) failed or produced no counter file: no summary" >&2; exit 1; }
 python3 - "$out" <<'P'
 import csv, glob, os, re, sys, collections
 out = sys.argv[1]

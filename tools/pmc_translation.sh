@@ -3,8 +3,10 @@
 # stalls), L2 (TCC tag stalls, requests in flight) and the fabric behind it (EA read requests, DRAM credit stalls), per kernel
 # and grid size, for chosen operations (tools/size_sweep.py as the workload).  One rocprofv3 --pmc pass per group, only
 # --kernel-trace beside it; a pass that fails (a counter the device refuses) is reported and skipped, and the script exits
-# non-zero when NO pass produced a counter file.
-# usage: tools/pmc_translation.sh <outdir> "<op,op,...>" "<size,...>"        (D377_LIB selects a variant build)
+# non-zero when NO pass produced a counter file.  (The TA_* and TD_* groups are left out: on this pool rocprofv3 never returns
+# from a pass that holds them -- two passes, 300 s each, killed by their timeouts in round 6.)
+# usage: tools/pmc_translation.sh <outdir> "<op,op,...>" "<size,...>"        (D377_LIB selects a variant build;
+#        PMC_GROUPS=<file> replaces the counter groups below: one group per line)
 set -u
 out=$(realpath -m "$1"); ops=$2; sizes=$3
 ROOT=$(realpath "$(dirname "$0")/..")
@@ -15,12 +17,12 @@ ok=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/pmc$i" -- python3 "$ROOT/tools/size_sweep.py" --ops "$ops" --sizes "$sizes" > "$out/pmc$i.log" 2>&1
+  timeout -k 10 150 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/pmc$i" -- python3 "$ROOT/tools/size_sweep.py" --ops "$ops" --sizes "$sizes" > "$out/pmc$i.log" 2>&1
   rc=$?
   nf=$(find "$out/pmc$i" -name '*counter_collection.csv' 2>/dev/null | wc -l)
   echo "pass $i ($grp): rc=$rc counter files=$nf"
   [ "$nf" -gt 0 ] && ok=$((ok+1))
-done <<'G'
+done < <(if [ -n "${PMC_GROUPS:-}" ]; then cat "$PMC_GROUPS"; else cat <<'G'
 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU
 SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_BUSY_CYCLES
 TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_PERMISSION_MISS_sum
@@ -29,13 +31,12 @@ TCP_UTCL1_LFIFO_FULL_sum TCP_UTCL1_STALL_LFIFO_NO_RES_sum TCP_UTCL1_STALL_UTCL2_
 TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum
 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum
 TCP_RFIFO_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_READ_sum
-TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
-TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum
 TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_TAG_STALL_sum
 TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_LEVEL_sum TCC_BUSY_sum TCC_EA0_RDREQ_DRAM_sum
 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum
 GRBM_UTCL2_BUSY GRBM_TA_BUSY GRBM_GUI_ACTIVE
 G
+fi)
 cd "$ROOT"
 [ "$ok" -gt 0 ] || { echo "no pass produced counters"; exit 1; }
 python3 - "$out" <<'P'

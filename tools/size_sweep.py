@@ -70,6 +70,9 @@ def main():
         "scalar_mul_var_element": lambda n: ctx.scalar_mul_var_element(P[:n], k[:n], outs=[oE[:n]]),
         "to_affine": lambda n: ctx.to_affine(P[:n], outs=[oA[:n]]),
         "add": lambda n: ctx.add(P[:n], P[:n], outs=[oE[:n]]),
+        # n TERMS in n // m independent sums of m (d377_batch_msm_small): the rate is terms per second
+        "msm_small (3 terms)": lambda n: ctx.msm_small(P[:3 * (n // 3)], k[:3 * (n // 3)], 3, outs=[o32[:n // 3]]),
+        "msm_small (8 terms)": lambda n: ctx.msm_small(P[:8 * (n // 8)], k[:8 * (n // 8)], 8, outs=[o32[:n // 8]]),
         "msm (Elements)": lambda n: ctx.msm(P[:n], k[:n]),
         "msm (Encodings)": lambda n: ctx.msm(enc[:n], k[:n]),
     }
