@@ -61,6 +61,9 @@ struct FixedTab {                        // every lane gathers its own record, r
   const uint32_t* base;
   gea_raw raw;
   __device__ __forceinline__ void request(int i, int j) {
+#ifdef D377_FB_DIAG_HOT                  // diagnostic build: every gather falls into 16 entries per window (cache-resident): the kernel without its HBM gathers
+    j &= 15;
+#endif
     raw = pt_load_affine_raw(base + ((size_t)i * FbShape<BITS>::entries + j) * FBW_ENTRY_WORDS);
   }
   __device__ __forceinline__ gea take(bool swap) const { return gea_from_raw(raw, swap); }
@@ -525,7 +528,12 @@ __global__ void __launch_bounds__(BLOCK, FB_SETS) k_scalar_mul_base(SqrtTables T
   FixedTab<BITS> ft{fbase, {}};
 #endif
   uint32_t kc[8] = {};                     // the current scalar, reduced and halved; its first entry is on its way
-  dcb_rounds<0, true, true, true, D377_FB_AHEAD != 0>(n, io, pt,
+#ifdef D377_FB_DIAG_NOFINISH             // diagnostic build: no compressor (the outputs are not encodings)
+  constexpr bool FB_FINISH = false;
+#else
+  constexpr bool FB_FINISH = true;
+#endif
+  dcb_rounds<0, FB_FINISH, true, true, D377_FB_AHEAD != 0>(n, io, pt,
     [&](size_t, int) {},
     [&](size_t i, int j, const uint32_t (*)[8], bool) {
       const bool live = i < n;           // a ragged last wave: its idle lanes redo the last scalar and store nothing
