@@ -1089,44 +1089,35 @@ D377_HD int fb_digit(const uint32_t k[8], int i, uint32_t& carry) {
   carry = (dd >= (1u << (BITS - 1))) ? 1u : 0u;        // k < r < 2^251: the top digit never carries out
   return (int)dd - (int)(carry << BITS);
 }
-// want_t: whether the caller reads T of the result.  FTab: request(i, j) asks for entry j of window i, take(swap) -> gea hands
-// over the entry requested last (swap: the record of -P, Y + X and Y - X exchanged).  The entry of window i + 1 is requested
-// before the addition of window i, right after window i's has been taken, so a table may keep ONE entry in flight in storage
-// of its own (d377.hip: FixedTabCoop's LDS tile, FixedTab's raw registers).
-// REQUESTED: the caller has requested window 0's entry already (fb_request_first: a kernel that walks several scalars asks for
-// the next scalar's first entry before it closes the current one, so that no scalar starts by waiting for a gather).
+// want_t: whether the caller reads T of the result.  The entry of window i + 1 is fetched before the addition of
+// window i: the table lives in L2 / Infinity Cache, and one mixed addition is only ~1 500 instructions.  (Two entries
+// in flight instead of one: 1.07-1.11e9/s against 1.09-1.12e9/s at 2^20 and 2^22, same box -- the gathers are covered.)
 template <int BITS = FB_BITS, class FTab>
-D377_HD void fb_request_first(const uint32_t k[8], FTab& ftab) {
-  uint32_t carry = 0;
-  const int d = fb_digit<BITS>(k, 0, carry);
-  ftab.request(0, d < 0 ? -d : d);
-}
-template <int BITS = FB_BITS, bool REQUESTED = false, class FTab>
-D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], FTab& ftab, bool want_t = true) {
+D377_HD ge ge_scalar_mul_base_w8(const uint32_t k[8], const FTab& ftab, bool want_t = true) {
   constexpr int W = FbShape<BITS>::windows;
   uint32_t carry = 0;
   int d = fb_digit<BITS>(k, 0, carry);
   bool neg = d < 0;
-  if (!REQUESTED) ftab.request(0, neg ? -d : d);
+  gea e = ftab.load(0, neg ? -d : d, neg);
   // window 0: the sum starts from the record itself (ge_from_cached_affine: 4 products) instead of a 7-product addition to
   // the identity -- 85 M + 3 S per scalar where the plain loop took 88 M + 3 S
   ge r;
   {
-    const gea cur = ftab.take(neg);
+    const gea cur = e;
     const bool neg_cur = neg;
     d = fb_digit<BITS>(k, 1, carry);
     neg = d < 0;
-    ftab.request(1, neg ? -d : d);
+    e = ftab.load(1, neg ? -d : d, neg);
     r = ge_from_cached_affine(cur, neg_cur);
   }
 #pragma unroll 1
   for (int i = 1; i < W; ++i) {
-    const gea cur = ftab.take(neg);
+    const gea cur = e;
     const bool neg_cur = neg;
     if (i + 1 < W) {
       d = fb_digit<BITS>(k, i + 1, carry);
       neg = d < 0;
-      ftab.request(i + 1, neg ? -d : d);
+      e = ftab.load(i + 1, neg ? -d : d, neg);
     }
     r = ge_add_affine(r, cur, neg_cur, want_t || i + 1 < W);
   }
@@ -1355,49 +1346,6 @@ D377_HD void dcb_finish_with(IO& io, int cnt, INV invert) {       // (cnt = 0: t
     const bool neg = fe_is_negative(fe_mul(fe_from_words(w), inv_j));     // sign of E / F (encoding.rs:104)
     io.get(neg ? 3 : 2, j, w);
     fe s = fe_canon(fe_mul(fe_from_words(w), inv_j));
-    s = fe_select((s.l[0] & 1u) != 0, fe_canon_negate(s), s);             // .abs(), encoding.rs:110
-    fe_to_words(s, w);
-    io.emit(j, w);
-  }
-}
-// The same with every record requested one element ahead of its use.  As written above an element's records are loaded where
-// they are used -- the prefix product's factor, then the parked prefix, p, w and, once the sign is known, one of n0 / n1: five
-// dependent trips to L2 per element, ~4 000 cycles a wave waits; next to the ~21 000 instructions of a fixed-base
-// multiplication that is a fifth of the kernel (SQ_WAIT_ANY 9 700 cycles per element and wave: profiles/r06_fb_translation.txt),
-// next to a square root's 57 000 a twentieth.  Here the walk holds the next element's records (both n0 and n1: the sign is
-// not known yet) while it multiplies the current one's: 40 registers, in a phase that holds no group element.
-template <class IO, class INV>
-D377_HD void dcb_finish_ahead_with(IO& io, int cnt, INV invert) {  // (cnt = 0: the lane only takes part in `invert`)
-  uint32_t w[8], wn[8] = {};
-  fe c = fe_const(FE_ONE);
-  if (cnt > 0) io.get(0, 0, wn);
-#pragma unroll 1
-  for (int j = 0; j < cnt; ++j) {                       // prefix products, parked in the output records
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = wn[k];
-    if (j + 1 < cnt) io.get(0, j + 1, wn);
-    uint32_t cw[8];
-    fe_to_words(c, cw);
-    io.park(j, cw);
-    c = fe_mul_strict(c, fe_from_words(w));
-  }
-  uint32_t pk[8] = {}, p0[8] = {}, p1[8] = {}, n0[8] = {}, n1[8] = {};
-  if (cnt > 0) {                                        // the last element's records travel while the lanes' product is inverted
-    io.parked(cnt - 1, pk); io.get(0, cnt - 1, p0); io.get(1, cnt - 1, p1); io.get(2, cnt - 1, n0); io.get(3, cnt - 1, n1);
-  }
-  fe inv = invert(c);
-#pragma unroll 1
-  for (int j = cnt - 1; j >= 0; --j) {
-    uint32_t a[8], b[8], e[8], f0[8], f1[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { a[k] = pk[k]; b[k] = p0[k]; e[k] = p1[k]; f0[k] = n0[k]; f1[k] = n1[k]; }
-    if (j > 0) { io.parked(j - 1, pk); io.get(0, j - 1, p0); io.get(1, j - 1, p1); io.get(2, j - 1, n0); io.get(3, j - 1, n1); }
-    const fe inv_j = fe_mul(inv, fe_from_words(a));     // 1 / p_j
-    inv = fe_mul(inv, fe_from_words(b));
-    const bool neg = fe_is_negative(fe_mul(fe_from_words(e), inv_j));     // sign of E / F (encoding.rs:104)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f0[k] = neg ? f1[k] : f0[k];
-    fe s = fe_canon(fe_mul(fe_from_words(f0), inv_j));
     s = fe_select((s.l[0] & 1u) != 0, fe_canon_negate(s), s);             // .abs(), encoding.rs:110
     fe_to_words(s, w);
     io.emit(j, w);

@@ -57,58 +57,12 @@ struct GlobalTab {
 // shared fixed-base comb FB[i][j] = affine cached j * 2^(FB_BITS i) * B, [FB_WINDOWS][FB_ENTRIES] 128-byte records
 // (device_util.hpp: pt_load_affine -- two sectors per gather; round 2's three 48-byte slots cost 3.25)
 template <int BITS>
-struct FixedTab {                        // every lane gathers its own record, raw words in registers until their turn
+struct FixedTab {
   const uint32_t* base;
-  gea_raw raw;
-  __device__ __forceinline__ void request(int i, int j) {
-#ifdef D377_FB_DIAG_HOT                  // diagnostic build: every gather falls into 16 entries per window (cache-resident): the kernel without its HBM gathers
-    j &= 15;
-#endif
-    raw = pt_load_affine_raw(base + ((size_t)i * FbShape<BITS>::entries + j) * FBW_ENTRY_WORDS);
-  }
-  __device__ __forceinline__ gea take(bool swap) const { return gea_from_raw(raw, swap); }
-};
-// The same gather done by the WAVE, through LDS.  A lane that loads its own 128-byte record issues seven 16-byte loads, each
-// of which has the 64 lanes in 64 different lines: the CU's texture cache looks up 64 tags per instruction and, from the
-// second instruction on, finds every one of them pending -- it stalls until the lines arrive, in order, with every other
-// wave's loads queued behind (TCP_PENDING_STALL_CYCLES: 43 % of the kernel's cycles per CU at 2^20 scalars, 448 tag lookups
-// per wave and gather; TCP -> L2 read latency 765 cycles; UTCL1 miss rate 0.023: profiles/r06_fb_translation.txt).  Here
-// instruction k fetches the records of lanes 8k .. 8k + 7 whole -- eight lanes per record, 16 bytes each: 8 lines per
-// instruction, every line touched by one instruction only -- as LDS-DMA (global_load_lds_dwordx4: no registers in flight)
-// into the wave's 8 KiB tile, and each lane then reads its record with seven ds_read_b128.  The DMA's LDS destination is
-// lane-linear, so the XOR swizzle that keeps those reads off each other's banks goes on the SOURCE chunk (chunk c of record
-// R lands at R * 8 + (c ^ (R & 7))).  All 64 lanes take part in every request (dcb_rounds' WAVE_UNIFORM walk).
-template <int BITS>
-struct FixedTabCoop {
-  const uint32_t* base;
-  uint4* tile;                           // this wave's 512 x 16 bytes
-  int lane;
-  __device__ __forceinline__ void request(int i, int j) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of the entry taken last are done with the tile
-    const uint32_t* win = base + (size_t)i * FbShape<BITS>::entries * FBW_ENTRY_WORDS;
-    const int sub = lane >> 3, c = (lane & 7) ^ sub;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int jr = __shfl(j, 8 * k + sub);
-      const uint32_t* src = win + (size_t)jr * FBW_ENTRY_WORDS + c * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(tile + k * 64), 16, 0, 0);
-    }
-  }
-  __device__ __forceinline__ gea take(bool swap) const {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    gea_raw r;
-#pragma unroll
-    for (int q = 0; q < 7; ++q) r.v[q] = tile[lane * 8 + (q ^ (lane & 7))];
-    return gea_from_raw(r, swap);
+  __device__ __forceinline__ gea load(int i, int j, bool swap) const {
+    return pt_load_affine(base + ((size_t)i * FbShape<BITS>::entries + j) * FBW_ENTRY_WORDS, swap);
   }
 };
-#ifndef D377_FB_COOP
-#define D377_FB_COOP 1                  // 0: A/B -- every lane gathers its own records (rounds 2-5)
-#endif
-#ifndef D377_FB_AHEAD
-#define D377_FB_AHEAD 1                 // 0: A/B -- a scalar requests its own first entry, the compressor loads where it uses (rounds 2-5)
-#endif
 
 // ------------------------------------------------------------------------- init kernels ---
 __device__ fe fe_pow_u32(const fe& x, uint32_t e) {   // e >= 1
@@ -515,51 +469,17 @@ __global__ void __launch_bounds__(BLOCK, FB_SETS) k_scalar_mul_base(SqrtTables T
                                                            const uint8_t* scalar32, size_t n, uint8_t* out32, DcbScratch dcb) {
   D377_POW_LDS();                        // unused here (no square root): residency is capped by the launch's LDS padding
   D377_DCB_BEGIN(out32);
-  // A scalar's first comb entry is requested by the scalar BEFORE it (fb_request_first), ahead of that one's compressor state,
-  // and its bytes are loaded a whole multiplication ahead: as written in rounds 2-5 every scalar began with two trips to HBM one
-  // after the other -- its bytes, then, once the first digit was known, its first entry -- ~4 000 cycles a wave waited, next to
-  // the compressor's ~4 000 (dcb_finish_ahead_with): SQ_WAIT_ANY / SQ_WAVE_CYCLES 0.22, 18 % of the issue slots empty.  Index i
-  // of the walk's element j + 1 is i + BLOCK; past the batch (a chunk's last element, a ragged wave's idle lanes) the last
-  // scalar stands in and what was requested for it is simply never taken.
-#if D377_FB_COOP
-  __shared__ uint4 fb_tile[BLOCK / 64][512];
-  FixedTabCoop<BITS> ft{fbase, fb_tile[threadIdx.x >> 6], (int)(threadIdx.x & 63)};
-#else
-  FixedTab<BITS> ft{fbase, {}};
-#endif
-  uint32_t kc[8] = {};                     // the current scalar, reduced and halved; its first entry is on its way
-#ifdef D377_FB_DIAG_NOFINISH             // diagnostic build: no compressor (the outputs are not encodings)
-  constexpr bool FB_FINISH = false;
-#else
-  constexpr bool FB_FINISH = true;
-#endif
-  dcb_rounds<0, FB_FINISH, true, true, D377_FB_AHEAD != 0>(n, io, pt,
+  FixedTab<BITS> ft{fbase};
+  dcb_rounds<0, true>(n, io, pt,
     [&](size_t, int) {},
     [&](size_t i, int j, const uint32_t (*)[8], bool) {
-      const bool live = i < n;           // a ragged last wave: its idle lanes redo the last scalar and store nothing
-#if D377_FB_AHEAD
-      if (j == 0) {                      // a chunk's first scalar has nobody before it
-        load32(scalar32, live ? i : n - 1, kc);
-        fr_reduce_words(kc);
-        fr_half_words(kc);
-        fb_request_first<BITS>(kc, ft);
-      }
-      uint32_t kn[8];
-      load32(scalar32, i + BLOCK < n ? i + BLOCK : n - 1, kn);
-      const ge r = ge_scalar_mul_base_w8<BITS, true>(kc, ft, DCB_WANT_T);
-      fr_reduce_words(kn);
-      fr_half_words(kn);
-      fb_request_first<BITS>(kn, ft);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) kc[q] = kn[q];
-#else
-      load32(scalar32, live ? i : n - 1, kc);
-      fr_reduce_words(kc);
-      fr_half_words(kc);
-      const ge r = ge_scalar_mul_base_w8<BITS>(kc, ft, DCB_WANT_T);
-#endif
-      D377_INVARIANT(T, r, live);
-      if (live) dcb_put(io, j, ge_dcb_from_half(r, false));
+      uint32_t k[8];
+      load32(scalar32, i, k);
+      fr_reduce_words(k);
+      fr_half_words(k);
+      const ge r = ge_scalar_mul_base_w8<BITS>(k, ft, DCB_WANT_T);
+      D377_INVARIANT(T, r, true);
+      dcb_put(io, j, ge_dcb_from_half(r, false));
     });
   D377_DCB_END();
 }
@@ -1051,7 +971,7 @@ __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_var_el(con
 template <int BITS>
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD) k_scalar_mul_base_el(const uint32_t* fbase, const uint8_t* scalar32, size_t n,
                                                                               uint64_t* out) {
-  FixedTab<BITS> ft{fbase, {}};
+  FixedTab<BITS> ft{fbase};
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t k[8];
     load32(scalar32, i, k);
@@ -1458,37 +1378,37 @@ int with_fb_bits(int bits, F&& f) {
   return fail(D377_ERR_ARG, "%s", "comb width: 18, 21 or 23 bits (or 0 for the library's default)");
 }
 
-// residency of the fixed-base kernel of the context's comb width: its wide launch (FB_SETS lane sets per CU) and its narrow one.
-// The kernel holds a static LDS tile (FixedTabCoop: 32 KiB per workgroup), so the padding that caps a launch at `sets`
-// workgroups per CU is what is missing to 160 KiB / (sets + 1) + 1 KiB per workgroup -- and the launch must then really hold
-// `sets` of them (or as many as its registers allow): a pad that left one workgroup per CU would halve the kernel silently.
+// residency of the fixed-base kernel of the context's comb width: its wide launch (FB_SETS lane sets per CU) and its narrow one
 int check_residency_fb(DeviceState& d, const void* fn) {
   const bool verbose = getenv("D377_DEBUG_RESIDENCY") != nullptr;
-  hipFuncAttributes attr;
-  HIP_TRY(hipFuncGetAttributes(&attr, fn));
-  const int stat = (int)attr.sharedSizeBytes;
-  int by_regs = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_regs, fn, BLOCK, 0));
-  auto settle = [&](int sets, int* pad_out, int* nb_out, const char* what) -> int {
-    int pad = 0, nb = by_regs;
+  {
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, 0));
+    d.chunk_lds[CK_MUL_BASE] = 0;
+    const int sets = d.chunk_sets[CK_MUL_BASE];
+    const int pad = (160 * 1024) / (sets + 1) + 1024;
     if (nb > sets) {
-      pad = (160 * 1024) / (sets + 1) + 1024 - stat;
-      if (pad < 0) pad = 0;
-      if (pad + stat > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+      if (pad > 64 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+      d.chunk_lds[CK_MUL_BASE] = pad;
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, (size_t)pad));
     }
-    if (verbose) fprintf(stderr, "d377: k_scalar_mul_base<%d>, %s launch: %d workgroups per CU (%d by registers and its %d bytes of static LDS) with %d bytes of LDS padding\n",
-                         d.fb_bits, what, nb, by_regs, stat, pad);
-    const int want = by_regs < sets ? by_regs : sets;
-    if (nb < 1 || nb != want)
-      return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", what);
-    *pad_out = pad; *nb_out = nb;
-    return D377_OK;
-  };
-  int rc;
-  if ((rc = settle(d.chunk_sets[CK_MUL_BASE], &d.chunk_lds[CK_MUL_BASE], &d.chunk_blocks[CK_MUL_BASE], "k_scalar_mul_base (wide)"))) return rc;
-  int nb_narrow = 0;
-  if ((rc = settle(WAVES_PER_SIMD, &d.fb_narrow_lds, &nb_narrow, "k_scalar_mul_base (narrow)"))) return rc;
+    if (verbose) fprintf(stderr, "d377: k_scalar_mul_base<%d>: %d workgroups per CU with %d bytes of LDS padding\n", d.fb_bits, nb, d.chunk_lds[CK_MUL_BASE]);
+    d.chunk_blocks[CK_MUL_BASE] = nb;
+    if (nb < 1 || nb > sets)
+      return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", "k_scalar_mul_base");
+  }
+  // the narrow launch (WAVES_PER_SIMD workgroups per CU, up to FB_WIDE_GENERATIONS generation of full chunks): its own padding
+  {
+    const int pad = (160 * 1024) / (WAVES_PER_SIMD + 1) + 1024;
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, (size_t)pad));
+    if (verbose) fprintf(stderr, "d377: k_scalar_mul_base<%d>, narrow launch: %d workgroups per CU with %d bytes of LDS padding\n", d.fb_bits, nb, pad);
+    if (nb < 1 || nb > WAVES_PER_SIMD)
+      return fail(D377_ERR_INIT, "residency of %s does not match the lane sets of the scratch areas", "k_scalar_mul_base (narrow launch)");
+    d.fb_narrow_lds = pad;
+    if (pad > d.chunk_lds[CK_MUL_BASE] && pad > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pad));
+  }
   return D377_OK;
 }
 

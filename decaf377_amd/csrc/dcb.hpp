@@ -180,12 +180,7 @@ __device__ __forceinline__ void dcb_progress_priority_steps(int done, int total,
 }
 // post(io, cnt): runs after a chunk's outputs have been written (a kernel's rare fix-ups: k_hash_to_curve).
 struct DcbNoPost { __device__ __forceinline__ void operator()(DcbIO&, int) const {} };
-// WAVE_UNIFORM: every lane of a wave walks as many elements as the wave's first lane (which has the most: a chunk's rounds
-// end lane by lane), so that a kernel may do wave-wide work inside phase1 (k_scalar_mul_base gathers its comb entries
-// cooperatively); phase1 then sees element indices >= n in a batch's last, ragged wave: it loads from a clamped index and
-// must not store for them.  The compressor still closes the lane's own `cnt` elements.
-// FINISH_AHEAD: the compressor requests every record one element ahead of its use (curve.hpp: dcb_finish_ahead_with).
-template <int NINV, bool FINISH, bool SMALL_OK = true, bool WAVE_UNIFORM = false, bool FINISH_AHEAD = false, class PT, class P0, class P1, class PF = DcbNoPost>
+template <int NINV, bool FINISH, bool SMALL_OK = true, class PT, class P0, class P1, class PF = DcbNoPost>
 __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase0, P1 phase1, PF post = PF()) {
   constexpr int NW = NINV > 0 ? NINV : 1;
   // chunk c covers the elements from BLOCK x (c x per_lane + min(c, extra)): the first `extra` chunks are one round longer
@@ -230,10 +225,8 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
 #endif
       }
     }
-    int walk = cnt;
-    if constexpr (WAVE_UNIFORM) walk = __shfl(cnt, 0);   // lane 0 of this wave (width 64): its count is the wave's largest
 #pragma unroll 1
-    for (int j = 0; j < walk; ++j) {
+    for (int j = 0; j < cnt; ++j) {
       dcb_progress_priority(io.prio, j, per_lane);
       uint32_t cur[NW][8] = {};
       if (assist) {
@@ -245,8 +238,7 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
 #if defined(D377_DCB_LANE_INVERSIONS)
     if (FINISH) dcb_finish(pt, io, cnt);
 #else
-    if constexpr (FINISH && FINISH_AHEAD) dcb_finish_ahead_with(io, cnt, [](const fe& c) { return row::fe_invert_lanes(c); });
-    else if (FINISH) dcb_finish_with(io, cnt, [](const fe& c) { return row::fe_invert_lanes(c); });
+    if (FINISH) dcb_finish_with(io, cnt, [](const fe& c) { return row::fe_invert_lanes(c); });
 #endif
     post(io, cnt);
   }

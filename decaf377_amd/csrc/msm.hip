@@ -689,108 +689,6 @@ __device__ __forceinline__ void span_partials_of(const SpanPlan& sp, int w, int 
 // the next record in flight while the current one is added, one partial sum stored per bucket the span touches.  A lane's
 // first point is lifted from its record (4 products); after a bucket boundary inside the span the sum restarts from the
 // identity with a full addition -- a branch there would have every wave that holds such a lane walk both paths.
-#ifndef D377_SPANS_COOP
-#define D377_SPANS_COOP 1               // 0: A/B -- every lane gathers its own records, raw words in registers (round 5)
-#endif
-#if D377_SPANS_COOP
-// The records are gathered by the WAVE through LDS, as the fixed-base kernel gathers its comb entries (d377.hip: FixedTabCoop;
-// profiles/r06_fb_translation.txt): a lane that loads its own 128-byte record issues seven loads that each put 64 lanes in 64
-// lines, and from the second one on the CU's texture cache finds those lines pending and waits, in order.  Here instruction k
-// of a request fetches the records of lanes 8k .. 8k + 7 whole (eight lanes per record, LDS-DMA into the wave's 8 KiB tile,
-// the bank swizzle on the source chunk) and every lane reads its record back with seven ds_read_b128.  Every lane of a wave
-// takes part in every request, so the walk is UNIFORM: L steps for everybody (L is the launch's), a lane whose span is
-// shorter -- a window's last lane -- or that has no span at all -- past the last lane -- keeps requesting a clamped entry,
-// keeps adding into a sum nobody reads, and stores nothing.
-struct SpanTile {
-  const uint32_t* pts;
-  uint4* tile;                           // this wave's 512 x 16 bytes
-  int lane;
-  __device__ __forceinline__ void request(uint32_t rec) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of the record taken last are done with the tile
-    const int sub = lane >> 3, c = (lane & 7) ^ sub;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t rr = (uint32_t)__shfl((int)rec, 8 * k + sub);
-      const uint32_t* src = pts + (size_t)rr * AP_WORDS + c * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(tile + k * 64), 16, 0, 0);
-    }
-  }
-  __device__ __forceinline__ gea take(bool swap) const {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    gea_raw r;
-#pragma unroll
-    for (int q = 0; q < 7; ++q) r.v[q] = tile[lane * 8 + (q ^ (lane & 7))];
-    return gea_from_raw(r, swap);
-  }
-};
-__global__ void __launch_bounds__(BLOCK, SEG_BLOCKS_PER_CU)
-k_msm_spans(const uint32_t* pts, const uint32_t* idx, SpanPlan sp, const uint32_t* meta, size_t n, int W, int nb, uint32_t* partial) {
-  __shared__ uint4 span_tiles[BLOCK / 64][512];
-  const int len = nb + 1;
-  const uint32_t L = meta[0], lanes = meta[2];
-  SpanTile st{pts, span_tiles[threadIdx.x >> 6], (int)(threadIdx.x & 63)};
-  if (lanes == 0) return;
-  for (size_t g0 = (size_t)blockIdx.x * BLOCK + (threadIdx.x & ~63u); g0 < lanes; g0 += (size_t)gridDim.x * BLOCK) {   // uniform per wave
-    const size_t gi_raw = g0 + (size_t)st.lane;
-    bool done = gi_raw >= lanes;                         // no span: a lane past the last one walks the last span and stores nothing
-    const size_t gi = done ? (size_t)lanes - 1 : gi_raw;
-    int w = 0;
-    while (w + 1 < W && sp.winfo[w + 1].lane0 <= gi) ++w;
-    const WinInfo wi = sp.winfo[w];
-    const uint32_t pos = (uint32_t)(gi - wi.lane0) * L;
-    uint32_t end = pos + L;
-    if (end > wi.len) end = wi.len;                      // (pos < end: a window has ceil(len / L) lanes)
-    const uint32_t* ow = sp.offs + (size_t)w * len;
-    int lo_b = 0, hi_b = nb;                             // the bucket that holds entry pos: the largest b with ow[b] <= pos
-    while (hi_b - lo_b > 1) {
-      const int mid = (lo_b + hi_b) >> 1;
-      if (ow[mid] <= pos) lo_b = mid; else hi_b = mid;
-    }
-    int b = lo_b;
-    size_t slot = (size_t)gi + wi.ne0 + sp.ne[(size_t)w * len + b];
-    uint32_t bend = ow[b + 1];
-    const uint32_t* iw = idx + (size_t)w * n;
-    // one record ahead: at the top of a step the tile holds entry j (requested a whole addition ago); it is taken, the tile is
-    // refilled with entry j + 1 -- whose index was fetched an addition earlier -- and the index of entry j + 2 is fetched
-    uint32_t e_cur = iw[pos];
-    uint32_t e_nxt = iw[pos + 1 < end ? pos + 1 : end - 1];
-    st.request(e_cur & 0x7FFFFFFFu);
-    uint32_t j = pos;                                    // entries [pos, j) are in acc (or flushed); the tile holds entry j
-    const int last = (int)(L / 32) > 0 ? (int)(L / 32) : 1;
-    dcb_progress_priority_steps(0, (int)L, last);        // (dcb.hpp: the wave that is behind outranks the ones ahead)
-    ge acc = ge_identity();
-#pragma unroll 1
-    for (uint32_t step = 0; step < L; ++step) {          // uniform over the launch
-      if (!done && step != 0 && (j == bend || j == end)) {   // the bucket, or the span, ends here
-        pt_store_ext(partial + slot * PT_WORDS, acc);
-        if (j == end) {
-          done = true;
-        } else {
-          ++b;
-          while (ow[b + 1] <= j) ++b;                    // empty buckets in between (j < end <= ow[nb]: this stops)
-          bend = ow[b + 1];
-          ++slot;
-          acc = ge_identity();
-        }
-      }
-      const bool neg = (e_cur >> 31) != 0;
-      gea cur = st.take(neg);
-      gea_pin(cur);
-      e_cur = e_nxt;
-      st.request(e_nxt & 0x7FFFFFFFu);
-      e_nxt = iw[j + 2 < end ? j + 2 : end - 1];         // (clamped to the span: a finished lane re-reads its last entry)
-      asm volatile("" ::: "memory");                     // ... and no load sinks below this line, to its first use after the addition
-      if (step == 0) acc = ge_from_cached_affine(cur, neg);   // the lane's first entry is lifted from its record (4 products)
-      else acc = ge_add_affine(acc, cur, neg, true);
-      if (j < end) ++j;
-      dcb_progress_priority_steps((int)step + 1, (int)L, last);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the request of the last step (nobody takes it) has landed before the tile is reused
-    if (!done) pt_store_ext(partial + slot * PT_WORDS, acc);      // a full span ends with the walk (j == end)
-  }
-}
-#else
 __global__ void __launch_bounds__(BLOCK, SEG_BLOCKS_PER_CU)
 k_msm_spans(const uint32_t* pts, const uint32_t* idx, SpanPlan sp, const uint32_t* meta, size_t n, int W, int nb, uint32_t* partial) {
   const int len = nb + 1;
@@ -870,8 +768,6 @@ k_msm_spans(const uint32_t* pts, const uint32_t* idx, SpanPlan sp, const uint32_
     }
   }
 }
-
-#endif
 
 // A further level of the same reduction: one lane per group of <= `red` partial sums of one bucket (so_out: prefix of the
 // groups; the inputs of level 0 are the span partials, found by the closed form, those of later levels lie packed by

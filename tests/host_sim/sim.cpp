@@ -32,9 +32,6 @@ struct HostTab {
 };
 struct HostFTab {
   const uint32_t* p;
-  int ri = 0, rj = 0;
-  void request(int i, int j) { ri = i; rj = j; }
-  gea take(bool swap) const { return load(ri, rj, swap); }
   gea load(int i, int j, bool swap) const {
     gea g; const uint32_t* q = p + ((size_t)i * FB_ENTRIES + j) * 27;
     for (int k = 0; k < 9; ++k) { g.ypx.l[k] = q[(swap ? 9 : 0) + k]; g.ymx.l[k] = q[(swap ? 0 : 9) + k]; g.kt.l[k] = q[18 + k]; }
