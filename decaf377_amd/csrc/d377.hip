@@ -2250,7 +2250,7 @@ static bool tuning_range(int key, long long* lo, long long* hi) {
     case D377_TUNE_FB_WIDE: case D377_TUNE_MSM_CHUNKED_SUMS: case D377_TUNE_MSM_SORT_PACKED: *lo = 0; *hi = 1; return true;
     case D377_TUNE_FB_K: *lo = 1; *hi = DCB_KMAX; return true;
     case D377_TUNE_AFFINE_BLOCKS_PER_CU: *lo = 1; *hi = 64; return true;
-    case D377_TUNE_MSM_WINDOW: *lo = 4; *hi = 16; return true;
+    case D377_TUNE_MSM_WINDOW: *lo = 4; *hi = 18; return true;
     case D377_TUNE_MSM_SEG: *lo = 1; *hi = 128; return true;
     case D377_TUNE_MSM_SLICES: *lo = 1; *hi = 4096; return true;
     case D377_TUNE_MSM_RED: *lo = 2; *hi = 64; return true;

@@ -33,6 +33,7 @@
 #include <chrono>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/decaf377_amd.h"
@@ -79,7 +80,10 @@ using row::rq_store_point;
 using row::rq_store_cached;
 using row::rq_load_point;
 
-__device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t i, size_t n, const WinShape& ws, bool skip, int16_t* digits) {
+// Digits travel as int16 up to 16-bit windows (|digit| <= 2^15: 2 bytes per point and window through the sort) and as int32 for
+// the 17- and 18-bit windows of the largest batches (DT).
+template <class DT>
+__device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t i, size_t n, const WinShape& ws, bool skip, DT* digits) {
   uint32_t k[8];
   load32(scalar32, i, k);
   fr_reduce_words(k);
@@ -89,14 +93,15 @@ __device__ __forceinline__ void msm_write_digits(const uint8_t* scalar32, size_t
   for (int w = 0; w < ws.W; ++w) {
     int d = msm_digit(k, w, ws, carry);
     if (skip) d = 0;                                    // invalid points contribute nothing
-    digits[(size_t)w * n + i] = (int16_t)d;
+    digits[(size_t)w * n + i] = (DT)d;
   }
 }
 
 // Encodings: one lane per point; decompression leaves Z = 1, so the affine record costs nothing extra.
+template <class DT>
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, WinShape ws,
-                  uint32_t* pts, int16_t* digits, uint8_t* status) {
+                  uint32_t* pts, DT* digits, uint8_t* status) {
   D377_POW_LDS();
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
     uint32_t w[8];
@@ -114,9 +119,10 @@ k_msm_prepare_enc(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, s
 // k_decompress_chunked decode their points): 5-8 % fewer cycles per decompression; msm_launch uses it from DCB_ASSIST_MIN
 // points per resident lane, like d377_batch_decompress (393 216 points on 256 CUs: the call -0.7 % there, -2 % at 2^20, -4 % at
 // 2^22; profiles/r05_decompress_route_sweep.txt).
+template <class DT>
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* scalar32, size_t n, WinShape ws,
-                          uint32_t* pts, int16_t* digits, uint8_t* status, DcbScratch dcb) {
+                          uint32_t* pts, DT* digits, uint8_t* status, DcbScratch dcb) {
   D377_POW_LDS();
   D377_DCB_BEGIN(status);
   dcb_rounds<1, false, false>(n, io, pt,
@@ -149,8 +155,9 @@ k_msm_prepare_enc_chunked(SqrtTables T, const uint8_t* enc32, const uint8_t* sca
 // 128-byte Element and stores its own 128-byte affine record issues 6 + 8 instructions that each touch 64 lines and use an
 // eighth of them; a wave moves its 64 records as eight coalesced 1 KiB instructions each way instead (HBM-priced kernel: 320
 // bytes per point).
+template <class DT>
 __global__ void __launch_bounds__(BLOCK, 4)
-k_msm_prepare_affine(SqrtTables T, const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinShape ws, uint32_t* pts, int16_t* digits,
+k_msm_prepare_affine(SqrtTables T, const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinShape ws, uint32_t* pts, DT* digits,
                      uint32_t* flag) {
   (void)T;
   D377_RECORD_TILES(rec0) {
@@ -193,8 +200,9 @@ k_msm_prepare_affine(SqrtTables T, const uint64_t* xyzt, const uint8_t* scalar32
 // lane's grid-stride elements up, parking each prefix product in the element's own record slot; one inversion;
 // the backward pass peels 1/z_i off, writes the affine record and the digits.  A record with z = 0 is no group
 // element: it becomes the identity with digits 0.
+template <class DT>
 __global__ void __launch_bounds__(BLOCK, 4)
-k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinShape ws, uint32_t* pts, int16_t* digits,
+k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinShape ws, uint32_t* pts, DT* digits,
                  const uint32_t* flag) {
   if (*flag == 0) return;
   const size_t Tn = (size_t)gridDim.x * BLOCK, t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -241,43 +249,50 @@ k_msm_prepare_el(const uint64_t* xyzt, const uint8_t* scalar32, size_t n, WinSha
 // histogram of returning global atomics (one per point and window, each its own L2 round trip) and the
 // scattered rank reads cost 5.7 ms of a 12.6 ms MSM at 2^22.
 constexpr int SORT_THREADS = 1024;
-// slice s of window w covers points [s * per, min(n, (s + 1) * per))
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const int16_t* digits, size_t n, int nb, int S, size_t per,
+// slice s of window w covers points [s * per, min(n, (s + 1) * per)).  Windows wider than 16 bits have more buckets than LDS
+// holds counters for (2^17 + 1 at 18 bits: 512 KiB): the bucket range is then cut into R parts of nbr buckets and workgroup
+// (window, slice, part) counts the digits that fall into its part -- the digits are read R times (R = 2 at 17 bits, 4 at 18).
+template <class DT>
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_count(const DT* digits, size_t n, int nb, int S, size_t per, int R, int nbr,
                                                             uint32_t* blockhist) {
   extern __shared__ uint32_t h[];
-  const int w = blockIdx.x / S, sl = blockIdx.x % S;
-  for (int j = threadIdx.x; j < nb; j += SORT_THREADS) h[j] = 0;
+  constexpr int PER_VEC = 16 / (int)sizeof(DT);                  // digits per 16-byte load
+  const int ws_ = blockIdx.x / R, part = blockIdx.x % R;
+  const int w = ws_ / S, sl = ws_ % S;
+  const int b_lo = part * nbr, b_hi = b_lo + nbr < nb ? b_lo + nbr : nb;
+  for (int j = threadIdx.x; j < b_hi - b_lo; j += SORT_THREADS) h[j] = 0;
   __syncthreads();
   const size_t lo = (size_t)sl * per, hi = (lo + per < n) ? lo + per : n;
-  const int16_t* dw = digits + (size_t)w * n;
-  // eight digits per 16-byte load where the row allows it (one 2-byte load per lane and trip left the kernel waiting on
+  const DT* dw = digits + (size_t)w * n;
+  auto tally = [&](int d) {
+    const int b = d < 0 ? -d : d;
+    if (d != 0 && b >= b_lo && b < b_hi) atomicAdd(&h[b - b_lo], 1u);
+  };
+  // a 16-byte load of digits per lane where the row allows it (one 2-byte load per lane and trip left the kernel waiting on
   // memory latency: 1 TB/s); the unaligned head and the tail go one by one
   const size_t a0 = ((reinterpret_cast<uintptr_t>(dw + lo) + 15) & ~(uintptr_t)15) - reinterpret_cast<uintptr_t>(dw + lo);
-  size_t head = lo + a0 / 2;
+  size_t head = lo + a0 / sizeof(DT);
   if (head > hi) head = hi;
-  const size_t nvec = (hi - head) / 8;
-  for (size_t i = lo + threadIdx.x; i < head; i += SORT_THREADS) {
-    const int d = dw[i];
-    if (d != 0) atomicAdd(&h[d < 0 ? -d : d], 1u);
-  }
+  const size_t nvec = (hi - head) / PER_VEC;
+  for (size_t i = lo + threadIdx.x; i < head; i += SORT_THREADS) tally((int)dw[i]);
   const uint4* dv = reinterpret_cast<const uint4*>(dw + head);
   for (size_t v = threadIdx.x; v < nvec; v += SORT_THREADS) {
     const uint4 q = dv[v];
-    const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+    const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int d0 = (int16_t)(ws[k] & 0xFFFFu), d1 = (int16_t)(ws[k] >> 16);
-      if (d0 != 0) atomicAdd(&h[d0 < 0 ? -d0 : d0], 1u);
-      if (d1 != 0) atomicAdd(&h[d1 < 0 ? -d1 : d1], 1u);
+      if (sizeof(DT) == 2) {
+        tally((int)(int16_t)(wq[k] & 0xFFFFu));
+        tally((int)(int16_t)(wq[k] >> 16));
+      } else {
+        tally((int)wq[k]);
+      }
     }
   }
-  for (size_t i = head + nvec * 8 + threadIdx.x; i < hi; i += SORT_THREADS) {
-    const int d = dw[i];
-    if (d != 0) atomicAdd(&h[d < 0 ? -d : d], 1u);
-  }
+  for (size_t i = head + nvec * PER_VEC + threadIdx.x; i < hi; i += SORT_THREADS) tally((int)dw[i]);
   __syncthreads();
-  uint32_t* out = blockhist + (size_t)blockIdx.x * nb;
-  for (int j = threadIdx.x; j < nb; j += SORT_THREADS) out[j] = h[j];
+  uint32_t* out = blockhist + (size_t)ws_ * nb + b_lo;
+  for (int j = threadIdx.x; j < b_hi - b_lo; j += SORT_THREADS) out[j] = h[j];
 }
 
 // Prefix sums of the sort and the plan of the bucket sums, three small kernels over workgroups (window, 1024 buckets).
@@ -444,7 +459,8 @@ __global__ void __launch_bounds__(1024) k_msm_scan3(const uint32_t* offs, uint32
 // 64 different lines costs the address coalescer 64 cycles, and three of those per entry were what was left of the
 // sort (1.36 ms at 2^22) once the lines stayed in cache.
 constexpr int SUPER_BITS = 7, SUPER = 1 << SUPER_BITS;
-constexpr int MAX_SUPER = ((1 << 15) + 1 + SUPER - 1) / SUPER;         // c <= 16
+constexpr int MSM_MAX_WINDOW = 18;                                     // widest window: digits as int32 beyond 16 bits
+constexpr int MAX_SUPER = ((1 << (MSM_MAX_WINDOW - 1)) + 1 + SUPER - 1) / SUPER;   // 1 025 super-buckets at 18 bits
 constexpr int MAX_BINS = MAX_SUPER > SUPER ? MAX_SUPER : SUPER;
 constexpr int TILE_PER_THREAD = 8, TILE = SORT_THREADS * TILE_PER_THREAD;
 struct TileLds {
@@ -575,11 +591,13 @@ __device__ __forceinline__ void tile_scatter(TileLds& L, size_t lo, size_t hi, i
 // super-bucket, 24 bits of point index -- instead of a word and a byte in two arrays (the byte stores came in runs of a few
 // dozen bytes: 5 bytes written and 5 read per entry became 4 and 4).
 constexpr size_t PACKED_MAX_POINTS = (size_t)1 << 24;
-template <bool PACKED>
-__global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const int16_t* digits, size_t n, int nb, int S, size_t per,
+// (TileLds is 73 KiB with bins for 18-bit windows: beyond the 64 KiB of static LDS, so both levels take it as dynamic LDS)
+template <bool PACKED, class DT>
+__global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const DT* digits, size_t n, int nb, int S, size_t per,
                                                              const uint32_t* blockhist, const uint32_t* offs,
                                                              uint32_t* tmp_idx, uint8_t* tmp_sub) {
-  __shared__ TileLds L;
+  extern __shared__ uint8_t tile_lds_[];
+  TileLds& L = *reinterpret_cast<TileLds*>(tile_lds_);
   const int w = blockIdx.x / S, sl = blockIdx.x % S;
   const int nsuper = (nb + SUPER - 1) >> SUPER_BITS;
   const uint32_t* before_me = blockhist + (size_t)blockIdx.x * nb;      // points of earlier slices, per bucket
@@ -593,11 +611,11 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const int16_t* digi
   }
   __syncthreads();
   const size_t lo = (size_t)sl * per, hi = (lo + per < n) ? lo + per : n;
-  const int16_t* dw = digits + (size_t)w * n;
+  const DT* dw = digits + (size_t)w * n;
   tile_scatter<!PACKED, true>(L, lo, hi, nsuper,
-                     [dw](size_t i) { return (uint64_t)(uint16_t)dw[i]; },
+                     [dw](size_t i) { return (uint64_t)(uint32_t)(int32_t)dw[i]; },
                      [](uint64_t raw, size_t i, uint32_t* pay, int* bin, uint32_t* sub) {
-                       const int d = (int16_t)(uint16_t)raw;
+                       const int d = (int32_t)(uint32_t)raw;
                        if (d == 0) return false;
                        const int b = d < 0 ? -d : d;
                        *pay = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
@@ -613,7 +631,8 @@ __global__ void __launch_bounds__(SORT_THREADS) k_msm_place1(const int16_t* digi
 template <bool PACKED>
 __global__ void __launch_bounds__(SORT_THREADS) k_msm_place2(const uint32_t* tmp_idx, const uint8_t* tmp_sub, size_t n, int nb,
                                                              const uint32_t* offs, uint32_t* idx) {
-  __shared__ TileLds L;
+  extern __shared__ uint8_t tile_lds_[];
+  TileLds& L = *reinterpret_cast<TileLds*>(tile_lds_);
   const int nsuper = (nb + SUPER - 1) >> SUPER_BITS;
   const int w = blockIdx.x / nsuper, B = blockIdx.x % nsuper;
   const uint32_t* ow = offs + (size_t)w * (nb + 1);
@@ -905,7 +924,7 @@ k_msm_chunks(const uint32_t* buckets, int W, int nb, int nchunks, uint32_t* chun
     const uint32_t s = (uint32_t)(lo - 1);
     ge r = ge_identity();
 #pragma unroll 1
-    for (int bit = 15; bit >= 0; --bit) {
+    for (int bit = MSM_MAX_WINDOW - 1; bit >= 0; --bit) {   // s < 2^(c-1) + 1
       r = ge_double(r);
       if ((s >> bit) & 1u) r = ge_add(r, run);
     }
@@ -1154,13 +1173,48 @@ inline int wsb_cap1(int depth, int m) {
   const int rec = ((depth + 1) * RQ_WORDS + LP_WORDS - 1) / LP_WORDS;       // the Horner chain's records, in points
   return pts > rec ? pts : rec;
 }
+// The levels between the block nodes and k_msm_wsum_window for trees deeper than 16 (windows of 17 and 18 bits: 2^16 or 2^17
+// leaves, 128 or 256 block nodes per window -- k_msm_wsum_window's first merged level alone would be 200 KB of LDS): workgroup
+// (window, group) merges 2^(m_out - m_in) consecutive block nodes of depth m_in into one node of depth m_out (m_out + 1
+// points), first level from global memory, the rest in LDS.
+constexpr int WSM_THREADS = 256;
+constexpr int MID_STRIDE = 16;                   // points per node of the middle level (depth <= 15)
+constexpr int WSM_CAP = 96;                      // points per LDS buffer: 8 nodes of 11 points after the first level of a 16-to-1 merge
+__global__ void __launch_bounds__(WSM_THREADS)
+k_msm_wsum_mid(const uint32_t* nodes_in, int m_in, int nblk_in, int m_out, int nblk_out, uint32_t* nodes_out) {
+  __shared__ uint32_t lds[2 * WSM_CAP * LP_WORDS];
+  const int w = blockIdx.x / nblk_out, grp = blockIdx.x % nblk_out, t = threadIdx.x;
+  LdsPts X{lds, WSM_CAP}, Y{lds + WSM_CAP * LP_WORDS, WSM_CAP};
+  const int fan = 1 << (m_out - m_in);                          // input nodes per output node (>= 2)
+  const uint32_t* wn = nodes_in + ((size_t)w * nblk_in + (size_t)grp * fan) * NODE_STRIDE * PT_WORDS;
+  {
+    const int per = m_in + 1, merges = fan >> 1;                // level m_in, operands in global memory
+    for (int l = t; l < merges * per; l += WSM_THREADS) {
+      const int mu = l / per, tt = l - mu * per;
+      const ge a = pt_load_ext(wn + ((size_t)(2 * mu) * NODE_STRIDE + tt) * PT_WORDS);
+      const ge b = pt_load_ext(wn + ((size_t)(2 * mu + 1) * NODE_STRIDE + tt) * PT_WORDS);
+      X.store(mu * (per + 1) + tt, ge_add(a, b));
+      if (tt == 0) X.store(mu * (per + 1) + per, b);
+    }
+  }
+  __syncthreads();
+  LdsPts cur = X, nxt = Y;
+#pragma unroll 1
+  for (int j = m_in + 1; j < m_out; ++j) {
+    wsum_level_any(cur, nxt, j, 1 << (m_out - j - 1), t, WSM_THREADS);
+    __syncthreads();
+    const LdsPts tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (t <= m_out) pt_store_ext(nodes_out + (((size_t)w * nblk_out + grp) * MID_STRIDE + t) * PT_WORDS, cur.load(t));
+}
+
 __global__ void __launch_bounds__(WSB_THREADS)
-k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, int cap0, int cap1, uint32_t* sums) {
+k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, int stride, int cap0, int cap1, uint32_t* sums) {
   // c here: the DEPTH of the window's tree, log2 of its leaves (the window width less one: see the leaves' numbering above)
   extern __shared__ uint32_t lds[];
   const int w = blockIdx.x, t = threadIdx.x;
   LdsPts X{lds, cap0}, Y{lds + (size_t)cap0 * LP_WORDS, cap1};
-  const uint32_t* wn = nodes + (size_t)w * nblk * NODE_STRIDE * PT_WORDS;
+  const uint32_t* wn = nodes + (size_t)w * nblk * stride * PT_WORDS;
   LdsPts cur = X, nxt = Y;
   if (c == m) {                                                // the block node is the window's node
     if (t <= m) X.store(t, pt_load_ext(wn + (size_t)t * PT_WORDS));
@@ -1168,8 +1222,8 @@ k_msm_wsum_window(const uint32_t* nodes, int c, int m, int nblk, int cap0, int c
     const int per = m + 1, merges = 1 << (c - m - 1);         // level m, operands in global memory
     for (int l = t; l < merges * per; l += WSB_THREADS) {
       const int mu = l / per, tt = l - mu * per;
-      const ge a = 2 * mu < nblk ? pt_load_ext(wn + ((size_t)(2 * mu) * NODE_STRIDE + tt) * PT_WORDS) : ge_identity();
-      const ge b = 2 * mu + 1 < nblk ? pt_load_ext(wn + ((size_t)(2 * mu + 1) * NODE_STRIDE + tt) * PT_WORDS) : ge_identity();
+      const ge a = 2 * mu < nblk ? pt_load_ext(wn + ((size_t)(2 * mu) * stride + tt) * PT_WORDS) : ge_identity();
+      const ge b = 2 * mu + 1 < nblk ? pt_load_ext(wn + ((size_t)(2 * mu + 1) * stride + tt) * PT_WORDS) : ge_identity();
       X.store(mu * (per + 1) + tt, ge_add(a, b));
       if (tt == 0) X.store(mu * (per + 1) + per, b);
     }
@@ -1485,8 +1539,13 @@ int pick_window(const DeviceState& d, size_t n) {
   // (profiles/r05_msm_window_sweep.txt): 16 bits from 3 x 2^20 points.
   // At HEAD of round 5 (12 / 13 / 14 / 15 / 16 bits): 2^18 698 / 703 / 703 / 815 / 897 us, 2^19 1037 / 1029 / 1007 / 1070 / 1139,
   // 2^20 1685 / 1685 / 1522 / 1585 / 1638, 2^21 2981 / 2976 / 2720 / 2776 / 2784: 14 bits from 2^19 points.
+  // Round 6: windows of 17 and 18 bits exist (int32 digits, the counting pass in parts, a middle level in the tree of bit-sums)
+  // and do not pay up to 2^24 points -- 16 / 17 / 18 bits: 2^22 4828 / 4974 / 5641 us, 2^23 8953 / 9038 / 9559, 2^24 17310 /
+  // 17275 / 17437 (profiles/r06_msm_window_sweep.txt): at 2^24 the span sums shrink by 1.5 ms from 16 to 18 bits and the
+  // counting pass, the first placement level, the per-bucket sums and the tree's 3.5 times as many leaves take it back
+  // (profiles/r06_msm_breakdown_16_17_18.txt).  They stay behind the override for batches beyond 2^24.
   const int c = n >= ((size_t)3 << 20) ? 16 : (n >= ((size_t)1 << 19) ? 14 : 12);
-  return (int)d.tuned(D377_TUNE_MSM_WINDOW, c);              // developer override: 4 .. 16 (>= 4: at most 63 windows, k_msm_final's table of cached sums)
+  return (int)d.tuned(D377_TUNE_MSM_WINDOW, c);              // developer override: 4 .. 18 (>= 4: at most 63 windows, k_msm_final's table of cached sums)
 }
 
 // Lanes of the span sums (k_msm_spans): as many as the device keeps resident at once -- what the runtime says the kernel's
@@ -1589,7 +1648,8 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const size_t per = (n + (size_t)S - 1) / (size_t)S;
   const size_t o_flag = carve(256);
   const size_t o_pts = carve(n * AP_WORDS * 4);
-  const size_t o_dig = carve((size_t)W * n * 2);
+  const bool wide_digits = c > 16;                            // |digit| <= 2^(c-1): int16 up to 16-bit windows, int32 beyond
+  const size_t o_dig = carve((size_t)W * n * (wide_digits ? 4 : 2));
   const size_t o_bh = carve((size_t)W * S * nb * 4);
   const size_t o_off = carve((size_t)W * (nb + 1) * 4);
   const size_t o_seg = carve((size_t)REDUCE_LEVELS * W * (nb + 1) * 4);
@@ -1647,13 +1707,18 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   const int ws_m = ws8 ? WS_M8 : (ws_depth < WS_M ? ws_depth : WS_M);        // >= 2: window widths start at 4 here
   const int ws_nblk = 1 << (ws_depth - ws_m);
   const size_t o_nodes = carve(tree ? (size_t)W * ws_nblk * NODE_STRIDE * PT_WORDS * 4 : 0);
+  // trees deeper than 15 (17- and 18-bit windows): a middle level merges the block nodes 8 or 16 to 1 (k_msm_wsum_mid), down
+  // to 16 nodes per window for k_msm_wsum_window
+  const bool ws_mid = tree && ws_depth > 15;
+  const int ws_mid_m = ws_depth - 4, ws_mid_nblk = 16;
+  const size_t o_mid = carve(ws_mid ? (size_t)W * ws_mid_nblk * MID_STRIDE * PT_WORDS * 4 : 0);
   const size_t o_sums = carve((size_t)W * PT_WORDS * 4);
   int rc;
   MsmHeld held{d.msm.guard, s, false};
   if ((rc = msm_reserve(d, s, off, held))) return rc;
   uint8_t* m = d.msm.mem;
   uint32_t* pts = (uint32_t*)(m + o_pts);
-  int16_t* dig = (int16_t*)(m + o_dig);
+  void* dig_raw = m + o_dig;
   uint32_t *bh = (uint32_t*)(m + o_bh), *offs = (uint32_t*)(m + o_off);
   uint32_t *segoff = (uint32_t*)(m + o_seg), *partial = (uint32_t*)(m + o_par);
   uint32_t* idx = (uint32_t*)(m + o_idx);
@@ -1661,49 +1726,59 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   uint8_t* tmp_sub = m + o_sub;
   uint32_t *bkt = (uint32_t*)(m + o_bkt), *ch = (uint32_t*)(m + o_ch), *f0 = (uint32_t*)(m + o_f0), *f1 = (uint32_t*)(m + o_f1);
   const SqrtTables T = d.tables();
-  const size_t hist_bytes = (size_t)nb * 4;                  // one window's histogram in LDS (<= 128 KiB at c = 16)
-  if (hist_bytes > 64 * 1024) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-  }
-
-  if (n) {
-    if (encoded) {
-      const size_t chunked_min = (size_t)d.tuned(D377_TUNE_MSM_ENC_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_ASSIST_MIN));
-      if (n >= chunked_min && d.msm_enc_chunked < 0) {
-        // the chunked kernel claims lane sets of the scratch areas: only if its residency matches them (as d377_ctx_create
-        // checks for the kernels of d377.hip); otherwise the wide kernel stays
-        int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_msm_prepare_enc_chunked), BLOCK, 0));
-        d.msm_enc_chunked = (nb >= 1 && nb <= WAVES_PER_SIMD) ? 1 : 0;
-      }
-      if (n >= chunked_min && d.msm_enc_chunked == 1) {
-        const ChunkDeal c = deal_chunks((n + BLOCK - 1) / BLOCK, (size_t)d.cus * WAVES_PER_SIMD, (size_t)DCB_K_LONG, (size_t)d.cus * 64);
-        const size_t nchunks = c.nchunks;
-        DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)c.per_lane, d.dcb_sets * BLOCK, (int)c.extra, d.pool_health};
-        dcb.prio = nchunks <= 2 * (size_t)d.cus * WAVES_PER_SIMD ? 1 : 0;      // as d377.hip's chunks_of: launches of one or two generations
-        GuardScope vb{d.vb_guard, s};                       // the lane-set areas: queue behind their last user
-        if ((rc = vb.acquire())) return rc;
-        hipLaunchKernelGGL(k_msm_prepare_enc_chunked, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, wshape,
-                           pts, dig, status, dcb);
-        if ((rc = vb.finish())) return rc;
+  // the counting pass keeps a histogram of at most 2^15 + 1 buckets in LDS (128 KiB): wider windows are counted in R parts
+  const int count_parts = (nb + (1 << 15)) / ((1 << 15) + 1);
+  const int count_nbr = (nb + count_parts - 1) / count_parts;
+  const size_t hist_bytes = (size_t)count_nbr * 4;
+  // prepare (points -> affine records, scalars -> digits) and the counting pass, for the digit type of this window width
+  auto front = [&](auto tag) -> int {
+    using DT = decltype(tag);
+    DT* dig = reinterpret_cast<DT*>(dig_raw);
+    if (hist_bytes > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_count<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+    if (n) {
+      if (encoded) {
+        const size_t chunked_min = (size_t)d.tuned(D377_TUNE_MSM_ENC_CHUNKED_MIN, (long long)(d.resident_lanes() * DCB_ASSIST_MIN));
+        if (n >= chunked_min && d.msm_enc_chunked < 0) {
+          // the chunked kernel claims lane sets of the scratch areas: only if its residency matches them (as d377_ctx_create
+          // checks for the kernels of d377.hip); otherwise the wide kernel stays
+          int nbk = 0, nbk32 = 0;
+          HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, reinterpret_cast<const void*>(k_msm_prepare_enc_chunked<int16_t>), BLOCK, 0));
+          HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk32, reinterpret_cast<const void*>(k_msm_prepare_enc_chunked<int32_t>), BLOCK, 0));
+          d.msm_enc_chunked = (nbk >= 1 && nbk <= WAVES_PER_SIMD && nbk32 >= 1 && nbk32 <= WAVES_PER_SIMD) ? 1 : 0;
+        }
+        if (n >= chunked_min && d.msm_enc_chunked == 1) {
+          const ChunkDeal cd = deal_chunks((n + BLOCK - 1) / BLOCK, (size_t)d.cus * WAVES_PER_SIMD, (size_t)DCB_K_LONG, (size_t)d.cus * 64);
+          const size_t nchunks = cd.nchunks;
+          DcbScratch dcb{d.dcb_scratch, d.slot_pool, d.cus * WAVES_PER_SIMD, (int)cd.per_lane, d.dcb_sets * BLOCK, (int)cd.extra, d.pool_health};
+          dcb.prio = nchunks <= 2 * (size_t)d.cus * WAVES_PER_SIMD ? 1 : 0;      // as d377.hip's chunks_of: launches of one or two generations
+          GuardScope vb{d.vb_guard, s};                       // the lane-set areas: queue behind their last user
+          int r;
+          if ((r = vb.acquire())) return r;
+          hipLaunchKernelGGL(k_msm_prepare_enc_chunked<DT>, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, wshape,
+                             pts, dig, status, dcb);
+          if ((r = vb.finish())) return r;
+        } else {
+          hipLaunchKernelGGL(k_msm_prepare_enc<DT>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, wshape, pts,
+                             dig, status);
+        }
       } else {
-        hipLaunchKernelGGL(k_msm_prepare_enc, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint8_t*)pts_in, scalars, n, wshape, pts,
-                           dig, status);
+        uint32_t* zflag = (uint32_t*)(m + o_flag);
+        HIP_TRY(hipMemsetAsync(zflag, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_msm_prepare_affine<DT>, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint64_t*)pts_in, scalars, n, wshape, pts,
+                           dig, zflag);
+        // ~32 elements per lane share one inversion, but never fewer lanes than one wave per SIMD (see k_to_affine)
+        size_t lanes = (n + 31) / 32;
+        const size_t fill = (size_t)d.cus * BLOCK;
+        if (lanes < fill) lanes = fill < n ? fill : n;
+        hipLaunchKernelGGL(k_msm_prepare_el<DT>, dim3((unsigned)((lanes + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, (const uint64_t*)pts_in,
+                           scalars, n, wshape, pts, dig, zflag);
       }
-    } else {
-      uint32_t* zflag = (uint32_t*)(m + o_flag);
-      HIP_TRY(hipMemsetAsync(zflag, 0, sizeof(uint32_t), s));
-      hipLaunchKernelGGL(k_msm_prepare_affine, dim3(grid_of(d, n)), dim3(BLOCK), 0, s, T, (const uint64_t*)pts_in, scalars, n, wshape, pts,
-                         dig, zflag);
-      // ~32 elements per lane share one inversion, but never fewer lanes than one wave per SIMD (see k_to_affine)
-      size_t lanes = (n + 31) / 32;
-      const size_t fill = (size_t)d.cus * BLOCK;
-      if (lanes < fill) lanes = fill < n ? fill : n;
-      hipLaunchKernelGGL(k_msm_prepare_el, dim3((unsigned)((lanes + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, (const uint64_t*)pts_in,
-                         scalars, n, wshape, pts, dig, zflag);
     }
-  }
-  hipLaunchKernelGGL(k_msm_count, dim3(W * S), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, bh);
+    hipLaunchKernelGGL(k_msm_count<DT>, dim3(W * S * count_parts), dim3(SORT_THREADS), hist_bytes, s, dig, n, nb, S, per, count_parts, count_nbr, bh);
+    return D377_OK;
+  };
+  if ((rc = wide_digits ? front(int32_t{}) : front(int16_t{}))) return rc;
   uint32_t* tot = (uint32_t*)(m + o_tot);
   uint32_t* lvlmax = (uint32_t*)(m + o_lvl);
   HIP_TRY(hipMemsetAsync(lvlmax, 0, LVL_WORDS * sizeof(uint32_t), s));
@@ -1713,12 +1788,23 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
   hipLaunchKernelGGL(k_msm_scan2, dim3(W * scan_chunks), dim3(1024), 0, s, offs, bsz, segoff, tot, tot2, nb, W, scan_chunks, lanes_target,
                      forced_L, red, lvlmax, meta);
   hipLaunchKernelGGL(k_msm_scan3, dim3(W * scan_chunks), dim3(1024), 0, s, offs, segoff, tot2, nb, W, scan_chunks, meta, winfo);
-  if (n <= PACKED_MAX_POINTS && d.tuned(D377_TUNE_MSM_SORT_PACKED, 1) != 0) {
-    hipLaunchKernelGGL(k_msm_place1<true>, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
-    hipLaunchKernelGGL(k_msm_place2<true>, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
-  } else {
-    hipLaunchKernelGGL(k_msm_place1<false>, dim3(W * S), dim3(SORT_THREADS), 0, s, dig, n, nb, S, per, bh, offs, tmp_idx, tmp_sub);
-    hipLaunchKernelGGL(k_msm_place2<false>, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), 0, s, tmp_idx, tmp_sub, n, nb, offs, idx);
+  {
+    // the two placement levels (TileLds: 73 KiB of dynamic LDS each)
+    const bool packed = n <= PACKED_MAX_POINTS && d.tuned(D377_TUNE_MSM_SORT_PACKED, 1) != 0;
+    const size_t tile_lds = sizeof(TileLds);
+    auto place = [&](auto tag, auto packed_tag) -> int {
+      using DT = decltype(tag);
+      constexpr bool PK = decltype(packed_tag)::value;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_place1<PK, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_place2<PK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+      hipLaunchKernelGGL((k_msm_place1<PK, DT>), dim3(W * S), dim3(SORT_THREADS), tile_lds, s, reinterpret_cast<const DT*>(dig_raw), n, nb, S, per, bh, offs,
+                         tmp_idx, tmp_sub);
+      hipLaunchKernelGGL(k_msm_place2<PK>, dim3(W * ((nb + SUPER - 1) / SUPER)), dim3(SORT_THREADS), tile_lds, s, tmp_idx, tmp_sub, n, nb, offs, idx);
+      return D377_OK;
+    };
+    if (wide_digits) rc = packed ? place(int32_t{}, std::true_type{}) : place(int32_t{}, std::false_type{});
+    else rc = packed ? place(int16_t{}, std::true_type{}) : place(int16_t{}, std::false_type{});
+    if (rc) return rc;
   }
   const SpanPlan sp{offs, segoff, winfo, 0u};                  // (L travels in meta: the kernels read it there)
   hipLaunchKernelGGL(k_msm_spans, dim3(grid_of(d, span_lanes_max)), dim3(BLOCK), 0, s, pts, idx, sp, meta, n, W, nb, partial);
@@ -1754,11 +1840,18 @@ int msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, 
       hipLaunchKernelGGL(k_msm_wsum_block2, dim3(W * ws_nblk), dim3(WS2_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
     else
       hipLaunchKernelGGL(k_msm_wsum_block, dim3(W * ws_nblk), dim3(WS_THREADS), 0, s, bkt, nb, ws_m, ws_nblk, nodes);
-    const int cap0 = wsb_cap0(ws_depth, ws_m), cap1 = wsb_cap1(ws_depth, ws_m);
+    const uint32_t* top_nodes = nodes;
+    int top_m = ws_m, top_nblk = ws_nblk, top_stride = NODE_STRIDE;
+    if (ws_mid) {
+      uint32_t* mid = (uint32_t*)(m + o_mid);
+      hipLaunchKernelGGL(k_msm_wsum_mid, dim3(W * ws_mid_nblk), dim3(WSM_THREADS), 0, s, nodes, ws_m, ws_nblk, ws_mid_m, ws_mid_nblk, mid);
+      top_nodes = mid; top_m = ws_mid_m; top_nblk = ws_mid_nblk; top_stride = MID_STRIDE;
+    }
+    const int cap0 = wsb_cap0(ws_depth, top_m), cap1 = wsb_cap1(ws_depth, top_m);
     const size_t wsb_lds = (size_t)(cap0 + cap1) * LP_WORDS * sizeof(uint32_t);
     if (wsb_lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_wsum_window), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsb_lds));
-    hipLaunchKernelGGL(k_msm_wsum_window, dim3(W), dim3(WSB_THREADS), wsb_lds, s, nodes, ws_depth, ws_m, ws_nblk, cap0, cap1, sums);
+    hipLaunchKernelGGL(k_msm_wsum_window, dim3(W), dim3(WSB_THREADS), wsb_lds, s, top_nodes, ws_depth, top_m, top_nblk, top_stride, cap0, cap1, sums);
     cur_in = sums;
   } else {
     hipLaunchKernelGGL(k_msm_chunks, dim3(grid_of(d, (size_t)W * nchunks)), dim3(BLOCK), 0, s, bkt, W, nb, nchunks, ch);

@@ -163,7 +163,7 @@ int d377_ctx_invariant_failures(d377_ctx* ctx, int dev, uint64_t* count);
  *   FB_WIDE                scalar_mul_base: 0 = narrow launch (2 workgroups per CU), 1 = wide (3 per CU) at every size the lane kernel takes
  *   FB_K                   scalar_mul_base: elements per lane per shared inversion, 1..16
  *   AFFINE_BLOCKS_PER_CU   to_affine: workgroups per CU that share the batch, >= 1
- *   MSM_WINDOW             msm: window width in bits, 4..16
+ *   MSM_WINDOW             msm: window width in bits, 4..18
  *   MSM_SEG                msm: sorted entries per span lane, 1..128 (built-in: entries / resident lanes, at least 8)
  *   MSM_SMALL_MAX          msm: batches up to this many points skip the buckets (0 = never)
  *   MSM_SLICES             msm: slices per window of the counting sort, 1..4096

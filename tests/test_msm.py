@@ -178,9 +178,10 @@ def test_msm_on_elements_from_every_producer(ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window", [4, 5, 6, 7, 9, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("window", [4, 5, 6, 7, 9, 12, 13, 14, 15, 16, 17, 18])
 def test_msm_every_window_width(ctx, oracle, window):
-    """Same inputs through different bucket widths (developer override) give the same bytes."""
+    """Same inputs through different bucket widths (developer override) give the same bytes.  17 and 18 bits: int32 digits,
+    the counting pass in 2 / 4 parts of the bucket range, 513 / 1 025 super-buckets, a middle level in the tree of bit-sums."""
     c = ctx
     with ctx.tuning(msm_window=window, msm_small_max=0):       # 3000 points would not reach the buckets otherwise
         rng = np.random.default_rng(702)
@@ -222,6 +223,13 @@ def test_msm_sort_forms_and_span_lengths_agree(ctx, oracle):
                     assert bytes(ctx.msm(P, k)[0]) == want, (name, L)
             with ctx.tuning(msm_window=16, msm_seg=5):
                 assert bytes(ctx.msm(P, k)[0]) == want, name
+            for wide in (17, 18):                                 # the wide windows' own kernels, Elements and Encodings, both sort forms
+                with ctx.tuning(msm_window=wide):
+                    assert bytes(ctx.msm(P, k)[0]) == want, (name, wide)
+                    e2, _, st2 = ctx.msm(oracle.compress(P), k)
+                    assert bytes(e2) == want and not st2.any(), (name, wide)
+                    with ctx.tuning(msm_sort_packed=0, msm_seg=3):
+                        assert bytes(ctx.msm(P, k)[0]) == want, (name, wide)
 
 
 @pytest.mark.gpu
