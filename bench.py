@@ -246,7 +246,9 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
-    ctx = d.Context([local])
+    # the 5.9 GB fixed-base comb is built by the first fixed-base call (the `extra` legs), not at context creation: a rank
+    # whose job has no fixed-base leg (--no-extra, the multi-GPU headline) never pays for it (d377_ctx_create_ex)
+    ctx = d.Context([local], comb_lazy=True)
     from decaf377_amd import sharding
     n = 1 << args.log2n
     mode = "from-root" if args.from_root else args.scaling
@@ -385,6 +387,7 @@ def main():
         "frac": ach / HBM_PEAK_GBS,
         "traffic": traffic,
         "traffic_source": traffic_source,
+        "traffic_measured_in_this_run": False,    # a replay of separate rocprofv3 --pmc passes on the builder's box, gated on the kernel sources' hash
         # what the memory system really moves (per-lane window tables in global scratch), against the same peak; an
         # upper bound on HBM bytes: the counters also see Infinity-Cache hits
         "achieved_measured": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
@@ -576,6 +579,29 @@ def main():
         pm2 = torch.empty_like(pm)
         ker, _ = time_op(torch, lambda: ctx.scalar_mul_var_element(pm, scalars[:ne], outs=[pm2]), 5, 5)
         extra["scalar_mul_var_element"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3)}
+        # many small multiscalar sums at once (d377_batch_msm_small): 2^20 (or n) independent 3-term sums, the shape of the
+        # reference's own multiscalar test (tests/operations.rs:44-60), against the composition the call replaces
+        g3 = torch.Generator(device=dev).manual_seed(9000 + rank)
+        r3 = torch.randint(0, 256, (3 * ne, 32), dtype=torch.uint8, device=dev, generator=g3)
+        k3 = torch.randint(0, 256, (3 * ne, 32), dtype=torch.uint8, device=dev, generator=g3)
+        p3, _ = ctx.decompress(ctx.encode_to_curve(r3))
+        o3 = torch.empty((ne, 32), dtype=torch.uint8, device=dev)
+        ker, _ = time_op(torch, lambda: ctx.msm_small(p3, k3, 3, outs=[o3]), 3, 2)
+        cols = [p3[j::3].contiguous() for j in range(3)]
+        kcols = [k3[j::3].contiguous() for j in range(3)]
+
+        def composed3():
+            acc = ctx.scalar_mul_var_element(cols[0], kcols[0])
+            for j in (1, 2):
+                acc = ctx.add(acc, ctx.scalar_mul_var_element(cols[j], kcols[j]))
+            return ctx.compress(acc)
+
+        ker_c, _ = time_op(torch, composed3, 2, 1)
+        same3 = bool(torch.equal(composed3(), ctx.msm_small(p3, k3, 3)))
+        extra["msm_small_3_terms"] = {"sums": ne, "terms": 3, "ms": ker, "sums_per_sec": ne / (ker * 1e-3), "terms_per_sec": 3 * ne / (ker * 1e-3),
+                                      "composition_ms": ker_c, "composition_over_msm_small": ker_c / ker, "equal_to_composition": same3,
+                                      "note": "one Straus chain per sum; composition = 3 x scalar_mul_var_element + 2 x add + compress"}
+        del r3, p3, cols
         ker, _ = time_op(torch, lambda: ctx.fr_op("mul", scalars[:ne], r0[:ne], outs=[o1, s1]), 5, 5)
         extra["fr_mul"] = {"n": ne, "kernel_ms": ker, "per_sec": ne / (ker * 1e-3), "algo_GBps": 97 * ne / (ker * 1e-3) / 1e9}
         # the remaining group-level entry points of the path, for the record (same 2^20 records)

@@ -1611,6 +1611,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     }
     if (nchunks > (size_t)d.cus * 64) nchunks = (size_t)d.cus * 64;
     grid = (int)nchunks;
+#ifdef D377_DCB_TICKETS                   // A/B only (dcb.hpp): the resident workgroups take the chunks by ticket
+    if ((size_t)grid > places) grid = (int)places;
+#endif
     sc = DcbScratch{d.dcb_scratch, d.slot_pool, d.cus * sets, (int)per_lane, d.dcb_sets * BLOCK, (int)extra, d.pool_health};
     // Issue priority by progress (dcb.hpp dcb_progress_priority) for launches of one or two generations of workgroups: there the
     // workgroups of a CU would end one after the other (-4 to -8 % at 2^20, -1 to -3 % at 1.5 and 2 x 2^20).  Longer launches
@@ -1619,6 +1622,9 @@ int launch(DeviceState& d, hipStream_t s, Op op, int aux, const void* in0, const
     sc.prio = nchunks <= 2 * places ? 1 : 0;
   };
   chunks_of(WAVES_PER_SIMD, DCB_K_LONG, gv, dcb);  // every chunked kernel but the fixed-base one (up to 2^20 on 256 CUs: <= DCB_K per lane either way)
+#ifdef D377_DCB_TICKETS
+  HIP_TRY(hipMemsetAsync(d.pool_health + 3, 0, sizeof(uint32_t), s));      // the launch's chunk counter
+#endif
   GuardScope vb{d.vb_guard, s};            // released (event recorded) when this function returns, if it was acquired
   int rc;
   switch (op) {

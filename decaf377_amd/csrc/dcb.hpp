@@ -190,6 +190,25 @@ __device__ __forceinline__ void dcb_rounds(size_t n, DcbIO& io, PT& pt, P0 phase
   const size_t CHUNK = (size_t)per_lane * BLOCK;
   for (size_t chunk = blockIdx.x; chunk * CHUNK < n; chunk += gridDim.x) {
     io.base = chunk * CHUNK + threadIdx.x;
+#elif defined(D377_DCB_TICKETS)
+  // A/B only (tools/build_variant.sh tickets -DD377_DCB_TICKETS): as many workgroups as are resident, each taking chunks by
+  // TICKET from a per-launch counter (health[3], zeroed by the host before the launch) until they run out -- an XCD whose
+  // clock is higher takes more chunks than a slower one, where chunks dealt by workgroup id give every XCD the same number.
+  const bool assist = NINV > 0 && (!SMALL_OK || io.per_lane + (io.extra != 0 ? 1 : 0) >= DCB_ASSIST_MIN);
+  __shared__ unsigned s_chunk_;
+  unsigned taken = 0;
+  for (;;) {
+    if (threadIdx.x == 0) s_chunk_ = atomicAdd(io.tickets + 3, 1u);
+    __syncthreads();
+    const unsigned chunk = s_chunk_;
+    __syncthreads();
+    const bool longer = chunk < (unsigned)io.extra;
+    int per_lane = io.per_lane + (longer ? 1 : 0);
+    const size_t first = ((size_t)chunk * (unsigned)io.per_lane + (longer ? chunk : (unsigned)io.extra)) * BLOCK;
+    if (first >= n) break;
+    io.base = first + threadIdx.x;
+    if (taken++ != 0 && threadIdx.x == 0)
+      atomicExch(io.claim, (int)(atomicAdd(io.tickets, 1u) & 0x7FFFFFFFu) + 1);
 #else
   // (a launch with extra != 0 has as many workgroups as chunks: only a workgroup's first chunk can be a long one)
   const bool longer = blockIdx.x < (unsigned)io.extra;

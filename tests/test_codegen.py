@@ -9,7 +9,7 @@ import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMITTED = os.path.join(ROOT, "profiles", "r05_resource_usage.txt")
+COMMITTED = os.path.join(ROOT, "profiles", "r06_resource_usage.txt")
 GUARDED = ("k_scalar_mul_var", "k_scalar_mul_base", "k_sqrt_ratio_zeta", "k_encode_to_curve", "k_hash_to_curve", "k_decompress", "k_compress",
            "k_roundtrip", "k_scalar_mul_var_el", "k_to_affine", "k_msm_spans", "k_msm_prepare_affine")
 

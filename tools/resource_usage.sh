@@ -1,7 +1,7 @@
 #!/bin/bash
 # hipcc's per-kernel resource table (VGPRs, spills, scratch, LDS, occupancy) for both translation units.
 # usage: tools/resource_usage.sh [extra -D flags]  > profiles/rNN_resource_usage.txt
-for u in d377 msm codec_chunked; do
+for u in d377 msm codec_chunked batch_msm; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC "$@" -Rpass-analysis=kernel-resource-usage -c decaf377_amd/csrc/$u.hip -o /tmp/ru_$u.o 2> /tmp/ru_$u.txt
   python3 - /tmp/ru_$u.txt <<'P'
 import re, sys

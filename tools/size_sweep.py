@@ -41,8 +41,11 @@ def main():
     ap.add_argument("--step", type=int, default=2)
     ap.add_argument("--ops", type=str, default="")
     ap.add_argument("--sizes", type=str, default="", help="explicit sizes (records), comma separated, instead of powers of two")
+    ap.add_argument("--tune", type=str, default="", help="developer overrides in force for every call: key=value,key=value (engine.TUNE_KEYS)")
     args = ap.parse_args()
     ctx = d.Context([0])
+    for kv in filter(None, args.tune.split(",")):
+        ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
     nmax = 1 << args.max
