@@ -17,8 +17,11 @@ grep -v "amdgpu.ids" $F/soak.txt > profiles/${R}_soak.txt
 grep -v "amdgpu.ids" $F/host_path.txt > profiles/${R}_host_path.txt
 grep -v "amdgpu.ids" $F/hbm_priced_ops.txt > profiles/${R}_hbm_priced_ops.txt
 [ -f $F/route_stress.txt ] && grep -v "amdgpu.ids" $F/route_stress.txt > profiles/${R}_route_stress.txt
+[ -f $F/msm_small_bench.txt ] && grep -v "amdgpu.ids" $F/msm_small_bench.txt > profiles/${R}_msm_small_bench.txt
 for f in size_sweep_quarter size_sweep_msm row_ops; do [ -f $F/$f.txt ] && grep -v "amdgpu.ids\|warning\|hipFree\|\^~\|^ *[0-9]* |" $F/$f.txt > profiles/${R}_$f.txt; done
 [ -f $F/clock_vs_traffic.txt ] && cp $F/clock_vs_traffic.txt profiles/${R}_clock_vs_traffic_rerun.txt
 tools/resource_usage.sh > profiles/${R}_resource_usage.txt 2>/dev/null
+# no artefact may be empty (round 5 committed four empty files)
+for f in profiles/${R}_*; do [ -s "$f" ] || { echo "EMPTY artefact: $f" >&2; exit 1; }; done
 # the release check of the PMC record against the kernel sources in the tree (tests/test_abi.py, skipped in the ordinary suites)
 D377_CHECK_ARTEFACTS=1 python3 -m pytest tests/test_abi.py -q -k pmc_record | tail -1
