@@ -30,6 +30,7 @@
 #include "dcb.hpp"
 #include "quad_ops.hpp"
 #include "row_ops.hpp"
+#include "straus.hpp"
 #include "host_state.hpp"
 
 using namespace d377;
@@ -38,7 +39,6 @@ namespace {
 
 constexpr int BM_MAX = D377_BATCH_MSM_MAX_TERMS;
 static_assert(BM_MAX == 8, "a window's digits of the m points of a sum are the eight nibbles of one word");
-constexpr int BM_WINDOWS = 64;                  // 63 signed 4-bit windows of k / 2 mod r < 2^251 and the recoding's carry (0 or 1)
 
 // Scratch of one resident lane: tables [point][entry][lane] as k_scalar_mul_var's (a wave stores one entry as 12 KiB
 // contiguous; a negative digit swaps the ypx / ymx slots by address), and the digit words [window][lane]: nibble p of word w =
@@ -64,104 +64,6 @@ struct StrausTab {
   __device__ __forceinline__ void dig_store(int w, uint32_t v) { dig[(size_t)w * nthreads + tid] = v; }
   __device__ __forceinline__ uint32_t dig_load(int w) const { return dig[(size_t)w * nthreads + tid]; }
 };
-__device__ __forceinline__ int nibble_digit(uint32_t word, int p) { return (int)(((word >> (4 * p)) & 15u) ^ 8u) - 8; }
-
-// ge_add_cached (curve.hpp) with the NEXT table entry requested behind the four products that read the current one: q's
-// registers are free from there, and the gather has the addition's other four products (and, at a window's last point, the four
-// doublings of the next window) to arrive in.  The products are volatile asm streams, so the fence keeps the loads behind them.
-template <class Reload>
-__device__ __forceinline__ ge ge_add_cached_reload(const ge& p, gec& q, bool neg, bool with_t, Reload reload) {
-  fe a = fe_mul(fe_sub_nc(p.y, p.x), q.ymx);
-  fe b = fe_mul(fe_add(p.y, p.x), q.ypx);
-  fe c = fe_mul(p.t, q.kt);
-  fe d = fe_mul(p.z, q.z2);
-  asm volatile("" ::: "memory");
-  reload(q);
-  asm volatile("" ::: "memory");
-  fe e = fe_sub(b, a), h = fe_add(b, a);
-  fe dmc = fe_sub(d, c), dpc = fe_add(d, c);
-  fe f = fe_select(neg, dpc, dmc), g = fe_select(neg, dmc, dpc);
-  ge r;
-  r.x = fe_mul(e, f); r.y = fe_mul(g, h); r.z = fe_mul(f, g);
-  r.t = p.t;
-  if (with_t) r.t = fe_mul(e, h);
-  return r;
-}
-
-struct NoPow {};                                   // the Element form takes no square root: no power table in LDS
-
-// The sum of one lane: tables of its m points, the digit words, the shared chain.  -> [1/2] of the sum (the caller encodes the double).
-// load_point(p, &g) -> dead (the point contributes nothing: an invalid Encoding, a record with Z = 0).
-template <class LoadPoint>
-__device__ __forceinline__ ge straus_sum(StrausTab& st, const uint8_t* scalar32, size_t first, int m, LoadPoint load_point) {
-  uint32_t deadmask = 0;
-#pragma unroll 1
-  for (int p = 0; p < m; ++p) {
-    ge g;
-    if (load_point(p, &g)) deadmask |= 1u << p;
-    gec id;
-    id.ypx = fe_const(FE_ONE); id.ymx = fe_const(FE_ONE); id.z2 = fe_dbl(fe_const(FE_ONE)); id.kt = fe_zero();
-    st.store(p, 0, id);
-    const gec pc = ge_to_cached(g);
-    st.store(p, 1, pc);
-    ge acc = ge_double_fast(g, true);
-    st.store(p, 2, ge_to_cached(acc));
-#pragma unroll 1
-    for (int j = 3; j <= 8; ++j) {
-      acc = ge_add_cached(acc, pc, false, true);
-      st.store(p, j, ge_to_cached(acc));
-    }
-  }
-  {
-    // the digit words: W[w] collects nibble w of every point's recoded k / 2 mod r (registers: static indices); a dead point's
-    // digits are 0, so it only ever meets its table's entry 0, the identity
-    uint32_t W[BM_WINDOWS];
-#pragma unroll
-    for (int w = 0; w < BM_WINDOWS; ++w) W[w] = 0;
-#pragma unroll 1
-    for (int p = 0; p < m; ++p) {
-      uint32_t k[8], dg[8];
-      load32(scalar32, first + (size_t)p, k);
-      fr_reduce_words(k);
-      fr_half_words(k);
-      fr_recode_signed16(k, dg);
-      const uint32_t live = ((deadmask >> p) & 1u) ? 0u : 15u;
-#pragma unroll
-      for (int wi = 0; wi < 8; ++wi)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) W[8 * wi + b] |= ((dg[wi] >> (4 * b)) & live) << (4 * p);
-    }
-#pragma unroll
-    for (int w = 0; w < BM_WINDOWS; ++w) st.dig_store(w, W[w]);
-  }
-  // the chain: (window, point) pairs from (63, 0) down to (0, m - 1); every addition requests the entry of the next pair
-  ge r = ge_identity();
-  uint32_t wn = st.dig_load(BM_WINDOWS - 1);
-  int d = nibble_digit(wn, 0);
-  bool neg = d < 0;
-  gec e = st.load(0, neg ? -d : d, neg);
-#pragma unroll 1
-  for (int i = BM_WINDOWS - 1; i >= 0; --i) {
-    const uint32_t wc = wn;
-    wn = st.dig_load(i > 0 ? i - 1 : 0);
-    if (i != BM_WINDOWS - 1) {
-#pragma unroll 1
-      for (int j = 0; j < 4; ++j) r = ge_double_neg(r, j == 3);   // (-2)^4 = 16; the additions read T
-    }
-#pragma unroll 1
-    for (int p = 0; p < m; ++p) {
-      const bool neg_cur = neg;
-      const bool more = p + 1 < m;
-      const int np = more ? p + 1 : 0;
-      d = nibble_digit(more ? wc : wn, np);
-      neg = d < 0;
-      const int nj = neg ? -d : d;
-      r = ge_add_cached_reload(r, e, neg_cur, more || (i == 0 && DCB_WANT_T), [&](gec& q) { q = st.load(np, nj, neg); });
-    }
-  }
-  return r;
-}
-
 template <bool ENCODED>
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_batch_msm_lane(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int m, size_t n, uint8_t* out32, uint8_t* status,
@@ -175,7 +77,7 @@ k_batch_msm_lane(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int 
     [&](size_t, int) {},
     [&](size_t i, int j, const uint32_t (*)[8], bool) {
       const size_t first = i * (size_t)m;
-      const ge r = straus_sum(st, scalar32, first, m, [&](int p, ge* g) -> bool {
+      const ge r = straus_sum(st, m, [&](int p, uint32_t k[8]) { load32(scalar32, first + (size_t)p, k); }, [&](int p, ge* g) -> bool {
         if (ENCODED) {
           uint32_t w[8];
           load32(reinterpret_cast<const uint8_t*>(pts_in), first + (size_t)p, w);
@@ -186,7 +88,7 @@ k_batch_msm_lane(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int 
         *g = load_ge_mont256(reinterpret_cast<const uint64_t*>(pts_in), first + (size_t)p);
         D377_INVARIANT(T, *g, !fe_is_zero(g->z));
         return fe_is_zero(g->z);                                   // a record with Z = 0 is no group element: the identity
-      });
+      }, DCB_WANT_T);
       dcb_put(io, j, ge_dcb_from_half(r, false));
     });
   D377_DCB_END();

@@ -7,6 +7,7 @@
 #include <vector>
 #include "curve.hpp"
 #include "msm_plan.hpp"
+#include "straus.hpp"
 using namespace d377;
 
 static std::vector<uint32_t> g_gtab(6 * 256 * GT_STRIDE);
@@ -507,6 +508,28 @@ void sim_scalar_mul_var(const uint32_t* enc, const uint32_t* k, size_t n, uint32
       uint32_t kk[8], dg[8]; memcpy(kk, k + 8 * i, 32); fr_reduce_words(kk); fr_half_words(kk); fr_recode_signed16(kk, dg);
       HostTab tab; ge r = ge_scalar_mul_w4(g, dg, tab, DCB_WANT_T);  // [k/2]P; the state is that of its double
       dcb_put(io, j, ge_dcb_from_half(r, bad != 0));
+    });
+}
+// d377_batch_msm_small's lane kernel (batch_msm.hip): n sums of m terms, Elements in (Montgomery-256 records), encodings out;
+// one host "lane" walks the sums in rounds as a device lane does, the Straus chain is the device's own (straus.hpp)
+struct HostStrausTab {
+  gec e[8][9];
+  uint32_t dig[BM_WINDOWS];
+  void store(int p, int j, const gec& g) { e[p][j] = g; }
+  gec load(int p, int j, bool swap) const { gec c = e[p][j]; if (swap) { fe t = c.ypx; c.ypx = c.ymx; c.ymx = t; } return c; }
+  void dig_store(int w, uint32_t v) { dig[w] = v; }
+  uint32_t dig_load(int w) const { return dig[w]; }
+};
+void sim_batch_msm(const uint32_t* xyzt, const uint32_t* k, int m, size_t n, uint32_t* out) {
+  dcb_rounds<0>(n, out, true,
+    [&](HostDcbIO&, size_t, int) {},
+    [&](HostDcbIO& io, size_t i, int j) {
+      HostStrausTab tab;
+      const size_t first = i * (size_t)m;
+      const ge r = straus_sum(tab, m,
+        [&](int p, uint32_t kk[8]) { memcpy(kk, k + 8 * (first + p), 32); },
+        [&](int p, ge* g) -> bool { *g = ge_load256(xyzt + 32 * (first + p)); return fe_is_zero(g->z); }, DCB_WANT_T);
+      dcb_put(io, j, ge_dcb_from_half(r, false));
     });
 }
 void sim_scalar_mul_var_sqrt(const uint32_t* enc, const uint32_t* k, size_t n, uint32_t* out, uint8_t* st) {

@@ -509,12 +509,48 @@ L.sim_hash_to_curve(p(r0), p(k), n_(n), p(out)); L.sim_compress_assisted(p(xyzt)
 L.sim_decompress_assisted(p(enc), n_(n), p(x2), p(st)); L.sim_roundtrip_assisted(p(k), n_(n), p(out), p(st))
 L.sim_roundtrip_chunked(p(enc), n_(n), p(out), p(st)); L.sim_roundtrip_chunked(p(k), n_(n), p(out), p(st))
 L.sim_scalar_mul_var_sqrt(p(enc), p(k), n_(n), p(out), p(st)); L.sim_encode_to_curve_sqrt(p(r0), n_(n), p(out))
+for m in (1, 3, 8):                                         # the Straus chain of d377_batch_msm_small (straus.hpp): 8 // m sums of m terms
+    L.sim_batch_msm(p(xyzt), p(k), ctypes.c_int(m), n_(n // m), p(out))
+L.sim_batch_msm(p(np.zeros((n, 16), np.uint64)), p(k), ctypes.c_int(2), n_(2), p(out))   # records with Z = 0
 w = np.zeros((n, 4), np.uint64)
 L.sim_fq_mul(p(xyzt), p(x2), n_(n), p(w)); L.sim_fq_sub(p(xyzt), p(x2), n_(n), p(w)); L.sim_fq_add(p(xyzt), p(x2), n_(n), p(w))
 print("BOUNDS_OK")
 """
     r = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "BOUNDS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_batch_msm_straus_chain_matches_oracle_fold(sim, oracle):
+    """d377_batch_msm_small's lane kernel on the host (straus.hpp: the device's own chain -- m tables of cached 0 .. 8 P, the
+    digit words, 252 shared doublings -- under the kernels' round structure): n sums of m terms against the oracle's fold of its
+    own products (src/ark_curve/element/projective.rs:99-117; tests/operations.rs:44-60), m = 1 .. 8, with scalars 0, 1,
+    r - 1, r, 2^256 - 1, the identity, projective Elements and a record with Z = 0 (the identity by contract) mixed in."""
+    rng = np.random.default_rng(8100)
+    R = 2111115437357092606062206234695386632838870926408408195193685246394721360383
+    ident = oracle.decompress(np.zeros((1, 32), np.uint8))[0][0]
+    for m in (1, 2, 3, 5, 8):
+        n = 11
+        terms = n * m
+        P = oracle.elligator_map_xyzt(rng.integers(0, 256, (terms, 32), dtype=np.uint8))
+        k = rng.integers(0, 256, (terms, 32), dtype=np.uint8)
+        for i, v in enumerate([0, 1, R - 1, R, (1 << 256) - 1]):
+            k[(3 * i) % terms] = np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+        P[terms - 1] = ident
+        if terms >= 4:
+            P[2:4] = oracle.scalar_mul_xyzt(P[2:4], k[0:2])                      # projective representatives (Z != 1)
+        Pz = P.copy()
+        Pref = P.copy()
+        if terms >= 6:
+            Pz[5] = 0                                                            # Z = 0
+            Pref[5] = ident
+        prod = oracle.scalar_mul_xyzt(Pref, k)
+        acc = prod[0::m].copy()
+        for j in range(1, m):
+            acc = oracle.add_xyzt(acc, prod[j::m])
+        want = oracle.compress(acc)
+        out = np.zeros((n, 32), np.uint8)
+        sim.sim_batch_msm(_p(np.ascontiguousarray(Pz)), _p(k), ctypes.c_int(m), n_(n), _p(out))
+        assert (out == want).all(), (m, np.nonzero((out != want).any(axis=1))[0])
 
 
 def test_msm_bucket_chain_matches_oracle(sim, oracle):
