@@ -8,6 +8,7 @@ compared; a sample of each result also goes to the oracle.  Test infrastructure 
                                          one wave per scalar            |  one lane per scalar        tiny_max
   sqrt_ratio_zeta, decompress, compress, round trip, encode_to_curve, hash_to_curve:
                                          four elements per wave         |  one lane per element       tiny_max
+  small sums (msm_small), 1..8 terms:    one wave per sum               |  one lane per sum           tiny_max
 usage: python tools/route_stress.py [rounds=40] [seed=1]   -> summary lines, exit 1 on any mismatch"""
 import os
 import sys
@@ -139,6 +140,40 @@ def main():
             print("MISMATCH smallest batches n = %d" % n, flush=True)
     print("smallest batches: %d sizes in [1, 6000], fixed base / sqrt (both roots) / decompress / round trip / compress / encode_to_curve / hash_to_curve, "
           "waves == lanes == oracle sample: %s" % (cnt, "ok" if bad == bad0 else "FAILED"), flush=True)
+    # small sums (d377_batch_msm_small): a wave per sum | a lane per sum, random term counts, Elements and Encodings (invalid
+    # ones sprinkled in: reported and left out of their sums), against the composition they replace and an oracle sample
+    bad0, cnt = bad, 0
+    for n in sizes(1, 3 * one_gen // 4, [cus * 16 - 1, cus * 16, cus * 16 + 1])[: rounds + 9]:
+        m = int(rng.integers(1, 9))
+        n = max(1, min(n, nmax // m))
+        t = n * m
+        res = []
+        for kv in (dict(tiny_max=0), dict(tiny_max=1 << 20), dict()):                                   # lanes, waves, default
+            if "tiny_max" in kv and kv["tiny_max"] and n > 3000:
+                continue
+            with ctx.tuning(**kv):
+                res.append((ctx.msm_small(P_all[:t], k[:t], m), *ctx.msm_small(enc_all[:t], k[:t], m)))
+        ok = all(torch.equal(a, b) for r in res[1:] for a, b in zip(res[0], r))
+        acc = ctx.scalar_mul_var_element(P_all[:t][0::m].contiguous(), k[:t][0::m].contiguous())
+        for j in range(1, m):
+            acc = ctx.add(acc, ctx.scalar_mul_var_element(P_all[:t][j::m].contiguous(), k[:t][j::m].contiguous()))
+        ok = ok and torch.equal(res[0][0], ctx.compress(acc))
+        st_ref = ctx.decompress(enc_all[:t])[1]
+        ok = ok and torch.equal(res[0][2], st_ref)
+        for i in np.unique(rng.integers(0, n, 3)):                   # the Encodings form on the oracle: the fold over the valid terms
+            e, kk = enc_all[i * m:(i + 1) * m].cpu().numpy(), k[i * m:(i + 1) * m].cpu().numpy()
+            prod, st = orc.scalar_mul_var(e, kk)
+            accp = ctx.identity()[None, :].copy()
+            for q in orc.decompress(prod[st == 0])[0]:
+                accp = orc.add_xyzt(accp, q[None, :])
+            want = orc.compress(accp)[0]
+            ok = ok and (res[0][1][i].cpu().numpy() == want).all()
+        bad += 0 if ok else 1
+        cnt += 1
+        if not ok:
+            print("MISMATCH small sums n = %d m = %d" % (n, m), flush=True)
+    print("small sums: %d (n, m) pairs, n in [1, %d], m in [1, 8], waves == lanes == default == composition (Elements), statuses == decompress's, "
+          "Encodings == oracle fold sample: %s" % (cnt, 3 * one_gen // 4, "ok" if bad == bad0 else "FAILED"), flush=True)
     print("ROUTE_STRESS_%s" % ("OK" if bad == 0 else "FAILED"))
     return 1 if bad else 0
 
