@@ -39,6 +39,7 @@ namespace {
 
 constexpr int BM_MAX = D377_BATCH_MSM_MAX_TERMS;
 static_assert(BM_MAX == 8, "a window's digits of the m points of a sum are the eight nibbles of one word");
+static_assert(VB_ENTRIES == 9, "straus_sum stores entries 0 .. 8 of every point's table");
 
 // Scratch of one resident lane: tables [point][entry][lane] as k_scalar_mul_var's (a wave stores one entry as 12 KiB
 // contiguous; a negative digit swaps the ypx / ymx slots by address), and the digit words [window][lane]: nibble p of word w =
@@ -104,6 +105,9 @@ struct OneIO {                                                   // the square-r
   __device__ __forceinline__ void emit(int, const uint32_t* w) { for (int k = 0; k < 8; ++k) out[k] = w[k]; }
 };
 using row::RQ_WORDS;
+// the square roots of a group of Encodings keep their POW_TAB odd powers (64 words each) in the table of the group's first
+// point, which is built after them
+static_assert(POW_TAB * 64 <= row::RQ_TAB_ENTRIES * RQ_WORDS, "row_sqrt_powers' scratch must fit in one point's LDS table");
 template <bool ENCODED>
 __global__ void __launch_bounds__(64)
 k_batch_msm_wave(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int m, size_t n, uint8_t* out32, uint8_t* status) {
