@@ -182,10 +182,10 @@ def load():
     lib.d377_msm_dev.argtypes = [vp, i32, vp, vp, vp, sz, vp, vp]
     lib.d377_msm_encoded_dev.argtypes = [vp, i32, vp, vp, vp, sz, vp, vp, vp]
     lib.d377_sum_elements_dev.argtypes = [vp, i32, vp, vp, sz, vp, vp]
-    lib.d377_batch_msm_small.argtypes = [vp, vp, vp, sz, sz, vp]
-    lib.d377_batch_msm_small_encoded.argtypes = [vp, vp, vp, sz, sz, vp, vp]
-    lib.d377_batch_msm_small_dev.argtypes = [vp, i32, vp, vp, vp, sz, sz, vp]
-    lib.d377_batch_msm_small_encoded_dev.argtypes = [vp, i32, vp, vp, vp, sz, sz, vp, vp]
+    lib.d377_batch_msm_small.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+    lib.d377_batch_msm_small_encoded.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp]
+    lib.d377_batch_msm_small_dev.argtypes = [vp, i32, vp, vp, vp, sz, sz, vp, vp]
+    lib.d377_batch_msm_small_encoded_dev.argtypes = [vp, i32, vp, vp, vp, sz, sz, vp, vp, vp]
     for name in ("d377_msm", "d377_msm_encoded", "d377_msm_dev", "d377_msm_encoded_dev", "d377_sum_elements_dev",
                  "d377_batch_msm_small", "d377_batch_msm_small_encoded", "d377_batch_msm_small_dev", "d377_batch_msm_small_encoded_dev"):
         getattr(lib, name).restype = i32

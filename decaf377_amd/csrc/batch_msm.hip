@@ -67,8 +67,8 @@ struct StrausTab {
 };
 template <bool ENCODED>
 __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-k_batch_msm_lane(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int m, size_t n, uint8_t* out32, uint8_t* status,
-                 uint32_t* tab, uint32_t* dig, DcbScratch dcb) {
+k_batch_msm_lane(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int m, size_t n, uint8_t* out32, uint64_t* xyzt_out,
+                 uint8_t* status, uint32_t* tab, uint32_t* dig, DcbScratch dcb) {
   __shared__ uint32_t lds_pow_[ENCODED ? POW_TAB * NL * BLOCK : 1];
   LdsPowTab pt;
   pt.col = lds_pow_ + (ENCODED ? threadIdx.x : 0);
@@ -90,6 +90,7 @@ k_batch_msm_lane(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int 
         D377_INVARIANT(T, *g, !fe_is_zero(g->z));
         return fe_is_zero(g->z);                                   // a record with Z = 0 is no group element: the identity
       }, DCB_WANT_T);
+      if (xyzt_out) store_ge_mont256(xyzt_out, i, ge_double_fast(r, true));   // the chain ran on k / 2: the sum is the double
       dcb_put(io, j, ge_dcb_from_half(r, false));
     });
   D377_DCB_END();
@@ -110,7 +111,8 @@ using row::RQ_WORDS;
 static_assert(POW_TAB * 64 <= row::RQ_TAB_ENTRIES * RQ_WORDS, "row_sqrt_powers' scratch must fit in one point's LDS table");
 template <bool ENCODED>
 __global__ void __launch_bounds__(64)
-k_batch_msm_wave(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int m, size_t n, uint8_t* out32, uint8_t* status) {
+k_batch_msm_wave(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int m, size_t n, uint8_t* out32, uint64_t* xyzt_out,
+                 uint8_t* status) {
   extern __shared__ uint32_t tab[];                                // m tables of RQ_TAB_ENTRIES x RQ_WORDS words (dynamic: 2 304 bytes per term)
   __shared__ uint32_t xrec[2 * RQ_WORDS];
   __shared__ uint32_t sdg[BM_MAX][8];                              // the points' signed digits (wave-uniform reads in the loop)
@@ -179,6 +181,7 @@ k_batch_msm_wave(SqrtTables T, const void* pts_in, const uint8_t* scalar32, int 
   xrec[t] = v;
   __syncthreads();
   const ge r = row::rq_load_point(xrec);
+  if (xyzt_out && t == 0) store_ge_mont256(xyzt_out, blockIdx.x, ge_double_fast(r, true));
   OneIO io;
   dcb_put(io, 0, ge_dcb_from_half(r, false));
   dcb_finish_with(io, 1, [](const fe& c) { return row::fe_invert_wave(c); });   // (every lane holds the same element)
@@ -193,7 +196,7 @@ size_t scratch_bytes(const DeviceState& d, int m) {
 
 // everything on device pointers, enqueued on `s`; the caller holds ctx->mu
 int batch_msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pts_in, const uint8_t* scalars, size_t m, size_t n,
-                     uint8_t* out32, uint8_t* status) {
+                     uint8_t* out32, uint64_t* xyzt_out, uint8_t* status) {
   if (n == 0) return D377_OK;
   const SqrtTables T = d.tables();
   // up to four sums per SIMD: a wave per sum (the lane kernel needs two sums per lane of the chip before it is the better use of
@@ -202,8 +205,8 @@ int batch_msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pt
   const size_t wave_max = 4 * (size_t)d.tuned(D377_TUNE_TINY_MAX, (long long)d.cus * 4);
   if (n <= wave_max) {
     const size_t lds = m * row::RQ_TAB_ENTRIES * RQ_WORDS * sizeof(uint32_t);
-    if (encoded) hipLaunchKernelGGL(k_batch_msm_wave<true>, dim3((unsigned)n), dim3(64), lds, s, T, pts_in, scalars, (int)m, n, out32, status);
-    else hipLaunchKernelGGL(k_batch_msm_wave<false>, dim3((unsigned)n), dim3(64), lds, s, T, pts_in, scalars, (int)m, n, out32, status);
+    if (encoded) hipLaunchKernelGGL(k_batch_msm_wave<true>, dim3((unsigned)n), dim3(64), lds, s, T, pts_in, scalars, (int)m, n, out32, xyzt_out, status);
+    else hipLaunchKernelGGL(k_batch_msm_wave<false>, dim3((unsigned)n), dim3(64), lds, s, T, pts_in, scalars, (int)m, n, out32, xyzt_out, status);
     HIP_TRY(hipGetLastError());
     return D377_OK;
   }
@@ -246,9 +249,9 @@ int batch_msm_launch(DeviceState& d, hipStream_t s, bool encoded, const void* pt
   uint32_t* tab = d.bm_scratch;
   uint32_t* dig = tab + d.resident_lanes() * (size_t)m * VB_ENTRIES * VB_ENTRY_WORDS;
   if (encoded)
-    hipLaunchKernelGGL(k_batch_msm_lane<true>, dim3((unsigned)c.nchunks), dim3(BLOCK), lds, s, T, pts_in, scalars, (int)m, n, out32, status, tab, dig, dcb);
+    hipLaunchKernelGGL(k_batch_msm_lane<true>, dim3((unsigned)c.nchunks), dim3(BLOCK), lds, s, T, pts_in, scalars, (int)m, n, out32, xyzt_out, status, tab, dig, dcb);
   else
-    hipLaunchKernelGGL(k_batch_msm_lane<false>, dim3((unsigned)c.nchunks), dim3(BLOCK), lds, s, T, pts_in, scalars, (int)m, n, out32, status, tab, dig, dcb);
+    hipLaunchKernelGGL(k_batch_msm_lane<false>, dim3((unsigned)c.nchunks), dim3(BLOCK), lds, s, T, pts_in, scalars, (int)m, n, out32, xyzt_out, status, tab, dig, dcb);
   HIP_TRY(hipGetLastError());
   return vb.finish();
 }
@@ -260,7 +263,7 @@ int check_terms(size_t m) {
 
 // one device's slice of a host batch: copies in, kernel, copies out, synchronised
 int batch_msm_one(DeviceState& d, bool encoded, const uint8_t* pts_in, const uint8_t* scalars, size_t m, size_t n, uint8_t* out32,
-                  uint8_t* status) {
+                  uint64_t* xyzt_out, uint8_t* status) {
   if (n == 0) return D377_OK;
   HIP_TRY(hipSetDevice(d.id));
   int rc = D377_OK;
@@ -270,14 +273,16 @@ int batch_msm_one(DeviceState& d, bool encoded, const uint8_t* pts_in, const uin
     int r;
     if ((r = ensure(d, 0, terms * rec))) return r;
     if ((r = ensure(d, 1, terms * 32))) return r;
-    if ((r = ensure(d, 2, n * 32))) return r;
+    if ((r = ensure(d, 2, n * (xyzt_out ? 32 + 128 : 32)))) return r;      // the Encodings, then the Element records
     if (encoded && (r = ensure(d, 3, terms))) return r;
     StarveCheck starve{d, d.stream};
     if ((r = starve.before())) return r;
     HIP_TRY(hipMemcpyAsync(d.buf[0], pts_in, terms * rec, hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.buf[1], scalars, terms * 32, hipMemcpyHostToDevice, d.stream));
-    if ((r = batch_msm_launch(d, d.stream, encoded, d.buf[0], d.buf[1], m, n, d.buf[2], d.buf[3]))) return r;
+    uint64_t* xyzt_dev = xyzt_out ? reinterpret_cast<uint64_t*>(d.buf[2] + n * 32) : nullptr;
+    if ((r = batch_msm_launch(d, d.stream, encoded, d.buf[0], d.buf[1], m, n, d.buf[2], xyzt_dev, d.buf[3]))) return r;
     HIP_TRY(hipMemcpyAsync(out32, d.buf[2], n * 32, hipMemcpyDeviceToHost, d.stream));
+    if (xyzt_out) HIP_TRY(hipMemcpyAsync(xyzt_out, xyzt_dev, n * 128, hipMemcpyDeviceToHost, d.stream));
     if (encoded) HIP_TRY(hipMemcpyAsync(status, d.buf[3], terms, hipMemcpyDeviceToHost, d.stream));
     if ((r = starve.after())) return r;
     HIP_TRY(hipStreamSynchronize(d.stream));
@@ -289,7 +294,7 @@ int batch_msm_one(DeviceState& d, bool encoded, const uint8_t* pts_in, const uin
 
 // host pointers: contiguous slices of the SUMS over the context's devices, one host thread per device (as d377.hip's run_host)
 int batch_msm_host(d377_ctx* ctx, bool encoded, const void* pts_in, const uint8_t* scalars, size_t m, size_t n, uint8_t* out32,
-                   uint8_t* status) {
+                   uint64_t* xyzt_out, uint8_t* status) {
   if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
   int rc = check_terms(m);
   if (rc) return rc;
@@ -297,7 +302,7 @@ int batch_msm_host(d377_ctx* ctx, bool encoded, const void* pts_in, const uint8_
   if (n == 0) return D377_OK;
   std::lock_guard<std::mutex> lock(ctx->mu);
   const size_t nd = ctx->devs.size(), rec = encoded ? 32 : 128;
-  if (nd == 1) return batch_msm_one(ctx->devs[0], encoded, (const uint8_t*)pts_in, scalars, m, n, out32, status);
+  if (nd == 1) return batch_msm_one(ctx->devs[0], encoded, (const uint8_t*)pts_in, scalars, m, n, out32, xyzt_out, status);
   const size_t per = (n + nd - 1) / nd;
   std::vector<int> rcs(nd, D377_OK);
   std::vector<std::string> errs(nd);
@@ -310,7 +315,7 @@ int batch_msm_host(d377_ctx* ctx, bool encoded, const void* pts_in, const uint8_
     workers.emplace_back([&, k, lo, cnt]() {
       if (delay > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay));
       rcs[k] = batch_msm_one(ctx->devs[k], encoded, (const uint8_t*)pts_in + lo * m * rec, scalars + lo * m * 32, m, cnt, out32 + lo * 32,
-                             encoded ? status + lo * m : nullptr);
+                             xyzt_out ? xyzt_out + lo * 16 : nullptr, encoded ? status + lo * m : nullptr);
       if (rcs[k] != D377_OK) errs[k] = d377_g_err;
     });
   }
@@ -321,37 +326,39 @@ int batch_msm_host(d377_ctx* ctx, bool encoded, const void* pts_in, const uint8_
 }
 
 int batch_msm_dev(d377_ctx* ctx, int dev, void* stream, bool encoded, const void* pts_in, const uint8_t* scalars, size_t m, size_t n,
-                  uint8_t* out32, uint8_t* status) {
+                  uint8_t* out32, uint64_t* xyzt_out, uint8_t* status) {
   if (!ctx) return fail(D377_ERR_ARG, "%s", "null context");
   if (dev < 0 || (size_t)dev >= ctx->devs.size()) return fail(D377_ERR_ARG, "%s", "device index out of range");
   int rc = check_terms(m);
   if (rc) return rc;
   if (n && (!pts_in || !scalars || !out32 || (encoded && !status))) return fail(D377_ERR_ARG, "%s", "null buffer");
-  if (!aligned16(pts_in) || !aligned16(scalars) || !aligned16(out32)) return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
+  if (!aligned16(pts_in) || !aligned16(scalars) || !aligned16(out32) || !aligned16(xyzt_out))
+    return fail(D377_ERR_ARG, "%s", "device record buffers must be 16-byte aligned");
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceState& d = ctx->devs[(size_t)dev];
   HIP_TRY(hipSetDevice(d.id));
-  return batch_msm_launch(d, (hipStream_t)stream, encoded, pts_in, scalars, m, n, out32, status);
+  return batch_msm_launch(d, (hipStream_t)stream, encoded, pts_in, scalars, m, n, out32, xyzt_out, status);
 }
 
 }  // namespace
 
 extern "C" {
 
-int d377_batch_msm_small(d377_ctx* ctx, const uint64_t* xyzt, const uint8_t* scalar32, size_t m, size_t n, uint8_t* enc32_out) {
-  return batch_msm_host(ctx, false, xyzt, scalar32, m, n, enc32_out, nullptr);
+int d377_batch_msm_small(d377_ctx* ctx, const uint64_t* xyzt, const uint8_t* scalar32, size_t m, size_t n, uint8_t* enc32_out,
+                         uint64_t* xyzt_out) {
+  return batch_msm_host(ctx, false, xyzt, scalar32, m, n, enc32_out, xyzt_out, nullptr);
 }
 int d377_batch_msm_small_encoded(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t m, size_t n, uint8_t* enc32_out,
-                                 uint8_t* status) {
-  return batch_msm_host(ctx, true, enc32, scalar32, m, n, enc32_out, status);
+                                 uint64_t* xyzt_out, uint8_t* status) {
+  return batch_msm_host(ctx, true, enc32, scalar32, m, n, enc32_out, xyzt_out, status);
 }
 int d377_batch_msm_small_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, const uint8_t* scalar32, size_t m, size_t n,
-                             uint8_t* enc32_out) {
-  return batch_msm_dev(ctx, dev, stream, false, xyzt, scalar32, m, n, enc32_out, nullptr);
+                             uint8_t* enc32_out, uint64_t* xyzt_out) {
+  return batch_msm_dev(ctx, dev, stream, false, xyzt, scalar32, m, n, enc32_out, xyzt_out, nullptr);
 }
 int d377_batch_msm_small_encoded_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, const uint8_t* scalar32, size_t m,
-                                     size_t n, uint8_t* enc32_out, uint8_t* status) {
-  return batch_msm_dev(ctx, dev, stream, true, enc32, scalar32, m, n, enc32_out, status);
+                                     size_t n, uint8_t* enc32_out, uint64_t* xyzt_out, uint8_t* status) {
+  return batch_msm_dev(ctx, dev, stream, true, enc32, scalar32, m, n, enc32_out, xyzt_out, status);
 }
 
 }  // extern "C"

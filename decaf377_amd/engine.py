@@ -454,12 +454,14 @@ class Context:
         return self._run("d377_batch_to_affine", [xyzt], [ELEM], [AFF], outs)[0]
 
     # -- multi-scalar multiplication -------------------------------------------------------------
-    def msm_small(self, points, scalar32, m, outs=None):
+    def msm_small(self, points, scalar32, m, outs=None, elements=False):
         """n independent multiscalar sums of m terms each (d377_batch_msm_small[_encoded]): Element::vartime_multiscalar_mul
         (src/ark_curve/element/projective.rs:99-117) in the shape of the reference's own test, a 3-term sum per case
         (tests/operations.rs:44-60), many at once.  points: [n * m, 16] u64 Elements or [n * m, 32] u8 Encodings, scalar32:
         [n * m, 32], term-major within a sum; 1 <= m <= 8.  Returns enc [n, 32] for Elements, (enc, status [n * m]) for
-        Encodings (an invalid Encoding is reported and left out of its sum)."""
+        Encodings (an invalid Encoding is reported and left out of its sum); with elements=True the sums also come back as
+        Element records, what the reference's function returns: (enc, xyzt [n, 16]) / (enc, xyzt, status), in d377_msm's
+        order.  outs: the same tuple of preallocated arrays."""
         m = int(m)
         if points.ndim != 2 or int(points.shape[1]) not in (16, 32):
             raise ValueError("msm_small: points must be [n * m, 16] Elements or [n * m, 32] Encodings")
@@ -471,27 +473,37 @@ class Context:
         _check(points, ENC if encoded else ELEM, terms, "msm_small points")
         _check(scalar32, ENC, terms, "msm_small scalars", points.device if _is_torch(points) else None)
         name = "d377_batch_msm_small_encoded" if encoded else "d377_batch_msm_small"
+        specs = [(ENC, n)] + ([(ELEM, n)] if elements else []) + ([(FLAG, terms)] if encoded else [])
+        null = ctypes.c_void_p(None)
         if _is_torch(points):
             import torch
             dev = points.device
             di = self._dev_index(dev)
             pts, sc = points.contiguous(), scalar32.contiguous()
             if outs is None:
-                outs = [torch.empty((n, 32), dtype=torch.uint8, device=dev)] + ([torch.empty((terms,), dtype=torch.uint8, device=dev)] if encoded else [])
-            for a, spec, rows in zip(outs, [ENC, FLAG], [n, terms]):
+                outs = [torch.empty((rows,) + tail, dtype=torch.uint8 if k == "u8" else torch.int64, device=dev) for (tail, k), rows in specs]
+            if len(outs) != len(specs):
+                raise ValueError("msm_small: %d output arrays expected" % len(specs))
+            for a, (spec, rows) in zip(outs, specs):
                 _check(a, spec, rows, "msm_small output", dev)
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             p = lambda t: ctypes.c_void_p(t.data_ptr())
-            args = [self._h, di, stream, p(pts), p(sc), ctypes.c_size_t(m), ctypes.c_size_t(n)] + [p(o) for o in outs]
-            _native.check(getattr(self._lib, name + "_dev")(*args))
-            return tuple(outs) if encoded else outs[0]
+            ptrs = [p(o) for o in outs]
+            if not elements:
+                ptrs.insert(1, null)
+            _native.check(getattr(self._lib, name + "_dev")(self._h, di, stream, p(pts), p(sc), ctypes.c_size_t(m), ctypes.c_size_t(n), *ptrs))
+            return tuple(outs) if len(outs) > 1 else outs[0]
         pts, sc = np.ascontiguousarray(points), np.ascontiguousarray(scalar32)
         if outs is None:
-            outs = [np.zeros((n, 32), np.uint8)] + ([np.zeros((terms,), np.uint8)] if encoded else [])
+            outs = [np.zeros((rows,) + tail, np.uint8 if k == "u8" else np.uint64) for (tail, k), rows in specs]
+        if len(outs) != len(specs):
+            raise ValueError("msm_small: %d output arrays expected" % len(specs))
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        args = [self._h, p(pts), p(sc), ctypes.c_size_t(m), ctypes.c_size_t(n)] + [p(o) for o in outs]
-        _native.check(getattr(self._lib, name)(*args))
-        return tuple(outs) if encoded else outs[0]
+        ptrs = [p(o) for o in outs]
+        if not elements:
+            ptrs.insert(1, null)
+        _native.check(getattr(self._lib, name)(self._h, p(pts), p(sc), ctypes.c_size_t(m), ctypes.c_size_t(n), *ptrs))
+        return tuple(outs) if len(outs) > 1 else outs[0]
 
     def msm(self, points, scalar32, encoded=None):
         """Element::vartime_multiscalar_mul (src/ark_curve/element/projective.rs:99-117).

@@ -285,7 +285,8 @@ int d377_msm_encoded(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar3
                      uint64_t* xyzt_out, uint8_t* status);
 
 /* MANY small multiscalar sums at once: sum i = scalar[i m] * point[i m] + ... + scalar[i m + m - 1] * point[i m + m - 1] for
- * i < n, m terms per sum, 1 <= m <= D377_BATCH_MSM_MAX_TERMS; enc32_out[i] = the canonical Encoding of sum i.  This is
+ * i < n, m terms per sum, 1 <= m <= D377_BATCH_MSM_MAX_TERMS; enc32_out[i] = the canonical Encoding of sum i and, if
+ * xyzt_out != NULL, xyzt_out[i] = sum i as an Element record (n x 16 u64; some extended representative, as d377_msm's).  This is
  * Element::vartime_multiscalar_mul (src/ark_curve/element/projective.rs:99-117) in the shape the reference's own test
  * exercises it -- a 3-term sum per case, tests/operations.rs:44-60 -- for callers that hold many such sums (d377_msm is ONE
  * long sum per call).  Each sum is one Straus chain: its m points share the 252 doublings, so a 3-term sum costs about half
@@ -295,9 +296,10 @@ int d377_msm_encoded(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar3
  * their sum, like d377_msm_encoded.  Scratch: 0.23 GB of HBM per term on a 256-CU device, allocated on the first call
  * with that many terms (so that call must not be inside a stream capture).  A multi-GPU context slices the SUMS. */
 #define D377_BATCH_MSM_MAX_TERMS 8
-int d377_batch_msm_small(d377_ctx* ctx, const uint64_t* xyzt, const uint8_t* scalar32, size_t m, size_t n, uint8_t* enc32_out);
+int d377_batch_msm_small(d377_ctx* ctx, const uint64_t* xyzt, const uint8_t* scalar32, size_t m, size_t n, uint8_t* enc32_out,
+                         uint64_t* xyzt_out);
 int d377_batch_msm_small_encoded(d377_ctx* ctx, const uint8_t* enc32, const uint8_t* scalar32, size_t m, size_t n,
-                                 uint8_t* enc32_out, uint8_t* status);
+                                 uint8_t* enc32_out, uint64_t* xyzt_out, uint8_t* status);
 
 /* Fq field operations on in-memory elements (4 Montgomery u64 limbs, R = 2^256, fully reduced), the
  * unit everything above is built from             src/fields/fq/u64/wrapper.rs:99-132, fq/ops.rs
@@ -406,9 +408,9 @@ int d377_msm_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, con
 int d377_msm_encoded_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, const uint8_t* scalar32,
                          size_t n, uint8_t* enc32_out, uint64_t* xyzt_out, uint8_t* status);
 int d377_batch_msm_small_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, const uint8_t* scalar32, size_t m,
-                             size_t n, uint8_t* enc32_out);
+                             size_t n, uint8_t* enc32_out, uint64_t* xyzt_out);
 int d377_batch_msm_small_encoded_dev(d377_ctx* ctx, int dev, void* stream, const uint8_t* enc32, const uint8_t* scalar32,
-                                     size_t m, size_t n, uint8_t* enc32_out, uint8_t* status);
+                                     size_t m, size_t n, uint8_t* enc32_out, uint64_t* xyzt_out, uint8_t* status);
 /* Sum of m Element records (e.g. the per-rank partial sums of a sharded MSM after an all-gather). */
 int d377_sum_elements_dev(d377_ctx* ctx, int dev, void* stream, const uint64_t* xyzt, size_t m,
                           uint8_t* enc32_out, uint64_t* xyzt_out);

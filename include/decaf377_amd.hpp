@@ -284,21 +284,27 @@ class Engine {
     return {out, results(points, st)};
   }
   /// MANY small sums at once: sum i = scalars[i m ..][..m] . points[i m ..][..m], m terms each (1 .. 8) -- the shape of the
-  /// crate's own multiscalar test, a 3-term sum per case (tests/operations.rs:44-60); the sums come back as Encodings.
-  std::vector<Encoding> vartime_multiscalar_mul_batch(size_t m, const std::vector<Fr>& scalars, const std::vector<Element>& points) {
+  /// crate's own multiscalar test, a 3-term sum per case (tests/operations.rs:44-60).  The sums come back as Elements, as
+  /// the crate's function returns them; `encodings`, if given, receives their Encodings, which the same pass computes.
+  std::vector<Element> vartime_multiscalar_mul_batch(size_t m, const std::vector<Fr>& scalars, const std::vector<Element>& points,
+                                                     std::vector<Encoding>* encodings = nullptr) {
     if (scalars.size() != points.size() || m == 0 || points.size() % m) throw std::invalid_argument("length mismatch");
-    std::vector<Encoding> out(points.size() / m);
-    check(d377_batch_msm_small(ctx_, u64(points), u8(scalars), m, out.size(), u8m(out)));
+    std::vector<Element> out(points.size() / m);
+    std::vector<Encoding> enc(out.size());
+    check(d377_batch_msm_small(ctx_, u64(points), u8(scalars), m, out.size(), u8m(enc), reinterpret_cast<uint64_t*>(out.data())));
+    if (encodings) *encodings = std::move(enc);
     return out;
   }
   /// The same over Encodings: an invalid one is reported (Err, per term) and left out of its sum.
-  std::pair<std::vector<Encoding>, std::vector<Result<Encoding>>> vartime_multiscalar_mul_batch_encoded(
-      size_t m, const std::vector<Fr>& scalars, const std::vector<Encoding>& points) {
+  std::pair<std::vector<Element>, std::vector<Result<Encoding>>> vartime_multiscalar_mul_batch_encoded(
+      size_t m, const std::vector<Fr>& scalars, const std::vector<Encoding>& points, std::vector<Encoding>* encodings = nullptr) {
     if (scalars.size() != points.size() || m == 0 || points.size() % m) throw std::invalid_argument("length mismatch");
-    std::vector<Encoding> out(points.size() / m);
+    std::vector<Element> out(points.size() / m);
+    std::vector<Encoding> enc(out.size());
     std::vector<uint8_t> st(points.size() ? points.size() : 1);
-    check(d377_batch_msm_small_encoded(ctx_, u8(points), u8(scalars), m, out.size(), u8m(out), st.data()));
+    check(d377_batch_msm_small_encoded(ctx_, u8(points), u8(scalars), m, out.size(), u8m(enc), reinterpret_cast<uint64_t*>(out.data()), st.data()));
     st.resize(points.size());
+    if (encodings) *encodings = std::move(enc);
     return {out, results(points, st)};
   }
   /// CurveGroup::normalize_batch (src/ark_curve/element.rs:74-81): affine (x, y) as 4 Montgomery limbs each

@@ -364,30 +364,37 @@ impl Element {
     }
     /// MANY small sums at once: sum i = scalars[i m ..][..m] . points[i m ..][..m], `m` terms each (1..=8) -- the shape of the
     /// crate's own multiscalar test, a 3-term sum per case (tests/operations.rs:44-60).  One Straus chain per sum on the GPU
-    /// (the m points share the doublings).  Returns the sums as Encodings.
-    pub fn vartime_multiscalar_mul_batch_gpu(ctx: &GpuContext, m: usize, scalars: &[Fr], points: &[Element]) -> Result<Vec<Encoding>, GpuError> {
+    /// (the m points share the doublings).  Returns the sums as Elements, like `vartime_multiscalar_mul`, and their
+    /// Encodings, which the same pass computes.
+    pub fn vartime_multiscalar_mul_batch_gpu(ctx: &GpuContext, m: usize, scalars: &[Fr], points: &[Element])
+        -> Result<(Vec<Element>, Vec<Encoding>), GpuError> {
         assert_eq!(scalars.len(), points.len());
         assert!(m >= 1 && points.len() % m == 0);
         let n = points.len() / m;
         let xyzt = elements_to_xyzt(points);
         let bytes = pack32(scalars, |k| k.to_bytes());
-        let mut out = vec![Encoding([0u8; 32]); n];
-        check(unsafe { ffi::d377_batch_msm_small(ctx.0, xyzt.as_ptr(), bytes.as_ptr(), m, n, out.as_mut_ptr() as *mut u8) })?;
-        Ok(out)
+        let mut enc = vec![Encoding([0u8; 32]); n];
+        let mut out = vec![0u64; 16 * n];
+        check(unsafe {
+            ffi::d377_batch_msm_small(ctx.0, xyzt.as_ptr(), bytes.as_ptr(), m, n, enc.as_mut_ptr() as *mut u8, out.as_mut_ptr())
+        })?;
+        Ok((out.chunks_exact(16).map(element_from_xyzt).collect(), enc))
     }
     /// The same over Encodings: an invalid one is reported (per term) and left out of its sum.
     pub fn vartime_multiscalar_mul_batch_encoded_gpu(ctx: &GpuContext, m: usize, scalars: &[Fr], points: &[Encoding])
-        -> Result<(Vec<Encoding>, Vec<Result<(), EncodingError>>), GpuError> {
+        -> Result<(Vec<Element>, Vec<Encoding>, Vec<Result<(), EncodingError>>), GpuError> {
         assert_eq!(scalars.len(), points.len());
         assert!(m >= 1 && points.len() % m == 0);
         let n = points.len() / m;
         let bytes = pack32(scalars, |k| k.to_bytes());
-        let mut out = vec![Encoding([0u8; 32]); n];
+        let mut enc = vec![Encoding([0u8; 32]); n];
+        let mut out = vec![0u64; 16 * n];
         let mut st = vec![0u8; points.len()];
         check(unsafe {
-            ffi::d377_batch_msm_small_encoded(ctx.0, enc_ptr(points), bytes.as_ptr(), m, n, out.as_mut_ptr() as *mut u8, st.as_mut_ptr())
+            ffi::d377_batch_msm_small_encoded(ctx.0, enc_ptr(points), bytes.as_ptr(), m, n, enc.as_mut_ptr() as *mut u8, out.as_mut_ptr(),
+                                              st.as_mut_ptr())
         })?;
-        Ok((out, results(&st, |_| ())))
+        Ok((out.chunks_exact(16).map(element_from_xyzt).collect(), enc, results(&st, |_| ())))
     }
 }
 

@@ -151,14 +151,17 @@ static void vartime_multiscalar_mul_matches_scalar_mul(Engine& e) {
     auto enc = e.encode_to_curve(r);
     std::vector<Element> pts;
     for (auto& d : e.vartime_decompress(enc)) pts.push_back(d.unwrap());
-    auto sums = e.vartime_multiscalar_mul_batch(m, k, pts);
-    auto sums_e = e.vartime_multiscalar_mul_batch_encoded(m, k, enc);
-    CHECK(sums.size() == cases && sums_e.first.size() == cases);
+    std::vector<Encoding> sums_enc, sums_e_enc;
+    auto sums = e.vartime_multiscalar_mul_batch(m, k, pts, &sums_enc);                 // Elements, as the crate's function returns
+    auto sums_e = e.vartime_multiscalar_mul_batch_encoded(m, k, enc, &sums_e_enc);
+    CHECK(sums.size() == cases && sums_e.first.size() == cases && sums_enc.size() == cases && sums_e_enc.size() == cases);
+    auto same = e.eq(sums, sums_e.first);
+    auto back = e.vartime_compress(sums);
     for (size_t c = 0; c < cases; ++c) {
       std::vector<Fr> kc(k.begin() + c * m, k.begin() + (c + 1) * m);
       std::vector<Element> pc(pts.begin() + c * m, pts.begin() + (c + 1) * m);
-      CHECK(e.vartime_compress({e.vartime_multiscalar_mul(kc, pc)})[0] == sums[c]);
-      CHECK(sums_e.first[c] == sums[c]);
+      CHECK(e.vartime_compress({e.vartime_multiscalar_mul(kc, pc)})[0] == sums_enc[c]);
+      CHECK(same[c] && back[c] == sums_enc[c] && sums_e_enc[c] == sums_enc[c]);
     }
     for (auto& st : sums_e.second) CHECK(st.ok);
   }

@@ -1504,8 +1504,8 @@ def _dev_cases(ctx, oracle, torch, n):
         "d377_batch_fr_from_bytes_checked_dev": lambda f: f.fr_from_bytes_checked,
         "d377_msm_dev": lambda f: f.msm,
         "d377_msm_encoded_dev": lambda f: f.msm,
-        "d377_batch_msm_small_dev": lambda f: f.msm_small,
-        "d377_batch_msm_small_encoded_dev": lambda f: f.msm_small,
+        "d377_batch_msm_small_dev": lambda f: (lambda p, k_, m: f.msm_small(p, k_, m, elements=True)),   # Encodings and Element records
+        "d377_batch_msm_small_encoded_dev": lambda f: (lambda p, k_, m: f.msm_small(p, k_, m, elements=m == 5)),
         "d377_sum_elements_dev": None,
         "d377_ctx_starved_counter_dev": None,          # test_starved_call_is_an_error_not_a_silent_partial_output
         "d377_batch_sharded_dev": None,

@@ -285,6 +285,22 @@ def _fold_sums(oracle, P, k, m, threads=8):
     return oracle.compress(acc)
 
 
+def _check_element_records(oracle, xyzt, want_enc, sample=48):
+    """The Element form of the sums (what the reference's function returns): every record encodes to the sum's Encoding, and
+    a sample is checked as the crate checks an Element (src/min_curve/element.rs:84-110): limbs below q, on the curve,
+    T Z = X Y."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import d377_model as mod
+    xyzt = np.ascontiguousarray(xyzt).view(np.uint64).reshape(-1, 16)
+    assert (oracle.compress(xyzt) == want_enc).all()
+    for i in np.unique(np.linspace(0, len(xyzt) - 1, min(sample, len(xyzt))).astype(int)) if len(xyzt) else []:
+        raw = [sum(int(l) << (64 * j) for j, l in enumerate(xyzt[i, 4 * c:4 * c + 4])) for c in range(4)]
+        assert all(v < mod.Q for v in raw), i
+        x, y, z, t = (mod.from_mont_limbs([int(l) for l in xyzt[i, 4 * c:4 * c + 4]]) for c in range(4))
+        assert z != 0 and mod.pt_on_curve((x, y, z, t)), i
+
+
 @pytest.fixture(params=["default", "lanes", "waves"])
 def small_route(request, ctx):
     """d377_batch_msm_small's two kernels on the same inputs: a wave per sum (batches up to one sum per SIMD by default) and a
@@ -316,6 +332,9 @@ def test_batch_msm_small_matches_oracle_fold(ctx, oracle, m, small_route):
         want = _fold_sums(oracle, P, k, m)
         got = ctx.msm_small(P, k, m)
         assert got.shape == (n, 32) and (got == want).all(), (m, n, small_route, np.nonzero((got != want).any(axis=1))[0][:8])
+        got2, got_x = ctx.msm_small(P, k, m, elements=True)                        # the sums as Elements too
+        assert (got2 == want).all() and got_x.shape == (n, 16)
+        _check_element_records(oracle, got_x, want)
         # Encoding input: the same sums; then with invalid encodings, which drop out of their sums
         encs = oracle.compress(P)
         got_e, st = ctx.msm_small(encs, k, m)
@@ -331,8 +350,9 @@ def test_batch_msm_small_matches_oracle_fold(ctx, oracle, m, small_route):
             want_b = _fold_sums(oracle, Pref, k, m)
             Pz = Pref.copy()
             Pz[3] = 0                                                               # Z = 0: no group element, counts as the identity
-            got_b, st = ctx.msm_small(bad, k, m)
+            got_b, got_bx, st = ctx.msm_small(bad, k, m, elements=True)
             assert list(np.nonzero(st)[0]) == [3, terms - 1] and (got_b == want_b).all(), (m, n, small_route)
+            _check_element_records(oracle, got_bx, want_b)
             assert (ctx.msm_small(Pz, k, m) == want_b).all(), (m, n, small_route)
 
 
@@ -354,6 +374,13 @@ def test_batch_msm_small_device_path_and_errors(ctx, oracle):
     enc_d = ctx.compress(Pd)
     out_e, st = ctx.msm_small(enc_d, kd, m)
     assert (out_e.cpu().numpy() == want).all() and not st.cpu().numpy().any()
+    out2, out_x = ctx.msm_small(Pd, kd, m, elements=True)
+    out3, out_ex, st = ctx.msm_small(enc_d, kd, m, elements=True)
+    assert torch.equal(out2, out) and torch.equal(out3, out) and not st.cpu().numpy().any()
+    assert torch.equal(ctx.compress(out_x), out) and bool(ctx.eq(out_x, out_ex).all())
+    _check_element_records(oracle, out_x.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        ctx.msm_small(Pd, kd, m, outs=[out], elements=True)                         # two output arrays expected
     with pytest.raises(nat.NativeError):
         ctx.msm_small(P[: 9 * 4], k[: 9 * 4], 9)                                    # more than D377_BATCH_MSM_MAX_TERMS terms
     with pytest.raises(ValueError):
@@ -383,8 +410,9 @@ def test_batch_msm_small_full_size(ctx, oracle, m, log_n):
     ref = ctx.compress(acc)
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
-    out_e, st = ctx.msm_small(encs, k, m)
+    out_e, out_ex, st = ctx.msm_small(encs, k, m, elements=True)
     assert torch.equal(out_e, ref) and int(st.sum().item()) == 0
+    assert torch.equal(ctx.compress(out_ex), ref) and bool(ctx.eq(out_ex, acc).all())   # the Element form: the same group elements
     q = 2048
     want = _fold_sums(oracle, P[: q * m].cpu().numpy().view(np.uint64), k[: q * m].cpu().numpy(), m, threads=16)
     assert (out[:q].cpu().numpy() == want).all()
