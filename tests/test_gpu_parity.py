@@ -1149,10 +1149,10 @@ def test_neg_identity_generator(ctx, oracle, kats):
     assert ctx.eq(ctx.neg(N), P).all()
 
 
-def test_multi_device_context_slicing(oracle):
+def test_multi_device_context_slicing(ctx, oracle):
     """A context that owns several devices slices the batch into contiguous shards.
     With one physical GPU the same device is listed twice / three times: that exercises the whole
-    multi-device host path (per-device tables, streams, slices, MSM partial-sum combine)."""
+    multi-device host path (per-device tables, streams, slices, MSM partial-sum combine; the small sums sliced by SUMS)."""
     import decaf377_amd as d
     rng = np.random.default_rng(679)
     for ids in ([0, 0], [0, 0, 0]):
@@ -1175,6 +1175,16 @@ def test_multi_device_context_slicing(oracle):
             keep = o_st == 0
             assert (st2 == o_st).all()
             assert bytes(e2) == bytes(oracle.msm(xyzt[keep], k[keep])[0])
+            for m in (2, 3):                          # d377_batch_msm_small: whole sums per device, outputs and statuses in place
+                t = m * (n // m)
+                if t == 0:
+                    continue
+                es, xs = c.msm_small(xyzt[:t], k[:t], m, elements=True)
+                es1 = ctx.msm_small(xyzt[:t], k[:t], m)       # the single-device context (tests/test_msm.py pins it to the oracle)
+                assert (es == es1).all() and (c.compress(xs) == es1).all(), (ids, n, m)
+                ee, st3 = c.msm_small(raw[:t], k[:t], m)
+                ee1, st1 = ctx.msm_small(raw[:t], k[:t], m)
+                assert (ee == ee1).all() and (st3 == st1).all() and (st3 == o_st[:t]).all(), (ids, n, m)
         c.close()
 
 
