@@ -1186,6 +1186,13 @@ def test_multi_device_context_slicing(ctx, oracle):
                 ee1, st1 = ctx.msm_small(raw[:t], k[:t], m)
                 assert (ee == ee1).all() and (st3 == st1).all() and (st3 == o_st[:t]).all(), (ids, n, m)
         c.close()
+    # a lazy comb on every device of a context: each builds its own on the first fixed-base slice it is handed
+    c = d.Context([0, 0], comb_bits=18, comb_lazy=True)
+    assert [c.comb_info(i)[1] for i in (0, 1)] == [False, False]
+    k = rng.integers(0, 256, (1001, 32), dtype=np.uint8)
+    assert (c.scalar_mul_base(k) == oracle.scalar_mul_base(k)).all()
+    assert [c.comb_info(i)[1] for i in (0, 1)] == [True, True] and c.comb_info(1)[0] == 18
+    c.close()
 
 
 def test_field_regression_seeds_gpu(ctx, oracle, kats):
