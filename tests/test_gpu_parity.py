@@ -1990,13 +1990,24 @@ def test_dev_calls_capture_into_a_hip_graph(ctx, oracle, torch_mod):
     enc = torch.empty((n, 32), dtype=torch.uint8, device=dev)
     out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
     st = torch.empty((n,), dtype=torch.uint8, device=dev)
+    # the small sums on both of their kernels: 128 four-term sums (a wave per sum), 5 000 two-term sums (a lane per sum: table scratch)
+    n2 = 10000
+    r2 = torch.from_numpy(rng.integers(0, 256, (n2, 32), dtype=np.uint8)).to(dev)
+    k2 = torch.from_numpy(rng.integers(0, 256, (n2, 32), dtype=np.uint8)).to(dev)
+    enc2 = torch.empty((n2, 32), dtype=torch.uint8, device=dev)
+    s4, s4x, s4st = (torch.empty(sh, dtype=dt, device=dev) for sh, dt in (((n // 4, 32), torch.uint8), ((n // 4, 16), torch.int64), ((n,), torch.uint8)))
+    s2, s2st = torch.empty((n2 // 2, 32), dtype=torch.uint8, device=dev), torch.empty((n2,), dtype=torch.uint8, device=dev)
     ctx.encode_to_curve(r0, outs=[enc]); ctx.scalar_mul_var(enc, k, outs=[out, st]); ctx.msm(enc, k)      # warm up: grow every workspace
+    ctx.encode_to_curve(r2, outs=[enc2]); ctx.msm_small(enc2, k2, 2, outs=[s2, s2st])
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         ctx.encode_to_curve(r0, outs=[enc])
         ctx.scalar_mul_var(enc, k, outs=[out, st])
         m_enc, _, m_st = ctx.msm(enc, k)
+        ctx.msm_small(enc, k, 4, outs=[s4, s4x, s4st], elements=True)
+        ctx.encode_to_curve(r2, outs=[enc2])
+        ctx.msm_small(enc2, k2, 2, outs=[s2, s2st])
     for rep in range(3):
         r0.copy_(torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
         k.copy_(torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)))
@@ -2008,3 +2019,13 @@ def test_dev_calls_capture_into_a_hip_graph(ctx, oracle, torch_mod):
         assert (out.cpu().numpy() == o_out).all() and not st.cpu().numpy().any()
         xyzt, _ = oracle.decompress(e_h)
         assert bytes(m_enc.cpu().numpy()) == bytes(oracle.msm(xyzt, k.cpu().numpy())[0])
+        r2.copy_(torch.from_numpy(rng.integers(0, 256, (n2, 32), dtype=np.uint8)))
+        k2.copy_(torch.from_numpy(rng.integers(0, 256, (n2, 32), dtype=np.uint8)))
+        g.replay()
+        torch.cuda.synchronize()
+        got4, got4x, got2 = s4.clone(), s4x.clone(), s2.clone()
+        e4, e4st = ctx.msm_small(enc, k, 4)                                        # eager calls on what the replay left in enc / enc2
+        e2, e2st = ctx.msm_small(enc2, k2, 2)
+        assert torch.equal(got4, e4) and torch.equal(ctx.compress(got4x), e4) and torch.equal(got2, e2)
+        assert not s4st.any() and not s2st.any() and not e4st.any() and not e2st.any()
+        assert (enc2.cpu().numpy()[:64] == oracle.encode_to_curve(r2.cpu().numpy()[:64])).all()
