@@ -68,6 +68,17 @@ def main():
     k[6000:6016] = kat["scalars"].repeat(4, 1)
     out, st = ctx.scalar_mul_var(pts, k)
     check("scalar_mul_var", (out, st), "scalar_mul_var", pts, k)
+    # the same (point, scalar) pairs as three-term sums (d377_batch_msm_small on Encodings; an invalid one drops out of its sum):
+    # the oracle folds its own products -- a failed product is the zero string, the identity's Encoding
+    ns = min(n // 3, 1 << 18)
+    t0 = time.time()
+    se, sx, sst = ctx.msm_small(pts[: 3 * ns], k[: 3 * ns], 3, elements=True)
+    prod, pst, _ = orc.run_threads("scalar_mul_var", pts[: 3 * ns].cpu().numpy(), k[: 3 * ns].cpu().numpy(), threads)
+    terms = orc.decompress(prod)[0]
+    fold = orc.compress(orc.add_xyzt(orc.add_xyzt(terms[0::3], terms[1::3]), terms[2::3]))
+    ok = bool((se.cpu().numpy() == fold).all()) and bool((sst.cpu().numpy() == pst).all()) and bool(torch.equal(ctx.compress(sx), se))
+    print("%-18s n = %9d  %s  (three-term sums, Encodings and Element records; oracle %.1f s)" % ("msm_small", ns, "bit-exact" if ok else "MISMATCH", time.time() - t0), flush=True)
+    bad += 0 if ok else 1
     kb = k[: n // 2]
     check("scalar_mul_base", (ctx.scalar_mul_base(kb),), "scalar_mul_base", kb, None)
     raw = torch.cat([enc[: n // 2], rnd(n // 2)])
