@@ -1020,7 +1020,9 @@ def test_soak_tool_small():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "14", "7"], cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("bit-exact") == 9 and "MISMATCH" not in r.stdout      # 9 legs (the small sums among them)
+    legs = [l for l in r.stdout.splitlines() if " n = " in l]
+    assert len(legs) >= 9 and all("bit-exact" in l for l in legs) and "MISMATCH" not in r.stdout, r.stdout   # every leg the tool has (9 today)
+    assert any(l.startswith("msm_small") for l in legs) and any(l.startswith("hash_to_curve") for l in legs)
 
 
 def test_full_size_var_base_2_22(ctx, torch_mod, oracle):
